@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- MPC QP solves/sec on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+    python bench.py [--gpus N --steps K --warmup W]            (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic instances per GPU: the compact
+(reference call pattern) form, horizon 20, 2 inputs, 262 144 instances per GPU (BASELINE config 3;
+at N=8 that is config 4's 2 097 152), inputs resident in HBM before the timed region.  The instance
+batch is embarrassingly parallel, so ranks shard it with no data-path collective during the solve;
+for N>1 the control outputs are all-gathered over RCCL inside the timed region (north_star).
+
+`value` is measured in fp64, the only dtype that meets the 1e-6 parity target (SURVEY.md section 0
+fact 3); the fp32 rate of the same workload is reported beside it under "fp32" with its error
+histogram against the fp64 result.  `roofline` prices the dominant kernel against HBM as the
+contract asks (this path moves 40 B per solve, so that fraction is tiny by construction), and
+"alu" prices the same kernel against the FP64 vector peak with ALGORITHMIC flops
+((46H-16) x mean iterations).  `cpu_baseline` is the real dlib path
+(oracle/_ref, kind "reference") or, where that build is absent, the C restatement (kind "port"),
+timed on this host's cores on a bounded sample; the GPU outputs of that sample are compared with
+it and the result is reported as "max_abs_du_vs_dlib".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VECTOR_PEAK_TF = 78.6     # MI355X vendor FP64 vector peak
+FP32_VECTOR_PEAK_TF = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=262144, help="instances per GPU")
+    ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--algo", default="auto", choices=["auto", "lane", "wave"])
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(H, v, dy, dphi, budget_s):
+    """Time the dlib CPU path on this host's cores on a bounded sample of the workload.
+    Returns (dict for the JSON line, sample size, reference outputs)."""
+    from oracle import bindings as ob
+    cores = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+        cores = min(cores, aff)
+    except Exception:
+        pass
+    if os.path.exists(ob.REF_SO):
+        ref, kind = ob.DlibRef(ob.REF_SO), "reference"
+        run = lambda n, th: ref.solve_compact(H, v[:n], dy[:n], dphi[:n], nthreads=th)
+    else:
+        orc, kind = ob.Oracle(), "port"
+        run = lambda n, th: orc.solve_compact(H, v[:n], dy[:n], dphi[:n], nthreads=th)[:2]
+    # probe one thread to size the sample for ~budget_s of wall time on all cores
+    probe = 128
+    t0 = time.perf_counter()
+    run(probe, 1)
+    per = (time.perf_counter() - t0) / probe
+    n = int(min(len(v), max(cores * 64, budget_s * cores / per)))
+    n -= n % 64
+    t0 = time.perf_counter()
+    f, r = run(n, cores)
+    dt = time.perf_counter() - t0
+    return ({"value": n / dt, "unit": "solves/s", "cores": cores, "kind": kind,
+             "per_core": n / dt / cores,
+             "sample": f"first {n} instances of the workload (H={H}, fp64, cold start), "
+                       f"{cores} threads, {dt:.1f} s"}, n, f, r)
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from trajectory_controller_amd import MpcSolver
+    from trajectory_controller_amd.synth import compact_inputs
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    H, n = a.horizon, a.batch
+    # weak scaling: rank r owns instances [r*n, (r+1)*n) of the horizon-H stream
+    v, dy, dphi = compact_inputs(H, n, first=rank * n)
+    tdt = torch.float64 if a.dtype == "f64" else torch.float32
+    tv, ty, tp = (torch.from_numpy(x).to(dev, dtype=tdt) for x in (v, dy, dphi))
+    front, rear = torch.empty_like(tv), torch.empty_like(tv)
+    iters_t = None
+    if world > 1:
+        gathered = torch.empty((world, 2, n), dtype=tdt, device=dev)
+        mine = torch.empty((2, n), dtype=tdt, device=dev)
+
+    solver = MpcSolver(horizon=H, device=local_rank, dtype=a.dtype, algo=a.algo)
+    solver.set_profiling(True)
+
+    def step():
+        if world > 1:
+            solver.solve_batch_compact(tv, ty, tp, out=(mine[0], mine[1]), want_flags=False)
+            dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1))   # RCCL over xGMI
+        else:
+            solver.solve_batch_compact(tv, ty, tp, out=(front, rear), want_flags=False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    k1 = k2 = 0.0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+        # HIP events the library recorded on the launch stream around each kernel; reading them
+        # waits for this step's kernels, which the step would do at the next sync anyway
+        x1, x2, algo_ran = solver.last_kernel_times()
+        k1 += x1
+        k2 += x2
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        front, rear = mine[0], mine[1]
+
+    if rank == 0:
+        # iteration statistics of this rank's shard (for the algorithmic-flop figure)
+        _, _, iters_t = solver.solve_batch_compact(tv, ty, tp, want_iters=True)
+        torch.cuda.synchronize()
+        mean_iters = float(iters_t.double().mean().item())
+        esz = 8 if a.dtype == "f64" else 4
+        total = world * n * a.steps
+        value = total / elapsed
+        # dominant kernel = the longer of the two launches of a step
+        dom_ms = max(k1, k2) / a.steps
+        dom_name = {1: "wave_kernel", 2: "lane_pg_kernel" if k2 >= k1 else "lane_cd_kernel"}[algo_ran]
+        alg_bytes = 5 * esz * n                       # 3 in + 2 out scalars per solve
+        # the PG kernel also reads what the CD kernel left per instance (not algorithmic traffic)
+        hbm_gbs = alg_bytes / (dom_ms * 1e-3) / 1e9
+        alg_flops = (46 * H - 16) * mean_iters * n
+        tfl = alg_flops / ((k1 + k2) / a.steps * 1e-3) / 1e12
+        peak_tf = FP64_VECTOR_PEAK_TF if a.dtype == "f64" else FP32_VECTOR_PEAK_TF
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tj):
+            try:
+                traffic = json.load(open(tj)).get(f"{dom_name}_{a.dtype}_H{H}_n{n}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MPC QP solves/sec (horizon N=20, 2 inputs) at 1/2/4/8 MI355X; max|du| vs dlib",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"batch {n} trajectories per GPU, N={H}, 2 inputs, compact "
+                                   f"(mpcControllerTobi) form, cold start, eps 0.01, max_iter 10000",
+                       "global_batch": world * n, "horizon": H, "algo": {1: "wave", 2: "lane"}[algo_ran],
+                       "parallelism": f"batch-sharded x{world}"},
+            "kernel_ms": {"first": k1 / a.steps, "second": k2 / a.steps, "dominant": dom_name},
+            "mean_iterations": mean_iters,
+            "roofline": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "note": "40 B/solve algorithmic: this path is issue-bound, not HBM-bound; see alu"},
+            "alu": {"bound": "fp64 vector issue" if a.dtype == "f64" else "fp32 vector issue",
+                    "achieved": tfl, "peak": peak_tf, "unit": "TFLOP/s", "frac": tfl / peak_tf,
+                    "flops_per_solve": (46 * H - 16) * mean_iters},
+        }
+        if not a.no_cpu:
+            cb, ns, cf, cr = cpu_baseline(H, v, dy, dphi, a.cpu_seconds)
+            gf, gr = front[:ns].cpu().numpy().astype(np.float64), rear[:ns].cpu().numpy().astype(np.float64)
+            out["cpu_baseline"] = cb
+            out["max_abs_du_vs_dlib"] = float(max(np.abs(gf - cf).max(), np.abs(gr - cr).max()))
+            out["gpu_over_cpu"] = value / cb["value"]
+        if not a.no_fp32 and a.dtype == "f64":
+            s32 = MpcSolver(horizon=H, device=local_rank, dtype="f32", algo=a.algo)
+            v32, y32, p32 = tv.float(), ty.float(), tp.float()
+            s32.solve_batch_compact(v32, y32, p32, want_flags=False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                f32, r32 = s32.solve_batch_compact(v32, y32, p32, want_flags=False)
+            torch.cuda.synchronize()
+            d32 = time.perf_counter() - t1
+            err = torch.maximum((f32.double() - front).abs(), (r32.double() - rear).abs())
+            out["fp32"] = {"value": n * a.steps / d32, "unit": "solves/s (1 GPU)",
+                           "within": {str(t): float((err <= t).double().mean().item())
+                                      for t in (1e-2, 1e-3, 1e-4, 1e-5, 1e-6)},
+                           "max_abs_du_vs_fp64": float(err.max().item())}
+            s32.close()
+        print(json.dumps(out), flush=True)
+    solver.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

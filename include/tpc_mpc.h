@@ -1,0 +1,182 @@
+/* tpc_mpc.h -- C ABI of the MI355X-native batched MPC-QP solver (libtpc_mpc.so).
+ *
+ * This is the drop-in boundary for ONE path of lms-org/trajectory_controller: the per-cycle
+ * box-constrained MPC QP that TrajectoryPointController::mpcControllerTobi solves through
+ * dlib::mpc<2,2,H>::operator().  Every entry point names the reference interface it replaces
+ * (paths relative to the reference tree).  The library reproduces dlib's iteration sequence
+ * (coordinate descent for `smo_iters` iterations, then accelerated projected gradient, stop when
+ * the largest free gradient component is < eps), so in fp64 its outputs equal the reference's.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types; no exception crosses this boundary.
+ *   - every function returns a tpc_mpc_status (0 = ok); tpc_mpc_last_error() gives text.
+ *   - the solve runs on the GPU.  There is no CPU fallback: without a usable gfx950 device
+ *     tpc_mpc_create fails with TPC_MPC_ERR_NO_DEVICE.
+ *   - a handle is not thread-safe; distinct handles are independent.  The library never keeps a
+ *     caller pointer past the call that received it.
+ *   - batch arrays are structure-of-arrays: component c of instance k lives at base[c*ld + k]
+ *     (`ld` >= n is the leading dimension, normally n; a shard of a larger batch passes the
+ *     shard's base pointer and the full batch's ld).  Element type is `dtype` (double or float).
+ */
+#ifndef TPC_MPC_H
+#define TPC_MPC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TPC_MPC_ABI_VERSION 1
+
+typedef struct tpc_mpc_context* tpc_mpc_handle;
+
+typedef enum tpc_mpc_status {
+    TPC_MPC_OK = 0,
+    TPC_MPC_ERR_BAD_ARG = 1,        /* null pointer, n < 0, ld < n, unknown enum value          */
+    TPC_MPC_ERR_BAD_WEIGHTS = 2,    /* min(Q) < 0 or min(R) <= 0   (mpc_abstract.h:90-97)       */
+    TPC_MPC_ERR_BAD_BOUNDS = 3,     /* upper < lower               (mpc_abstract.h:90-97)       */
+    TPC_MPC_ERR_BAD_HORIZON = 4,    /* horizon not one of tpc_mpc_supported_horizons()          */
+    TPC_MPC_ERR_BAD_EPS = 5,        /* eps <= 0                    (mpc.h:202 set_epsilon)      */
+    TPC_MPC_ERR_NO_DEVICE = 6,      /* no gfx950 GPU / HIP runtime unusable                     */
+    TPC_MPC_ERR_HIP = 7,            /* a HIP call failed; text in tpc_mpc_last_error            */
+    TPC_MPC_ERR_ALLOC = 8
+} tpc_mpc_status;
+
+typedef enum tpc_mpc_dtype { TPC_MPC_F64 = 0, TPC_MPC_F32 = 1 } tpc_mpc_dtype;
+
+/* Where batch arrays live. */
+typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_memory;
+
+/* Kernel family.
+ *   WAVE : one 64-lane wavefront per instance; lane j owns decision variable j, the dense
+ *          (I*H)x(I*H) Hessian column block is staged through LDS, reductions by wavefront
+ *          shuffles.  Lowest latency; used for small batches and solve_one.
+ *   LANE : one lane per instance, dlib's O(H) recurrences unrolled in registers, 64 instances
+ *          per wavefront with dynamic refill of finished lanes.  Bit-identical to the reference
+ *          arithmetic in fp64; highest throughput on large batches.
+ *   AUTO : LANE when the batch fills the chip, WAVE otherwise. */
+typedef enum tpc_mpc_algo { TPC_MPC_ALGO_AUTO = 0, TPC_MPC_ALGO_WAVE = 1, TPC_MPC_ALGO_LANE = 2 } tpc_mpc_algo;
+
+/* Non-fatal per-call flags, OR-ed into *flags_out (may be NULL). */
+#define TPC_MPC_FLAG_NONFINITE 0x1u  /* an instance had NaN/Inf inputs: it returns the untouched
+                                        start point like dlib does (every NaN comparison is
+                                        false, mpc.h:298-311) and this flag is raised           */
+#define TPC_MPC_FLAG_MAX_ITER  0x2u  /* an instance stopped on max_iter, not on eps             */
+
+/* Solver knobs.  Defaults (tpc_mpc_default_params) are dlib's and the reference module's:
+ *   eps 0.01 (mpc.h:104), max_iter 10000 (mpc.h:103), smo_iters 50 (mpc.h:319),
+ *   step_size 0.1 (src/trajectory_point_follower.cpp:96), wheelbase 0.21
+ *   (include/trajectory_point_follower.h:47), weights 20/7/0.0005/10
+ *   (src/trajectory_point_follower.cpp:92-95), bounds +-22 deg (src/...follower.cpp:16-18). */
+typedef struct tpc_mpc_params {
+    int32_t horizon;          /* H: MPC_HORIZON, include/trajectory_point_follower.h:48          */
+    int32_t dtype;            /* tpc_mpc_dtype of the batch arrays and of the arithmetic          */
+    int32_t algo;             /* tpc_mpc_algo                                                     */
+    int32_t reserved;
+    double eps;               /* dlib::mpc::set_epsilon        (mpc.h:197-208)                    */
+    uint64_t max_iter;        /* dlib::mpc::set_max_iterations (mpc.h:190-195)                    */
+    uint64_t smo_iters;       /* mpc.h:319                                                        */
+    /* compact ("reference pattern") model, used by solve_one / solve_batch_compact only:         */
+    double step_size;         /* mpcParameters.stepSize  T                                        */
+    double wheelbase;         /* l                                                                */
+    double weight_y, weight_phi, weight_steering_front, weight_steering_rear;
+    double lower[2], upper[2];
+} tpc_mpc_params;
+
+/* ---- lifetime --------------------------------------------------------------------------------- */
+
+/* Fill *p with the defaults above for horizon H, fp64, algo AUTO. */
+int tpc_mpc_default_params(tpc_mpc_params* p, int horizon);
+
+/* Create a solver bound to HIP device `device` (>= 0).  Owns device scratch; no other state. */
+int tpc_mpc_create(int device, tpc_mpc_handle* out);
+int tpc_mpc_destroy(tpc_mpc_handle h);
+
+/* Text of the last error on this handle (or of the last failed create when h == NULL). */
+const char* tpc_mpc_last_error(tpc_mpc_handle h);
+
+/* Writes up to `cap` supported horizons, returns how many exist. */
+int tpc_mpc_supported_horizons(int* out, int cap);
+int tpc_mpc_abi_version(void);
+
+/* ---- the call being replaced ------------------------------------------------------------------ */
+
+/* Replaces the body of
+ *   void TrajectoryPointController::mpcControllerTobi(double v, double delta_y, double delta_phi,
+ *                                                      double* steering_front, double* steering_rear)
+ * (include/trajectory_point_follower.h:44, src/trajectory_point_follower.cpp:301-389): builds
+ * A=[1,Tv;0,1], B=[0,Tv;Tv/l,-Tv/l], C=0, Q, R from `p`, a fresh controller, one target
+ * (delta_y, delta_phi) for all steps, x0 = 0, cold start, and returns u0.  `v` is the speed AFTER
+ * the module's velocity lookup (src/...follower.cpp:323).  One instance on the GPU (WAVE kernel). */
+int tpc_mpc_solve_one(tpc_mpc_handle h, const tpc_mpc_params* p, double v, double delta_y,
+                      double delta_phi, double* steering_front, double* steering_rear);
+
+/* The same computation for n independent instances in one launch.  Arrays are `p->dtype`,
+ * length n, in `mem`.  `iters` (int32, optional) receives each instance's iteration count,
+ * `flags_out` (optional) the OR of the per-instance flags.  `stream` is a hipStream_t or NULL;
+ * with TPC_MPC_DEVICE memory the call is asynchronous on that stream unless flags_out != NULL
+ * (reading the flags synchronises). */
+int tpc_mpc_solve_batch_compact(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n,
+                                const void* v, const void* delta_y, const void* delta_phi,
+                                void* steering_front, void* steering_rear, int32_t* iters,
+                                uint32_t* flags_out, int mem, void* stream);
+
+/* ---- the general dlib::mpc<2,I,H> surface ------------------------------------------------------- */
+
+/* Per-instance model and state, SoA with leading dimension ld (see header comment):
+ *   A[4]  row-major 2x2          B[2*I] row-major 2xI       C[2]  Q[2]  R[I]  lower[I]  upper[I]
+ *   x0[2] current_state          targets[H*2]  (step t, state s at component 2*t+s;
+ *                                               dlib::mpc::set_target(val,time), mpc.h:142-155)
+ *   controls_inout[H*I] optional: the controller's stored controls (mpc.h:363).  As in
+ *        operator() (mpc.h:229-239) they are shifted left by one step before the solve (warm
+ *        start); on return they hold the solved sequence.  NULL = fresh controller (zeros).
+ *   v_inout[H*I] optional: dlib's accelerated-gradient memory (mpc.h:250), which persists across
+ *        calls of one controller object.  NULL = zeros in, not written.
+ *   u0[I] out: controls[0], what operator() returns.
+ * The caller shifts `targets` between calls (mpc.h:236-237) -- tpc_mpc_rollout does it on device. */
+typedef struct tpc_mpc_general_io {
+    int32_t inputs;           /* I: 1 or 2 */
+    int32_t reserved;
+    int64_t n, ld;
+    const void *A, *B, *C, *Q, *R, *lower, *upper, *x0, *targets;
+    void *controls_inout, *v_inout;
+    void* u0;
+    int32_t* iters;           /* optional */
+} tpc_mpc_general_io;
+
+/* Replaces: dlib::mpc<2,I,H> ctor (mpc.h:51-125) + set_target (mpc.h:142-155) + operator()
+ * (mpc.h:216-240) for n independent controllers.  Uses p->horizon, dtype, algo, eps, max_iter,
+ * smo_iters; the compact-model fields of `p` are ignored. */
+int tpc_mpc_solve_batch_general(tpc_mpc_handle h, const tpc_mpc_params* p,
+                                const tpc_mpc_general_io* io, uint32_t* flags_out, int mem,
+                                void* stream);
+
+/* Closed loop on device: `steps` successive operator() calls per controller with warm start and
+ * target shift (mpc.h:229-239), plant update x <- A x + B u + C between calls (the loop of
+ * dlib_files/dlib/test/mpc.cpp:301-316).  io->x0 is the initial state and is left untouched;
+ * io->targets holds the initial H targets; new_last_targets (optional, SoA [steps*2] per
+ * instance) supplies set_last_target() values for steps >= 1 (NULL repeats the last target).
+ * controls_out: SoA [steps*I]; states_out (optional): SoA [steps*2]; iters_out (optional, int32):
+ * SoA [steps].  io->controls_inout / v_inout (optional) carry the controller state in and out. */
+int tpc_mpc_rollout(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mpc_general_io* io,
+                    int32_t steps, const void* new_last_targets, void* controls_out,
+                    void* states_out, int32_t* iters_out, uint32_t* flags_out, int mem,
+                    void* stream);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+
+/* No reference counterpart (the reference times nothing on this branch; its only timers are
+ * logger.time("mikMPC") around the other back-end, src/trajectory_point_follower.cpp:134,213).
+ * With profiling on, every solve records HIP events on its launch stream around each kernel;
+ * tpc_mpc_last_kernel_times waits for the last solve and returns the two kernel durations in ms
+ * (LANE: coordinate-descent kernel, projected-gradient kernel; WAVE: the one kernel, 0) and the
+ * tpc_mpc_algo that ran. */
+int tpc_mpc_set_profiling(tpc_mpc_handle h, int enable);
+int tpc_mpc_last_kernel_times(tpc_mpc_handle h, double* first_ms, double* second_ms, int* algo);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TPC_MPC_H */

@@ -1,0 +1,311 @@
+"""Parity tests proper (`-m gpu`): the HIP path, called through the C ABI, against
+  * the golden vectors generated from the REAL dlib::mpc (tests/golden/), and
+  * the pinned CPU oracle on seeded inputs,
+plus size-independent properties at BASELINE.json's full batch sizes.
+
+Tolerances (stated once, used below):
+  LANE kernels, fp64 : bit-exact (max |du| == 0) and identical iteration counts -- they execute
+                       dlib's own operation sequence.
+  WAVE kernel,  fp64 : |du| <= 1e-9 absolute (=> <= 1e-6 relative for every |u| >= 1e-3; bounds are
+                       +-0.384) and identical iteration counts; observed ~1e-11.
+  fp32 (either)      : a throughput / tolerance-sweep mode, not a parity mode (SURVEY.md section 0
+                       fact 3): only loose sanity bounds are asserted, the histogram is reported.
+"""
+import numpy as np
+import pytest
+
+from conftest import bits_equal, load_golden
+
+pytestmark = pytest.mark.gpu
+
+WAVE_ATOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch
+
+
+def _solver(H, algo, dtype="f64", **kw):
+    from trajectory_controller_amd import MpcSolver
+    return MpcSolver(horizon=H, device=0, dtype=dtype, algo=algo, **kw)
+
+
+def _dev(torch, *arrs, dtype=None):
+    return [torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0", dtype=dtype) for a in arrs]
+
+
+def _soa(a):
+    """AoS [n, ...] -> component-major [comps, n] (the ABI's layout)."""
+    a = np.asarray(a)
+    return np.ascontiguousarray(a.reshape(a.shape[0], -1).T)
+
+
+# ---------------------------------------------------------------------------------------------
+# compact form (the reference module's own call pattern) against real-dlib golden vectors
+
+@pytest.mark.parametrize("H", [4, 5, 10, 20, 40])
+@pytest.mark.parametrize("algo", ["lane", "wave"])
+def test_compact_golden(torch_cuda, H, algo):
+    if algo == "wave" and 2 * H > 64:
+        pytest.skip("WAVE kernel covers inputs*horizon <= 64")
+    torch = torch_cuda
+    g = load_golden(f"compact_H{H}.npz")
+    v, dy, dphi = _dev(torch, g["v"], g["dy"], g["dphi"])
+    with _solver(H, algo) as s:
+        f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+        torch.cuda.synchronize()
+        f, r, it = f.cpu().numpy(), r.cpu().numpy(), it.cpu().numpy()
+        assert s.last_flags & 1 == 0
+    if algo == "lane":
+        assert bits_equal(f, g["front"]) and bits_equal(r, g["rear"])
+    else:
+        assert np.abs(f - g["front"]).max() <= WAVE_ATOL
+        assert np.abs(r - g["rear"]).max() <= WAVE_ATOL
+    known = g["iters_lb"] >= 0
+    assert np.all(it[known] >= g["iters_lb"][known])
+
+
+@pytest.mark.parametrize("H", [4, 10, 20])
+@pytest.mark.parametrize("algo", ["lane", "wave"])
+def test_compact_vs_oracle_iters(torch_cuda, oracle, H, algo):
+    """Fresh seeded inputs (not the fixture ones): outputs AND iteration counts against the oracle."""
+    from trajectory_controller_amd.synth import compact_inputs
+    torch = torch_cuda
+    n = 3000   # not a multiple of 64: exercises the ragged last wavefront
+    v, dy, dphi = compact_inputs(H, n, first=100000)
+    of, orr, oit = oracle.solve_compact(H, v, dy, dphi, nthreads=8)
+    tv, ty, tp = _dev(torch, v, dy, dphi)
+    with _solver(H, algo) as s:
+        f, r, it = s.solve_batch_compact(tv, ty, tp, want_iters=True)
+        f, r, it = f.cpu().numpy(), r.cpu().numpy(), it.cpu().numpy()
+    assert np.array_equal(it, oit)
+    if algo == "lane":
+        assert bits_equal(f, of) and bits_equal(r, orr)
+    else:
+        assert max(np.abs(f - of).max(), np.abs(r - orr).max()) <= WAVE_ATOL
+
+
+@pytest.mark.parametrize("algo", ["lane", "wave"])
+def test_compact_knobs(torch_cuda, algo):
+    """eps = 0.05, max_iter = 300: the knobs commented out at src/trajectory_point_follower.cpp:374-375."""
+    torch = torch_cuda
+    g = load_golden("compact_knobs_H10.npz")
+    v, dy, dphi = _dev(torch, g["v"], g["dy"], g["dphi"])
+    with _solver(10, algo, eps=float(g["eps"]), max_iter=int(g["max_iter"])) as s:
+        f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+        f, r, it = f.cpu().numpy(), r.cpu().numpy(), it.cpu().numpy()
+    assert it.max() <= 300
+    if algo == "lane":
+        assert bits_equal(f, g["front"]) and bits_equal(r, g["rear"])
+    else:
+        assert max(np.abs(f - g["front"]).max(), np.abs(r - g["rear"]).max()) <= WAVE_ATOL
+
+
+@pytest.mark.parametrize("H", [4, 20])
+@pytest.mark.parametrize("algo", ["lane", "wave"])
+def test_compact_edge_cases(torch_cuda, H, algo):
+    """NaN inputs, zero target, saturating targets, crawling and very fast speeds (host-memory path)."""
+    from trajectory_controller_amd import FLAG_NONFINITE
+    g = load_golden("compact_edge.npz")
+    with _solver(H, algo) as s:
+        f, r, it = s.solve_batch_compact(g["v"], g["dy"], g["dphi"], want_iters=True)
+        flags = s.last_flags
+    if algo == "lane":
+        assert bits_equal(f, g[f"front_H{H}"]) and bits_equal(r, g[f"rear_H{H}"])
+    else:
+        assert np.nanmax(np.abs(f - g[f"front_H{H}"])) <= WAVE_ATOL
+        assert np.nanmax(np.abs(r - g[f"rear_H{H}"])) <= WAVE_ATOL
+    # NaN -> the untouched start point (0,0) at iteration 0, and the non-fatal flag is raised
+    assert np.all(f[:4] == 0) and np.all(r[:4] == 0) and np.all(it[:4] == 0)
+    assert flags & FLAG_NONFINITE
+
+
+def test_empty_and_tiny_batches(torch_cuda):
+    torch = torch_cuda
+    with _solver(10, "auto") as s:
+        f, r = s.solve_batch_compact(np.empty(0), np.empty(0), np.empty(0))
+        assert f.shape == (0,) and r.shape == (0,)
+        e = torch.empty(0, dtype=torch.float64, device="cuda:0")
+        f, r = s.solve_batch_compact(e, e, e)
+        assert f.numel() == 0
+        f, r = s.solve_batch_compact(np.array([1.0]), np.array([0.1]), np.array([0.05]))
+        assert abs(f[0] - 0.34964671107011402) < 1e-9 and abs(r[0] - 0.075655735449909028) < 1e-9
+
+
+def test_solve_one_reference_samples(torch_cuda):
+    """Sample outputs of the real reference recorded in SURVEY.md Appendix B."""
+    samples = [(4, 1.0, 0.1, 0.05, 0.28258865451261717, 0.059891817493776013),
+               (10, 1.0, 0.1, 0.05, 0.34964671107011402, 0.075655735449909028),
+               (20, 2.0, -0.2, 0.1, -0.34544297733739515, -0.21765810887303699),
+               (40, 0.5, 0.05, -0.3, -0.11433869614255573, 0.16123074991160702)]
+    for H, v, dy, dphi, ef, er in samples:
+        with _solver(H, "auto") as s:
+            f, r = s.mpc_controller_tobi(v, dy, dphi)
+        assert abs(f - ef) <= WAVE_ATOL and abs(r - er) <= WAVE_ATOL, (H, f, r)
+
+
+def test_bad_arguments(torch_cuda):
+    from trajectory_controller_amd import MpcSolver, TpcMpcError
+    with pytest.raises(TpcMpcError) as e:
+        MpcSolver(horizon=7)
+    assert e.value.status == 4
+    with MpcSolver(horizon=10) as s:
+        one = (np.array([1.0]), np.array([0.1]), np.array([0.05]))
+        for over, status in ((dict(weight_steering_rear=0.0), 2), (dict(weight_y=-1.0), 2),
+                             (dict(lower=(0.5, 0.5), upper=(0.1, 0.1)), 3), (dict(eps=0.0), 5)):
+            with pytest.raises(TpcMpcError) as e:
+                s.solve_batch_compact(*one, **over)
+            assert e.value.status == status, over
+    with MpcSolver(horizon=40, algo="wave") as s:
+        with pytest.raises(TpcMpcError) as e:
+            s.solve_batch_compact(*one)
+        assert e.value.status == 4
+
+
+# ---------------------------------------------------------------------------------------------
+# general dlib::mpc<2,I,H> surface
+
+@pytest.mark.parametrize("I", [1, 2])
+@pytest.mark.parametrize("H", [5, 10, 20])
+@pytest.mark.parametrize("algo", ["lane", "wave"])
+def test_general_golden(torch_cuda, I, H, algo):
+    torch = torch_cuda
+    g = load_golden(f"general_I{I}_H{H}.npz")
+    names = ["A", "B", "C", "Q", "R", "lo", "hi", "x0", "targets"]
+    dev = _dev(torch, *[_soa(g[k]) for k in names])
+    with _solver(H, algo) as s:
+        u0 = s.solve_batch_general(*dev, inputs=I)
+        u0 = u0.cpu().numpy()
+    if algo == "lane":
+        assert bits_equal(u0.T, g["u0"])
+    else:
+        assert np.abs(u0.T - g["u0"]).max() <= WAVE_ATOL
+
+
+@pytest.mark.parametrize("algo", ["lane", "wave"])
+def test_general_warm_start_vs_oracle(torch_cuda, oracle, algo):
+    """controls_inout: the warm-start shift (mpc.h:231-232) and the full solved sequence."""
+    from trajectory_controller_amd.synth import general_inputs
+    I, H, n = 2, 10, 777
+    g = general_inputs(H, n, I=I, first=4242)
+    rng = np.random.default_rng(5)
+    cin = rng.uniform(-0.3, 0.3, size=(n, H, I))
+    u0, cout, it = oracle.solve_general(I, H, g["A"], g["B"], g["C"], g["Q"], g["R"], g["lo"], g["hi"],
+                                        g["x0"], g["targets"], controls_in=cin, nthreads=8)
+    names = ["A", "B", "C", "Q", "R", "lo", "hi", "x0", "targets"]
+    host = [_soa(g[k]) for k in names]
+    controls = _soa(cin)
+    with _solver(H, algo) as s:
+        gu0, git = s.solve_batch_general(*host, controls=controls, inputs=I, want_iters=True)
+    assert np.array_equal(git, it)
+    if algo == "lane":
+        assert bits_equal(gu0.T, u0) and bits_equal(controls.T.reshape(n, H, I), cout)
+    else:
+        assert np.abs(gu0.T - u0).max() <= WAVE_ATOL
+        assert np.abs(controls.T.reshape(n, H, I) - cout).max() <= WAVE_ATOL
+
+
+# ---------------------------------------------------------------------------------------------
+# closed loop: warm start + target shift (mpc.h:229-239)
+
+@pytest.mark.parametrize("algo", ["lane", "wave"])
+def test_rollout_kat(torch_cuda, algo):
+    """The reference's own known-answer scenario (dlib_files/dlib/test/mpc.cpp:266-317):
+    mpc<2,1,30>, eps 1e-8, 30 warm-started closed-loop steps, against what real dlib produced."""
+    g = load_golden("rollout_kat.npz")
+    n = 3   # three identical controllers: also checks instances do not interfere
+    rep = lambda a: np.ascontiguousarray(np.repeat(np.asarray(a, dtype=np.float64).reshape(-1, 1), n, axis=1))
+    with _solver(30, algo, eps=1e-8, max_iter=10000) as s:
+        c, st, it = s.rollout(30, rep(g["A"]), rep(g["B"]), rep(g["C"]), rep(g["Q"]), rep(g["R"]),
+                              rep(g["lo"]), rep(g["hi"]), rep(g["x0"]), rep(g["targets0"].reshape(-1)),
+                              inputs=1, want_iters=True)
+    for k in range(n):
+        if algo == "lane":
+            assert bits_equal(c[:, k], g["controls"][:, 0]) and bits_equal(st[:, k], g["states"].reshape(-1))
+        else:
+            # dlib's own acceptance threshold for this scenario is 1e-7 (test/mpc.cpp:312)
+            assert np.abs(c[:, k] - g["controls"][:, 0]).max() <= 1e-7
+
+
+@pytest.mark.parametrize("algo", ["lane", "wave"])
+def test_rollout_i2(torch_cuda, algo):
+    g = load_golden("rollout_I2_H10.npz")
+    steps = int(g["steps"])
+    col = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1, 1))
+    with _solver(10, algo) as s:
+        c, st, _ = s.rollout(steps, col(g["A"]), col(g["B"]), col(g["C"]), col(g["Q"]), col(g["R"]),
+                             col(g["lo"]), col(g["hi"]), col(g["x0"]), col(g["targets0"].reshape(-1)),
+                             new_last_targets=col(g["new_last_targets"].reshape(-1)), inputs=2)
+    if algo == "lane":
+        assert bits_equal(c[:, 0], g["controls"].reshape(-1)) and bits_equal(st[:, 0], g["states"].reshape(-1))
+    else:
+        assert np.abs(c[:, 0] - g["controls"].reshape(-1)).max() <= 1e-7
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json sizes: size-independent properties
+
+def test_full_size_properties(torch_cuda):
+    """Batch 262 144, N=20, fp64 (BASELINE config 3 in its parity-grade dtype):
+    the first 1024 instances are the golden ones; solving a permutation of the batch permutes
+    the outputs bit-for-bit (no dependence on wave/lane placement or refill order); outputs obey
+    the bounds; a re-run is bit-identical."""
+    from trajectory_controller_amd.synth import compact_inputs
+    torch = torch_cuda
+    H, n = 20, 262144
+    g = load_golden("compact_H20.npz")
+    v, dy, dphi = compact_inputs(H, n)
+    tv, ty, tp = _dev(torch, v, dy, dphi)
+    with _solver(H, "auto") as s:
+        f, r, it = s.solve_batch_compact(tv, ty, tp, want_iters=True)
+        f2, r2 = s.solve_batch_compact(tv, ty, tp)
+        perm = torch.randperm(n, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(1))
+        fp, rp = s.solve_batch_compact(tv[perm].contiguous(), ty[perm].contiguous(), tp[perm].contiguous())
+        torch.cuda.synchronize()
+    assert bits_equal(f[:1024].cpu().numpy(), g["front"]) and bits_equal(r[:1024].cpu().numpy(), g["rear"])
+    assert torch.equal(f, f2) and torch.equal(r, r2)
+    assert torch.equal(f[perm], fp) and torch.equal(r[perm], rp)
+    amax = 22 * np.pi / 180
+    assert float(f.abs().max()) <= amax and float(r.abs().max()) <= amax
+    it = it.cpu().numpy()
+    assert it.min() >= 0 and it.max() <= 10000
+    # iteration statistics of the reference on this distribution: mean ~1031
+    assert 950 < it.mean() < 1100
+
+
+def test_lane_wave_agree_4096(torch_cuda):
+    """BASELINE config 2: batch 4096, N=10, fp64 -- both kernel families, same answers."""
+    from trajectory_controller_amd.synth import compact_inputs
+    torch = torch_cuda
+    v, dy, dphi = compact_inputs(10, 4096)
+    tv, ty, tp = _dev(torch, v, dy, dphi)
+    out = {}
+    for algo in ("lane", "wave"):
+        with _solver(10, algo) as s:
+            f, r, it = s.solve_batch_compact(tv, ty, tp, want_iters=True)
+            out[algo] = (f.cpu().numpy(), r.cpu().numpy(), it.cpu().numpy())
+    assert np.array_equal(out["lane"][2], out["wave"][2])
+    assert np.abs(out["lane"][0] - out["wave"][0]).max() <= WAVE_ATOL
+    assert np.abs(out["lane"][1] - out["wave"][1]).max() <= WAVE_ATOL
+
+
+@pytest.mark.parametrize("algo", ["lane", "wave"])
+def test_fp32_tolerance_sweep(torch_cuda, algo):
+    """BASELINE config 5 flavour: fp32 against the fp64 golden vectors.  fp32 cannot meet 1e-6
+    (SURVEY.md fact 3); the histogram is printed, only gross sanity is asserted."""
+    torch = torch_cuda
+    for H in (5, 10, 20):
+        g = load_golden(f"compact_H{H}.npz")
+        v, dy, dphi = _dev(torch, g["v"], g["dy"], g["dphi"], dtype=torch.float32)
+        with _solver(H, algo, dtype="f32") as s:
+            f, r = s.solve_batch_compact(v, dy, dphi)
+            f, r = f.cpu().numpy().astype(np.float64), r.cpu().numpy().astype(np.float64)
+        err = np.maximum(np.abs(f - g["front"]), np.abs(r - g["rear"]))
+        hist = {t: float(np.mean(err <= t)) for t in (1e-2, 1e-3, 1e-4, 1e-5, 1e-6)}
+        print(f"fp32 {algo} H={H}: fraction within tol {hist}")
+        assert np.all(np.isfinite(f)) and np.all(np.isfinite(r))
+        assert np.median(err) < 1e-3
+        assert hist[1e-2] > 0.5

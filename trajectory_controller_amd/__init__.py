@@ -1,0 +1,14 @@
+"""trajectory_controller_amd -- MI355X-native batched MPC-QP solver behind the
+TrajectoryPointController module surface of lms-org/trajectory_controller.
+
+Only the hot path lives here: csrc/ holds the gfx950 HIP kernels and the C ABI
+(include/tpc_mpc.h -> lib/libtpc_mpc.so); capi.py / solver.py are the host-side binding;
+host/ is the C++ module shim that keeps the LMS surface.  Nothing in this package imports
+oracle/ -- that directory is the checker used by tests/ and bench.py only.
+"""
+from .capi import (ALGO_AUTO, ALGO_LANE, ALGO_WAVE, F32, F64, FLAG_MAX_ITER, FLAG_NONFINITE,
+                   TpcMpcError, default_params, load_library)
+from .solver import MpcSolver
+
+__all__ = ["MpcSolver", "TpcMpcError", "default_params", "load_library", "ALGO_AUTO", "ALGO_WAVE",
+           "ALGO_LANE", "F64", "F32", "FLAG_NONFINITE", "FLAG_MAX_ITER"]

@@ -1,0 +1,65 @@
+// Internal launch interface between the C ABI (tpc_mpc_api.cpp) and the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tpc {
+
+constexpr int kWave = 64;   // CDNA4 wavefront width
+
+// Solver knobs shared by every kernel (fp64 on the host side; cast to T in the kernels).
+struct Knobs {
+    double eps;
+    uint32_t max_iter;
+    uint32_t smo_iters;
+};
+
+// Compact ("reference pattern") batch: model built from v per instance
+// (reference: src/trajectory_point_follower.cpp:326-333, :359-363).
+struct CompactArgs {
+    int64_t n;
+    const void *v, *dy, *dphi;     // [n]
+    void *front, *rear;            // [n]
+    int32_t* iters;                // [n] or null
+    uint32_t* flags;               // device word, OR-ed with TPC_MPC_FLAG_*, or null
+    double step, wheelbase;        // T, l
+    double q[2], r[2], lo[2], hi[2];
+};
+
+// General batch: SoA with leading dimension ld, component c of instance k at base[c*ld + k].
+struct GeneralArgs {
+    int64_t n, ld;
+    const void *A, *B, *C, *Q, *R, *lo, *hi, *x0, *targets;
+    void *controls, *v;            // in/out, may be null
+    void* u0;
+    int32_t* iters;
+    uint32_t* flags;
+    int shift_controls;            // 1: apply operator()'s warm-start shift (mpc.h:231-232)
+};
+
+// Device scratch owned by the handle (LANE kernels: state handed from the coordinate-descent
+// phase to the projected-gradient phase, and the work-queue ticket).
+struct Workspace {
+    void* state;        // [(2H + 2) * n] of T
+    uint32_t* ticket;   // 1 word
+    int64_t capacity_bytes;
+    // optional profiling: events recorded on the launch stream around each kernel
+    // (ev[0] .. ev[1] first kernel, ev[1] .. ev[2] second kernel); null when profiling is off
+    hipEvent_t* ev;
+};
+
+// Returns hipSuccess or the failing HIP error; *supported = 0 when (dtype,I,H) has no kernel.
+hipError_t launch_lane_compact(int dtype, int H, const CompactArgs& a, const Knobs& k,
+                               const Workspace& ws, hipStream_t s, int* supported);
+hipError_t launch_lane_general(int dtype, int I, int H, const GeneralArgs& a, const Knobs& k,
+                               const Workspace& ws, hipStream_t s, int* supported);
+hipError_t launch_wave_compact(int dtype, int H, const CompactArgs& a, const Knobs& k,
+                               hipStream_t s, int* supported);
+hipError_t launch_wave_general(int dtype, int I, int H, const GeneralArgs& a, const Knobs& k,
+                               hipStream_t s, int* supported);
+
+// bytes of Workspace::state the LANE kernels need for a batch
+int64_t lane_workspace_bytes(int dtype, int I, int H, int64_t n);
+
+}  // namespace tpc

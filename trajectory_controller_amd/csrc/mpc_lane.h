@@ -1,0 +1,307 @@
+// LANE kernels: one lane per MPC instance, 64 instances per wavefront, everything in VGPRs.
+//
+// Two launches per batch, both bit-faithful to dlib::mpc::solve_linear_mpc (mpc.h:253-347):
+//
+//   lane_cd_kernel  coordinate-descent phase (iter < smo_iters, mpc.h:319-335).  Every lane of a
+//                   wave runs the same <= smo_iters iterations in lockstep, so there is no
+//                   divergence to manage.  Q_diag sits in LDS ([var][lane], conflict-free) because
+//                   it is read at a per-lane dynamic index.  Leaves {controls, lambda, iter} of
+//                   each instance in a per-instance record in HBM.
+//   lane_pg_kernel  accelerated projected-gradient phase (mpc.h:336-345).  Iteration counts
+//                   differ 30x between instances, so waves are persistent
+//                   and a lane whose instance has converged pulls the next unfinished instance
+//                   from an atomic ticket: no lane waits for the slowest instance of its wave.
+//
+// Storage at H=20, fp64 (per lane): controls u and the M/df work array w live in VGPRs (2 x 40
+// doubles = 160 of the 256 VGPRs a VALU instruction can address); the linear term MM and the
+// accelerated-gradient memory v live in LDS as [var][lane] columns (2 x 20 KB per wave,
+// conflict-free, touched only by their own lane, so no barrier is ever needed).  4 waves x 40 KB
+// fill the CU's 160 KB LDS exactly: one wave per SIMD, where every instruction of a wave issues
+// in 4 cycles -- the fp64 VALU rate -- so the DP pipe is the bound.
+#pragma once
+
+#include "mpc_model.h"
+
+namespace tpc {
+
+// Per-instance record handed from the CD phase to the PG phase:
+//   rec[0 .. 2H-1] controls (indexed 2*i + j), rec[2H] lambda, rec[2H+1] meta (bit pattern)
+// meta: low 32 bits iteration count; bit 32 = stopped (eps reached); bit 33 = v := u was executed
+// at the last CD iteration (mpc.h:330-334); bit 34 = non-finite inputs.
+constexpr uint64_t kMetaStopped = 1ull << 32;
+constexpr uint64_t kMetaVInit = 1ull << 33;
+constexpr uint64_t kMetaNonFinite = 1ull << 34;
+
+template <typename T, int H> struct LaneRec {
+    // record length in T elements, padded to an even count of 8-byte words
+    static constexpr int kMetaT = sizeof(T) == 8 ? 1 : 2;         // meta needs 64 bits
+    static constexpr int kLen = ((2 * H + 1 + kMetaT) + 1) / 2 * 2;
+};
+
+template <typename T> TPC_DEV void store_meta(T* rec, uint64_t meta);
+template <> TPC_DEV void store_meta<double>(double* rec, uint64_t meta) {
+    rec[0] = __longlong_as_double((long long)meta);
+}
+template <> TPC_DEV void store_meta<float>(float* rec, uint64_t meta) {
+    rec[0] = __uint_as_float((uint32_t)meta);
+    rec[1] = __uint_as_float((uint32_t)(meta >> 32));
+}
+template <typename T> TPC_DEV uint64_t load_meta(const T* rec);
+template <> TPC_DEV uint64_t load_meta<double>(const double* rec) {
+    return (uint64_t)__double_as_longlong(rec[0]);
+}
+template <> TPC_DEV uint64_t load_meta<float>(const float* rec) {
+    return (uint64_t)__float_as_uint(rec[0]) | ((uint64_t)__float_as_uint(rec[1]) << 32);
+}
+
+// Output plumbing shared by both model kinds.
+template <typename T, int I, int H, class Args> struct LaneIO;
+
+template <typename T, int I, int H> struct LaneIO<T, I, H, CompactArgs> {
+    static TPC_DEV void init_controls(const CompactArgs&, int64_t, T* u) {
+#pragma unroll
+        for (int i = 0; i < 2 * H; ++i) u[i] = (T)0;
+    }
+    template <class VSet> static TPC_DEV void load_v(const CompactArgs&, int64_t, VSet vset) {
+#pragma unroll
+        for (int i = 0; i < 2 * H; ++i) vset(i, (T)0);
+    }
+    template <class VGet>
+    static TPC_DEV void write(const CompactArgs& g, int64_t k, const T* u, VGet, uint32_t it) {
+        ((T*)g.front)[k] = u[0];
+        ((T*)g.rear)[k] = u[1];
+        if (g.iters) g.iters[k] = (int32_t)it;
+    }
+};
+
+template <typename T, int I, int H> struct LaneIO<T, I, H, GeneralArgs> {
+    static TPC_DEV void init_controls(const GeneralArgs& g, int64_t k, T* u) {
+#pragma unroll
+        for (int i = 0; i < 2 * H; ++i) u[i] = (T)0;
+        if (g.controls) {
+            const T* cp = (const T*)g.controls + k;
+            // warm-start shift (mpc.h:231-232): controls[i-1] = controls[i], last one kept
+#pragma unroll
+            for (int i = 0; i < H; ++i)
+#pragma unroll
+                for (int j = 0; j < I; ++j) {
+                    const int src = (g.shift_controls && i + 1 < H) ? i + 1 : i;
+                    u[2 * i + j] = cp[(int64_t)(src * I + j) * g.ld];
+                }
+        }
+    }
+    template <class VSet> static TPC_DEV void load_v(const GeneralArgs& g, int64_t k, VSet vset) {
+        const T* vp = (const T*)g.v + k;
+#pragma unroll
+        for (int i = 0; i < H; ++i)
+#pragma unroll
+            for (int j = 0; j < I; ++j)
+                vset(2 * i + j, g.v ? vp[(int64_t)(i * I + j) * g.ld] : (T)0);
+    }
+    template <class VGet>
+    static TPC_DEV void write(const GeneralArgs& g, int64_t k, const T* u, VGet vget, uint32_t it) {
+#pragma unroll
+        for (int j = 0; j < I; ++j) ((T*)g.u0)[(int64_t)j * g.ld + k] = u[j];
+        if (g.controls) {
+            T* cp = (T*)g.controls + k;
+#pragma unroll
+            for (int i = 0; i < H; ++i)
+#pragma unroll
+                for (int j = 0; j < I; ++j) cp[(int64_t)(i * I + j) * g.ld] = u[2 * i + j];
+        }
+        if (g.v) {
+            T* vp = (T*)g.v + k;
+#pragma unroll
+            for (int i = 0; i < H; ++i)
+#pragma unroll
+                for (int j = 0; j < I; ++j) vp[(int64_t)(i * I + j) * g.ld] = vget(2 * i + j);
+        }
+        if (g.iters) g.iters[k] = (int32_t)it;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Phase 1: coordinate descent.  grid = ceil(n/64) blocks of one wave.
+template <typename T, int I, int H, class Model, class Args>
+__global__ __launch_bounds__(64, 1) void lane_cd_kernel(Args g, Knobs kn, T* __restrict__ recs) {
+    constexpr int RL = LaneRec<T, H>::kLen;
+    __shared__ T s_qd[2 * H][kWave];   // Q_diag[i](j) of lane l at s_qd[2*i + j][l]
+    __shared__ T s_mm[2 * H][kWave];   // MM[i](j)
+    const int lane = threadIdx.x;
+    const int64_t k = (int64_t)blockIdx.x * kWave + lane;
+    if (k >= g.n) return;   // no barriers below: a partial last wave just runs with fewer lanes
+
+    Model m;
+    m.load(g, k);
+    const bool nonfinite = m.nonfinite();
+
+    T u[2 * H], w[2 * H];
+    LaneIO<T, I, H, Args>::init_controls(g, k, u);
+    const T lambda = ctor_lambda_qdiag<T, I, H>(m, [&](int i, int j, T val) { s_qd[2 * i + j][lane] = val; });
+    linear_term<T, I, H>(m, w, [&](int q, T val) { s_mm[q][lane] = val; });
+
+    const T eps = (T)kn.eps;
+    const uint32_t cd_iters = kn.smo_iters < kn.max_iter ? kn.smo_iters : kn.max_iter;
+    uint32_t iter = 0;
+    bool stopped = Model::kScreen && nonfinite;   // see CompactModel::kScreen
+    bool vinit = false;
+#pragma unroll 1
+    for (uint32_t it = 0; it < cd_iters; ++it) {
+        if (__ballot(!stopped) == 0ull) break;
+        gradient<T, I, H>(m, u, [&](int q) { return s_mm[q][lane]; }, w);
+        // arg-max |df| over free variables, scanning i then j, strict '>' (mpc.h:289-309)
+        T max_df = (T)0, best_df = (T)0, best_u = (T)0;
+        int best = 0;
+#pragma unroll
+        for (int i = 0; i < H; ++i)
+#pragma unroll
+            for (int j = 0; j < I; ++j) {
+                const T uu = u[2 * i + j], dd = w[2 * i + j];
+                const bool blocked = (uu <= m.lo(j) && dd > (T)0) || (uu >= m.hi(j) && dd < (T)0);
+                const T mag = tabs(dd);
+                if (!blocked && mag > max_df) {
+                    max_df = mag; best = 2 * i + j; best_df = dd; best_u = uu;
+                }
+            }
+        if (!stopped && max_df < eps) stopped = true;           // mpc.h:310-311
+        if (!stopped) {
+            const T qdv = s_qd[best][lane];
+            if (qdv != (T)0) {                                  // mpc.h:322 (`continue` still counts)
+                const int bj = best & 1;
+                T nu = -(best_df - qdv * best_u) / qdv;         // mpc.h:325
+                nu = put_in_range(m.lo(bj), m.hi(bj), nu);      // mpc.h:326
+#pragma unroll
+                for (int q = 0; q < 2 * H; ++q)
+                    if ((q & 1) < I) u[q] = (q == best) ? nu : u[q];
+                vinit = (it + 1 == kn.smo_iters);               // mpc.h:330-334
+            }
+            ++iter;
+        }
+    }
+
+    T* rec = recs + (int64_t)k * RL;
+#pragma unroll
+    for (int q = 0; q < 2 * H; ++q) rec[q] = ((q & 1) < I) ? u[q] : (T)0;
+    rec[2 * H] = lambda;
+    uint64_t meta = (uint64_t)iter;
+    if (stopped) meta |= kMetaStopped;
+    if (vinit) meta |= kMetaVInit;
+    if (nonfinite) meta |= kMetaNonFinite;
+    store_meta<T>(rec + 2 * H + 1, meta);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Phase 2: accelerated projected gradient with lane refill.  Persistent waves; grid <= waves the
+// chip holds.  `ticket` must be zero at launch.
+template <typename T, int I, int H, class Model, class Args>
+__global__ __launch_bounds__(64, 1) void lane_pg_kernel(Args g, Knobs kn, const T* __restrict__ recs,
+                                                         uint32_t* __restrict__ ticket) {
+    constexpr int RL = LaneRec<T, H>::kLen;
+    __shared__ T s_mm[2 * H][kWave];   // MM[i](j) of lane l at s_mm[2*i + j][l]
+    __shared__ T s_v[2 * H][kWave];    // v[i](j)   (mpc.h:250)
+    const int lane = threadIdx.x;
+    const T eps = (T)kn.eps;
+    auto vget = [&](int q) { return s_v[q][lane]; };
+    auto vset = [&](int q, T val) { s_v[q][lane] = val; };
+
+    Model m;
+    T u[2 * H], w[2 * H];
+    T inv_lambda = (T)0, beta = (T)0;
+    int64_t k = 0;
+    uint32_t iter = 0;
+    bool have = false;        // this lane holds an unfinished instance
+    bool exhausted = false;   // the ticket ran past n: nothing left to pull
+    uint32_t flags = 0;
+
+#pragma unroll 1
+    while (true) {
+        // ---- refill (rare, wave-uniform branch): free lanes pull the next instance; instances the
+        // CD phase already finished are written out on the spot
+        if (__ballot(!have && !exhausted) != 0ull) {
+            if (!have && !exhausted) {
+                const uint32_t t = atomicAdd(ticket, 1u);
+                if ((int64_t)t >= g.n) {
+                    exhausted = true;
+                } else {
+                    k = (int64_t)t;
+                    const T* rec = recs + k * RL;
+#pragma unroll
+                    for (int q = 0; q < 2 * H; ++q)
+                        if ((q & 1) < I) u[q] = rec[q];
+                    const T lambda = rec[2 * H];
+                    const uint64_t meta = load_meta<T>(rec + 2 * H + 1);
+                    iter = (uint32_t)meta;
+                    if (meta & kMetaNonFinite) flags |= 0x1u;
+                    if (meta & kMetaVInit) {
+#pragma unroll
+                        for (int q = 0; q < 2 * H; ++q)
+                            if ((q & 1) < I) vset(q, u[q]);
+                    } else {
+                        LaneIO<T, I, H, Args>::load_v(g, k, vset);
+                    }
+                    if ((meta & kMetaStopped) || iter >= kn.max_iter) {
+                        if (!(meta & kMetaStopped)) flags |= 0x2u;
+                        LaneIO<T, I, H, Args>::write(g, k, u, vget, iter);
+                    } else {
+                        m.load(g, k);
+                        linear_term<T, I, H>(m, w, [&](int q, T val) { s_mm[q][lane] = val; });
+                        inv_lambda = (T)1.0 / lambda;                         // mpc.h:342
+                        const T sq = tsqrt(lambda);
+                        beta = (sq - (T)1) / (sq + (T)1);                     // mpc.h:343
+                        have = true;
+                    }
+                }
+            }
+        }
+        if (__ballot(have) == 0ull) {
+            if (__ballot(!exhausted) == 0ull) break;   // every lane saw the end of the queue
+            continue;                                  // drew only finished instances: pull again
+        }
+
+        // ---- one solver iteration on all 64 lanes (idle lanes compute on stale registers; their
+        // results are never stored).  Straight-line code: gradient, stop test, update.
+        gradient<T, I, H>(m, u, [&](int q) { return s_mm[q][lane]; }, w);
+        // largest free gradient component (mpc.h:289-309); the arg-max index is not needed here.
+        // max() is exact, so four independent accumulators give the same value as dlib's scan.
+        T acc[4] = {(T)0, (T)0, (T)0, (T)0};
+#pragma unroll
+        for (int i = 0; i < H; ++i)
+#pragma unroll
+            for (int j = 0; j < I; ++j) {
+                const T uu = u[2 * i + j], dd = w[2 * i + j];
+                const T up = (uu <= m.lo(j)) ? (T)0 : dd;      // at lower bound: only df<0 counts
+                const T dn = (uu >= m.hi(j)) ? (T)0 : -dd;     // at upper bound: only df>0 counts
+                acc[(i * I + j) & 3] = tmax(acc[(i * I + j) & 3], tmax(up, dn));
+            }
+        const T max_df = tmax(tmax(acc[0], acc[1]), tmax(acc[2], acc[3]));
+        const bool stop = have && (max_df < eps);               // mpc.h:310-311
+        if (__ballot(stop) != 0ull) {
+            if (stop) {
+                LaneIO<T, I, H, Args>::write(g, k, u, vget, iter);
+                have = false;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < H; ++i)
+#pragma unroll
+            for (int j = 0; j < I; ++j) {
+                const int q = 2 * i + j;
+                const T v_old = vget(q);
+                const T vn = clamp3(u[q] - inv_lambda * w[q], m.lo(j), m.hi(j));   // mpc.h:342
+                vset(q, vn);
+                u[q] = clamp3(vn + beta * (vn - v_old), m.lo(j), m.hi(j));         // mpc.h:343
+            }
+        ++iter;
+        const bool cap = have && iter >= kn.max_iter;           // mpc.h:271
+        if (__ballot(cap) != 0ull) {
+            if (cap) {
+                flags |= 0x2u;
+                LaneIO<T, I, H, Args>::write(g, k, u, vget, iter);
+                have = false;
+            }
+        }
+    }
+    if (g.flags && flags) atomicOr(g.flags, flags);
+}
+
+}  // namespace tpc

@@ -1,0 +1,271 @@
+// Device-side model policies and the arithmetic shared by the LANE and WAVE kernels.
+//
+// The arithmetic restates dlib::mpc (reference: dlib_files/dlib/control/mpc.h) in the operation
+// order dlib's expression templates produce (products: lhs(r,0)*rhs(0,c) then += for k ascending,
+// dlib_files/dlib/matrix/matrix.h:43-61).  This file is compiled with -ffp-contract=off: the
+// reference build contains no fused multiply-adds, and in fp64 the LANE kernels reproduce its
+// results bit for bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mpc_internal.h"
+
+namespace tpc {
+
+#define TPC_DEV __device__ __forceinline__
+
+// dlib 3-matrix clamp: val<=hi ? (lo<=val ? val : lo) : hi  (matrix_utilities.h:2835-2846).
+// For lo <= hi this is max(min(val,hi),lo), including val = NaN (min(NaN,hi)=hi -> hi).
+template <typename T> TPC_DEV T clamp3(T val, T lo, T hi);
+template <> TPC_DEV double clamp3<double>(double val, double lo, double hi) {
+    return __builtin_fmax(__builtin_fmin(val, hi), lo);
+}
+template <> TPC_DEV float clamp3<float>(float val, float lo, float hi) {
+    return __builtin_fmaxf(__builtin_fminf(val, hi), lo);
+}
+
+// dlib put_in_range(a,b,val) for a <= b (algs.h:716-752); NaN stays NaN.
+template <typename T> TPC_DEV T put_in_range(T lo, T hi, T val) {
+    return (val < lo) ? lo : ((val > hi) ? hi : val);
+}
+
+template <typename T> TPC_DEV T tabs(T x);
+template <> TPC_DEV double tabs<double>(double x) { return __builtin_fabs(x); }
+template <> TPC_DEV float tabs<float>(float x) { return __builtin_fabsf(x); }
+template <typename T> TPC_DEV T tmax(T a, T b);
+template <> TPC_DEV double tmax<double>(double a, double b) { return __builtin_fmax(a, b); }
+template <> TPC_DEV float tmax<float>(float a, float b) { return __builtin_fmaxf(a, b); }
+template <typename T> TPC_DEV T tsqrt(T x);
+template <> TPC_DEV double tsqrt<double>(double x) { return __builtin_sqrt(x); }
+template <> TPC_DEV float tsqrt<float>(float x) { return __builtin_sqrtf(x); }
+template <typename T> TPC_DEV bool tfinite(T x) { return tabs(x) <= (T)1.7976931348623157e308 && x == x; }
+template <> TPC_DEV bool tfinite<float>(float x) { return tabs(x) <= 3.4028234663852886e38f && x == x; }
+
+// ------------------------------------------------------------------------------------------------
+// General model: A 2x2, B 2xI, C, Q, R, lo, hi per instance (dlib::mpc<2,I,H> constructor
+// arguments, mpc.h:51-59), plus x0 and per-step targets read from the SoA batch on demand.
+template <typename T, int I_>
+struct GeneralModel {
+    static constexpr int I = I_;
+    T a00, a01, a10, a11;
+    T b[2][I_];
+    T c0, c1, q0, q1;
+    T r[I_], lo_[I_], hi_[I_];
+    T x00, x01;
+    const T* targets;   // SoA base of this instance: component c at targets[c*ld]
+    int64_t ld;
+
+    TPC_DEV T A(int r_, int c_) const { return r_ == 0 ? (c_ == 0 ? a00 : a01) : (c_ == 0 ? a10 : a11); }
+    TPC_DEV T B(int r_, int j) const { return b[r_][j]; }
+    TPC_DEV T C(int r_) const { return r_ == 0 ? c0 : c1; }
+    TPC_DEV T Q(int r_) const { return r_ == 0 ? q0 : q1; }
+    TPC_DEV T R(int j) const { return r[j]; }
+    TPC_DEV T lo(int j) const { return lo_[j]; }
+    TPC_DEV T hi(int j) const { return hi_[j]; }
+    TPC_DEV T x0(int r_) const { return r_ == 0 ? x00 : x01; }
+    TPC_DEV T target(int t, int s) const { return targets[(int64_t)(2 * t + s) * ld]; }
+
+    TPC_DEV void load(const GeneralArgs& g, int64_t k) {
+        const T* Ap = (const T*)g.A + k;
+        const T* Bp = (const T*)g.B + k;
+        a00 = Ap[0]; a01 = Ap[g.ld]; a10 = Ap[2 * g.ld]; a11 = Ap[3 * g.ld];
+#pragma unroll
+        for (int r_ = 0; r_ < 2; ++r_)
+#pragma unroll
+            for (int j = 0; j < I_; ++j) b[r_][j] = Bp[(int64_t)(r_ * I_ + j) * g.ld];
+        c0 = ((const T*)g.C)[k]; c1 = ((const T*)g.C)[g.ld + k];
+        q0 = ((const T*)g.Q)[k]; q1 = ((const T*)g.Q)[g.ld + k];
+#pragma unroll
+        for (int j = 0; j < I_; ++j) {
+            r[j] = ((const T*)g.R)[(int64_t)j * g.ld + k];
+            lo_[j] = ((const T*)g.lo)[(int64_t)j * g.ld + k];
+            hi_[j] = ((const T*)g.hi)[(int64_t)j * g.ld + k];
+        }
+        x00 = ((const T*)g.x0)[k]; x01 = ((const T*)g.x0)[g.ld + k];
+        targets = (const T*)g.targets + k;
+        ld = g.ld;
+    }
+    // dlib propagates non-finite values through the same arithmetic this model uses, so nothing
+    // is screened; the test only feeds TPC_MPC_FLAG_NONFINITE (bounds may legitimately be +-inf).
+    static constexpr bool kScreen = false;
+    TPC_DEV bool nonfinite() const {
+        bool f = tfinite(a00) && tfinite(a01) && tfinite(a10) && tfinite(a11) && tfinite(c0) &&
+                 tfinite(c1) && tfinite(q0) && tfinite(q1) && tfinite(x00) && tfinite(x01);
+#pragma unroll
+        for (int j = 0; j < I_; ++j)
+            f = f && tfinite(b[0][j]) && tfinite(b[1][j]) && tfinite(r[j]) && lo_[j] == lo_[j] &&
+                hi_[j] == hi_[j];
+        return !f;
+    }
+
+    // M <- B*u                                  (mpc.h:275)
+    TPC_DEV void first(T& m0, T& m1, const T* u) const {
+        T s0 = b[0][0] * u[0], s1 = b[1][0] * u[0];
+        if (I_ == 2) { s0 = s0 + b[0][I_ - 1] * u[I_ - 1]; s1 = s1 + b[1][I_ - 1] * u[I_ - 1]; }
+        m0 = s0; m1 = s1;
+    }
+    // M <- A*M + B*u                            (mpc.h:277)
+    TPC_DEV void fwd(T& m0, T& m1, const T* u) const {
+        T s0, s1;
+        first(s0, s1, u);
+        const T n0 = (a00 * m0 + a01 * m1) + s0;
+        const T n1 = (a10 * m0 + a11 * m1) + s1;
+        m0 = n0; m1 = n1;
+    }
+    // M <- Q.*W + trans(A)*N                    (mpc.h:279 then :281)
+    TPC_DEV void bwd(T& n0, T& n1, T w0, T w1) const {
+        const T t0 = w0 * q0 + (a00 * n0 + a10 * n1);
+        const T t1 = w1 * q1 + (a01 * n0 + a11 * n1);
+        n0 = t0; n1 = t1;
+    }
+    // (trans(B)*M)(j)                           (mpc.h:266, :283)
+    TPC_DEV T btm(int j, T m0, T m1) const { return b[0][j] * m0 + b[1][j] * m1; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Compact model: what mpcControllerTobi builds from the speed v
+// (reference: src/trajectory_point_follower.cpp:326-333):  A=[1,a;0,1]  B=[0,a;c,-c]  C=0,
+// a = T*v, c = T*v/l, x0 = 0, one target for all steps; Q, R, bounds uniform over the batch.
+// The hot recurrences drop the products with the literal 0 and 1 entries; that is exact
+// (1*x == x, 0*x + y == y, x + (-c)*y == x - c*y) for every finite a, c -- non-finite speeds are
+// screened out (kScreen) and return the untouched start point as dlib does.
+template <typename T>
+struct CompactModel {
+    static constexpr int I = 2;
+    T a, c;          // per instance
+    T ty, tphi;      // per instance target
+    T q0, q1, r0, r1, l0, l1, h0, h1;   // uniform
+
+    TPC_DEV T A(int r_, int c_) const { return r_ == 0 ? (c_ == 0 ? (T)1 : a) : (c_ == 0 ? (T)0 : (T)1); }
+    TPC_DEV T B(int r_, int j) const { return r_ == 0 ? (j == 0 ? (T)0 : a) : (j == 0 ? c : -c); }
+    TPC_DEV T C(int) const { return (T)0; }
+    TPC_DEV T Q(int r_) const { return r_ == 0 ? q0 : q1; }
+    TPC_DEV T R(int j) const { return j == 0 ? r0 : r1; }
+    TPC_DEV T lo(int j) const { return j == 0 ? l0 : l1; }
+    TPC_DEV T hi(int j) const { return j == 0 ? h0 : h1; }
+    TPC_DEV T x0(int) const { return (T)0; }
+    TPC_DEV T target(int, int s) const { return s == 0 ? ty : tphi; }
+
+    TPC_DEV void load(const CompactArgs& g, int64_t k) {
+        const T vk = ((const T*)g.v)[k];
+        const T step = (T)g.step;
+        a = step * vk;                      // T*v       (:327, :330)
+        c = step * vk / (T)g.wheelbase;     // T*v/l     (:330)
+        ty = ((const T*)g.dy)[k];
+        tphi = ((const T*)g.dphi)[k];
+        q0 = (T)g.q[0]; q1 = (T)g.q[1]; r0 = (T)g.r[0]; r1 = (T)g.r[1];
+        l0 = (T)g.lo[0]; l1 = (T)g.lo[1]; h0 = (T)g.hi[0]; h1 = (T)g.hi[1];
+    }
+    // Any non-finite v, dy or dphi makes every gradient component NaN in dlib, which then returns
+    // the untouched start point at iteration 0 (mpc.h:298-311); the shortcuts below assume finite
+    // a, c, so such instances are screened to exactly that result.
+    static constexpr bool kScreen = true;
+    TPC_DEV bool nonfinite() const { return !(tfinite(a) && tfinite(c) && tfinite(ty) && tfinite(tphi)); }
+
+    TPC_DEV void first(T& m0, T& m1, const T* u) const {
+        m0 = a * u[1];
+        m1 = c * u[0] - c * u[1];
+    }
+    TPC_DEV void fwd(T& m0, T& m1, const T* u) const {
+        const T n0 = (m0 + a * m1) + a * u[1];
+        const T n1 = m1 + (c * u[0] - c * u[1]);
+        m0 = n0; m1 = n1;
+    }
+    TPC_DEV void bwd(T& n0, T& n1, T w0, T w1) const {
+        const T t0 = w0 * q0 + n0;
+        const T t1 = w1 * q1 + (a * n0 + n1);
+        n0 = t0; n1 = t1;
+    }
+    TPC_DEV T btm(int j, T m0, T m1) const { return j == 0 ? c * m1 : a * m0 - c * m1; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Constructor quantities (mpc.h:116-123): lambda = trace bound on the Hessian's largest
+// eigenvalue; Q_diag[i] = diag(trans(B)*T_{H-1-i}*B) (NOT the Hessian diagonal: it omits R).
+// `emit(i, j, value)` receives Q_diag[i](j).
+template <typename T, int I, int H, class Model, class Emit>
+TPC_DEV T ctor_lambda_qdiag(const Model& m, Emit emit) {
+    T sumR = m.R(0);
+    if (I == 2) sumR = sumR + m.R(I - 1);
+    T lambda = sumR * (T)H;
+    T t00 = m.Q(0), t01 = (T)0, t10 = (T)0, t11 = m.Q(1);
+#pragma unroll 1
+    for (int cidx = 0; cidx < H; ++cidx) {
+        T tr = (T)0;
+#pragma unroll
+        for (int r_ = 0; r_ < I; ++r_) {
+            // W(r,:) = trans(B)(r,:) * T ; P(r,r) = W(r,:) * B(:,r)
+            const T w0 = m.B(0, r_) * t00 + m.B(1, r_) * t10;
+            const T w1 = m.B(0, r_) * t01 + m.B(1, r_) * t11;
+            const T p = w0 * m.B(0, r_) + w1 * m.B(1, r_);
+            emit(H - cidx - 1, r_, p);
+            tr = (r_ == 0) ? p : tr + p;
+        }
+        lambda = lambda + tr;
+        // T <- (trans(A)*T)*A + diagm(Q)
+        const T u00 = m.A(0, 0) * t00 + m.A(1, 0) * t10, u01 = m.A(0, 0) * t01 + m.A(1, 0) * t11;
+        const T u10 = m.A(0, 1) * t00 + m.A(1, 1) * t10, u11 = m.A(0, 1) * t01 + m.A(1, 1) * t11;
+        const T n00 = (u00 * m.A(0, 0) + u01 * m.A(1, 0)) + m.Q(0);
+        const T n01 = (u00 * m.A(0, 1) + u01 * m.A(1, 1)) + (T)0;
+        const T n10 = (u10 * m.A(0, 0) + u11 * m.A(1, 0)) + (T)0;
+        const T n11 = (u10 * m.A(0, 1) + u11 * m.A(1, 1)) + m.Q(1);
+        t00 = n00; t01 = n01; t10 = n10; t11 = n11;
+    }
+    return lambda;
+}
+
+// Linear term MM = trans(K)*Q*(M - target) (mpc.h:258-266); `emit(2*i + j, value)` receives
+// MM[i](j); `w` is scratch of 2*H values.
+template <typename T, int I, int H, class Model, class Emit>
+TPC_DEV void linear_term(const Model& m, T* w, Emit emit) {
+    T m0 = (m.A(0, 0) * m.x0(0) + m.A(0, 1) * m.x0(1)) + m.C(0);
+    T m1 = (m.A(1, 0) * m.x0(0) + m.A(1, 1) * m.x0(1)) + m.C(1);
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        if (i > 0) {
+            const T n0 = (m.A(0, 0) * m0 + m.A(0, 1) * m1) + m.C(0);
+            const T n1 = (m.A(1, 0) * m0 + m.A(1, 1) * m1) + m.C(1);
+            m0 = n0; m1 = n1;
+        }
+        w[2 * i] = (m0 - m.target(i, 0)) * m.Q(0);
+        w[2 * i + 1] = (m1 - m.target(i, 1)) * m.Q(1);
+    }
+    T n0 = w[2 * (H - 1)], n1 = w[2 * (H - 1) + 1];
+#pragma unroll
+    for (int i = H - 1; i >= 0; --i) {
+        if (i < H - 1) {
+            const T t0 = w[2 * i] + (m.A(0, 0) * n0 + m.A(1, 0) * n1);
+            const T t1 = w[2 * i + 1] + (m.A(0, 1) * n0 + m.A(1, 1) * n1);
+            n0 = t0; n1 = t1;
+        }
+#pragma unroll
+        for (int j = 0; j < I; ++j) emit(2 * i + j, m.B(0, j) * n0 + m.B(1, j) * n1);
+    }
+}
+
+// Gradient df = H*u + MM by dlib's forward/backward recurrences (mpc.h:275-283).
+// u, w are indexed [2*i + j], mm(2*i + j) returns MM[i](j); on return w[2*i + j] = df[i](j).
+template <typename T, int I, int H, class Model, class MmGet>
+TPC_DEV void gradient(const Model& m, const T* u, MmGet mm, T* w) {
+    T m0, m1;
+    m.first(m0, m1, &u[0]);
+    w[0] = m0; w[1] = m1;
+#pragma unroll
+    for (int i = 1; i < H; ++i) {
+        m.fwd(m0, m1, &u[2 * i]);
+        w[2 * i] = m0; w[2 * i + 1] = m1;
+    }
+    // i = H-1: M = Q.*W, no backward term
+    T n0 = w[2 * (H - 1)] * m.Q(0), n1 = w[2 * (H - 1) + 1] * m.Q(1);
+#pragma unroll
+    for (int i = H - 1; i >= 0; --i) {
+        if (i < H - 1) m.bwd(n0, n1, w[2 * i], w[2 * i + 1]);
+#pragma unroll
+        for (int j = 0; j < I; ++j)
+            w[2 * i + j] = (mm(2 * i + j) + m.btm(j, n0, n1)) + u[2 * i + j] * m.R(j);
+    }
+}
+
+}  // namespace tpc

@@ -1,0 +1,180 @@
+// WAVE kernel: one 64-lane wavefront per MPC instance (the layout BASELINE.json's north_star
+// describes).  Lane q owns decision variable q = i*I + j (i = horizon step, j = input).
+//
+//   prologue  every lane runs dlib's O(H) gradient recurrence on the unit vector e_q: that is
+//             column q of the dense Hessian Hd = K'QK + R, kept in the lane's VGPRs as "its row"
+//             (Hd is symmetric).  lambda, Q_diag and the linear term MM are computed redundantly by
+//             all lanes; each keeps its own element.
+//   loop      controls are exchanged through a 2H-entry LDS vector (one ds_write per lane, then
+//             broadcast ds_reads); df_q = Hd[q,:].u + MM_q is a register dot product.
+//             Coordinate-descent iterations (iter < smo_iters) need the arg-max: DPP wavefront
+//             max + ballot, lowest index wins like dlib's strict '>' scan (mpc.h:292-308).
+//             Projected-gradient iterations need only "is any free |df| >= eps": one compare and a
+//             ballot, no reduction at all.
+//
+// Not bit-identical to dlib (the dot product sums in a different order; fused multiply-adds are
+// used), but it takes dlib's decisions on dlib's quantities, so iteration counts agree and the
+// outputs differ by ~1e-11 relative in fp64 (tests/test_parity_gpu.py).
+// Iteration counts are wave-uniform: no divergence, no refill.  Supports I*H <= 64.
+#pragma once
+
+#include "mpc_model.h"
+
+namespace tpc {
+
+template <typename T> TPC_DEV T tfma(T a, T b, T c);
+template <> TPC_DEV double tfma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <> TPC_DEV float tfma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+template <int CTRL, int ROW_MASK = 0xf> TPC_DEV double dpp_mov(double old, double x) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK = 0xf> TPC_DEV float dpp_mov(float old, float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), CTRL, ROW_MASK, 0xf, false));
+}
+TPC_DEV double read_lane(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
+                            __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+TPC_DEV float read_lane(float x, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
+}
+
+// max over the 64 lanes, returned wave-uniform.  x >= 0 or NaN; NaN lanes are ignored (fmax).
+template <typename T> TPC_DEV T wave_max(T x) {
+    x = tmax(x, dpp_mov<0x111>(x, x));          // row_shr:1
+    x = tmax(x, dpp_mov<0x112>(x, x));          // row_shr:2
+    x = tmax(x, dpp_mov<0x114>(x, x));          // row_shr:4
+    x = tmax(x, dpp_mov<0x118>(x, x));          // row_shr:8   -> lane 15 of each row = row max
+    x = tmax(x, dpp_mov<0x142, 0xa>(x, x));     // row_bcast:15 -> rows 1,3
+    x = tmax(x, dpp_mov<0x143, 0xc>(x, x));     // row_bcast:31 -> rows 2,3; lane 63 = wave max
+    return read_lane(x, 63);
+}
+
+template <typename T, int I, int H, class Args> struct WaveIO;
+template <typename T, int I, int H> struct WaveIO<T, I, H, CompactArgs> {
+    static TPC_DEV T init_u(const CompactArgs&, int64_t, int, int) { return (T)0; }
+    static TPC_DEV T init_v(const CompactArgs&, int64_t, int, int) { return (T)0; }
+    static TPC_DEV void write(const CompactArgs& g, int64_t k, bool active, int qi, int qj, T u, T, uint32_t it) {
+        if (active && qi == 0) {
+            if (qj == 0) ((T*)g.front)[k] = u; else ((T*)g.rear)[k] = u;
+        }
+        if (g.iters && threadIdx.x == 0) g.iters[k] = (int32_t)it;
+    }
+};
+template <typename T, int I, int H> struct WaveIO<T, I, H, GeneralArgs> {
+    static TPC_DEV T init_u(const GeneralArgs& g, int64_t k, int qi, int qj) {
+        if (!g.controls) return (T)0;
+        const int src = (g.shift_controls && qi + 1 < H) ? qi + 1 : qi;   // mpc.h:231-232
+        return ((const T*)g.controls)[(int64_t)(src * I + qj) * g.ld + k];
+    }
+    static TPC_DEV T init_v(const GeneralArgs& g, int64_t k, int qi, int qj) {
+        return g.v ? ((const T*)g.v)[(int64_t)(qi * I + qj) * g.ld + k] : (T)0;
+    }
+    static TPC_DEV void write(const GeneralArgs& g, int64_t k, bool active, int qi, int qj, T u, T v, uint32_t it) {
+        if (active) {
+            if (qi == 0) ((T*)g.u0)[(int64_t)qj * g.ld + k] = u;
+            if (g.controls) ((T*)g.controls)[(int64_t)(qi * I + qj) * g.ld + k] = u;
+            if (g.v) ((T*)g.v)[(int64_t)(qi * I + qj) * g.ld + k] = v;
+        }
+        if (g.iters && threadIdx.x == 0) g.iters[k] = (int32_t)it;
+    }
+};
+
+template <typename T, int I, int H, class Model, class Args>
+__global__ __launch_bounds__(64) void wave_kernel(Args g, Knobs kn) {
+    constexpr int N = I * H;
+    static_assert(N <= kWave, "WAVE kernel: one variable per lane");
+    __shared__ __attribute__((aligned(16))) T s_u[N + 2];
+    const int lane = threadIdx.x;
+    const int64_t k = blockIdx.x;
+    const bool active = lane < N;
+    const int qi = active ? lane / I : 0, qj = active ? lane % I : 0;
+    const int slot = 2 * qi + qj;
+
+    Model m;
+    m.load(g, k);   // every lane reads the same instance: broadcast loads
+    const bool nonfinite = m.nonfinite();
+
+    // ---- prologue: this lane's Hessian row, Q_diag, linear-term element, lambda
+    T row[2 * H];
+    {
+        T e[2 * H];
+#pragma unroll
+        for (int q = 0; q < 2 * H; ++q) e[q] = (active && q == slot) ? (T)1 : (T)0;
+        gradient<T, I, H>(m, e, [](int) { return (T)0; }, row);   // row[2i+j] = Hd[(i,j)][q]
+    }
+    T my_qd = (T)0, my_g = (T)0;
+    const T lambda = ctor_lambda_qdiag<T, I, H>(m, [&](int i, int j, T val) { if (2 * i + j == slot) my_qd = val; });
+    {
+        T w[2 * H];
+        linear_term<T, I, H>(m, w, [&](int q, T val) { if (q == slot) my_g = val; });
+    }
+    const T lo = m.lo(qj), hi = m.hi(qj);
+    const T eps = (T)kn.eps;
+    const T inv_lambda = (T)1.0 / lambda;                 // mpc.h:342
+    const T sq = tsqrt(lambda);
+    const T beta = (sq - (T)1) / (sq + (T)1);             // mpc.h:343
+
+    T u = active ? WaveIO<T, I, H, Args>::init_u(g, k, qi, qj) : (T)0;
+    T v = active ? WaveIO<T, I, H, Args>::init_v(g, k, qi, qj) : (T)0;
+
+    uint32_t iter = 0;
+    bool capped = true;
+    if (Model::kScreen && nonfinite) { capped = false; } else {
+#pragma unroll 1
+    for (; iter < kn.max_iter; ++iter) {
+        // exchange controls through LDS (single-wave workgroup: the barrier is only a wait)
+        if (active) s_u[lane] = u;
+        __syncthreads();
+        T a0 = (T)0, a1 = (T)0, a2 = (T)0, a3 = (T)0;
+#pragma unroll
+        for (int i = 0; i < H; ++i)
+#pragma unroll
+            for (int j = 0; j < I; ++j) {
+                const int q = i * I + j;
+                const T uq = s_u[q];
+                if ((q & 3) == 0) a0 = tfma(row[2 * i + j], uq, a0);
+                else if ((q & 3) == 1) a1 = tfma(row[2 * i + j], uq, a1);
+                else if ((q & 3) == 2) a2 = tfma(row[2 * i + j], uq, a2);
+                else a3 = tfma(row[2 * i + j], uq, a3);
+            }
+        const T df = ((a0 + a1) + (a2 + a3)) + my_g;
+        const bool blocked = (u <= lo && df > (T)0) || (u >= hi && df < (T)0);   // mpc.h:298-299
+        const T c = (active && !blocked) ? tabs(df) : (T)0;
+
+        if (iter < kn.smo_iters) {
+            // coordinate descent on the arg-max (mpc.h:319-335)
+            const T mx = wave_max(c);
+            if (mx < eps) { capped = false; break; }                             // mpc.h:310-311
+            const unsigned long long hit = __ballot(c == mx);
+            const int best = __ffsll((long long)hit) - 1;                        // lowest index wins
+            const T qd = read_lane(my_qd, best);
+            if (qd != (T)0) {                                                    // mpc.h:322
+                if (lane == best) {
+                    T nu = -(df - qd * u) / qd;                                  // mpc.h:325
+                    u = put_in_range(lo, hi, nu);                                // mpc.h:326
+                }
+                if (iter + 1 == kn.smo_iters) v = u;                             // mpc.h:330-334
+            }
+        } else {
+            // accelerated projected gradient (mpc.h:336-345); stop test without a reduction
+            if (__ballot(c >= eps) == 0ull) { capped = false; break; }           // mpc.h:310-311
+            const T v_old = v;
+            v = clamp3(u - inv_lambda * df, lo, hi);
+            u = clamp3(v + beta * (v - v_old), lo, hi);
+        }
+    }
+    }
+    WaveIO<T, I, H, Args>::write(g, k, active, qi, qj, u, v, iter);
+    if (g.flags && lane == 0) {
+        uint32_t f = 0;
+        if (nonfinite) f |= 0x1u;
+        if (capped) f |= 0x2u;
+        if (f) atomicOr(g.flags, f);
+    }
+}
+
+}  // namespace tpc

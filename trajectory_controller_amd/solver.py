@@ -1,0 +1,259 @@
+"""Host-side handle over the C ABI: `MpcSolver`.
+
+Mirrors the reference's operator surface for this path -- dlib::mpc's constructor knobs
+(epsilon, max_iterations; mpc.h:187-214), `mpcControllerTobi(v, delta_y, delta_phi)`
+(src/trajectory_point_follower.cpp:301-389) -- for one instance or a batch.  Arrays may be numpy
+(host memory: the library stages them) or torch tensors on the GPU (device pointers are handed to
+the library as they are, launches go to torch's current stream).  torch is used for device memory
+and streams only; all arithmetic is in the HIP kernels behind libtpc_mpc.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import capi
+
+_NP = {capi.F64: np.float64, capi.F32: np.float32}
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+class MpcSolver:
+    """One tpc_mpc_handle bound to a HIP device.  Not thread-safe (like the handle)."""
+
+    def __init__(self, horizon: int = 20, device: int = 0, dtype: str = "f64", algo: str = "auto",
+                 **params):
+        self._lib = capi.load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.tpc_mpc_create(int(device), C.byref(self._h))
+        if rc != capi.OK:
+            raise capi.TpcMpcError(rc, self._lib.tpc_mpc_last_error(None).decode())
+        self.device = int(device)
+        self.dtype = {"f64": capi.F64, "f32": capi.F32}[dtype]
+        self.algo = {"auto": capi.ALGO_AUTO, "wave": capi.ALGO_WAVE, "lane": capi.ALGO_LANE}[algo]
+        self.params = capi.default_params(horizon, self.dtype, self.algo, **params)
+        self.last_flags = 0
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.tpc_mpc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def horizon(self) -> int:
+        return self.params.horizon
+
+    def _check(self, rc: int):
+        if rc != capi.OK:
+            raise capi.TpcMpcError(rc, self._lib.tpc_mpc_last_error(self._h).decode())
+
+    def _params(self, **over) -> capi.Params:
+        if not over:
+            return self.params
+        p = capi.Params.from_buffer_copy(self.params)
+        for k, val in over.items():
+            if k in ("lower", "upper"):
+                getattr(p, k)[0], getattr(p, k)[1] = float(val[0]), float(val[1])
+            else:
+                setattr(p, k, val)
+        return p
+
+    # -- measurement ------------------------------------------------------------------------------
+    def set_profiling(self, enable: bool = True):
+        self._check(self._lib.tpc_mpc_set_profiling(self._h, int(enable)))
+
+    def last_kernel_times(self):
+        """(first_kernel_ms, second_kernel_ms, algo) of the last solve; waits for it."""
+        a, b, algo = C.c_double(), C.c_double(), C.c_int()
+        self._check(self._lib.tpc_mpc_last_kernel_times(self._h, C.byref(a), C.byref(b), C.byref(algo)))
+        return a.value, b.value, algo.value
+
+    # -- the call being replaced ------------------------------------------------------------------
+    def mpc_controller_tobi(self, v: float, delta_y: float, delta_phi: float, **over):
+        """mpcControllerTobi(v, delta_y, delta_phi, &front, &rear): returns (front, rear)."""
+        f, r = C.c_double(), C.c_double()
+        self._check(self._lib.tpc_mpc_solve_one(self._h, C.byref(self._params(**over)), float(v),
+                                                float(delta_y), float(delta_phi), C.byref(f),
+                                                C.byref(r)))
+        return f.value, r.value
+
+    solve_one = mpc_controller_tobi
+
+    # -- batches ----------------------------------------------------------------------------------
+    def solve_batch_compact(self, v, delta_y, delta_phi, want_iters: bool = False,
+                            want_flags: bool = True, out=None, **over):
+        """n independent mpcControllerTobi calls.  Returns (front, rear[, iters])."""
+        p = self._params(**over)
+        if _is_torch(v):
+            import torch
+            tdt = torch.float64 if p.dtype == capi.F64 else torch.float32
+            n = v.numel()
+            for t in (v, delta_y, delta_phi):
+                if not (t.is_cuda and t.dtype == tdt and t.is_contiguous() and t.numel() == n):
+                    raise ValueError("device batch arrays must be contiguous CUDA tensors of the solver dtype")
+            if out is None:
+                front, rear = torch.empty_like(v), torch.empty_like(v)
+            else:
+                front, rear = out
+            iters = torch.empty(n, dtype=torch.int32, device=v.device) if want_iters else None
+            flags = C.c_uint32(0)
+            stream = torch.cuda.current_stream(v.device).cuda_stream
+            self._check(self._lib.tpc_mpc_solve_batch_compact(
+                self._h, C.byref(p), n, v.data_ptr(), delta_y.data_ptr(), delta_phi.data_ptr(),
+                front.data_ptr(), rear.data_ptr(), iters.data_ptr() if want_iters else None,
+                C.byref(flags) if want_flags else None, capi.DEVICE, C.c_void_p(stream)))
+            self.last_flags = flags.value
+        else:
+            dt = _NP[p.dtype]
+            v, delta_y, delta_phi = (np.ascontiguousarray(a, dtype=dt) for a in (v, delta_y, delta_phi))
+            n = v.shape[0]
+            front, rear = np.empty(n, dtype=dt), np.empty(n, dtype=dt)
+            iters = np.empty(n, dtype=np.int32) if want_iters else None
+            flags = C.c_uint32(0)
+            self._check(self._lib.tpc_mpc_solve_batch_compact(
+                self._h, C.byref(p), n, v.ctypes.data, delta_y.ctypes.data, delta_phi.ctypes.data,
+                front.ctypes.data, rear.ctypes.data, iters.ctypes.data if want_iters else None,
+                C.byref(flags), capi.HOST, None))
+            self.last_flags = flags.value
+        return (front, rear, iters) if want_iters else (front, rear)
+
+    def solve_batch_general(self, A, B, Cc, Q, R, lower, upper, x0, targets, controls=None,
+                            v_state=None, inputs: Optional[int] = None, want_iters: bool = False,
+                            **over):
+        """n independent dlib::mpc<2,I,H> controllers: ctor + set_target(t) + operator()(x0).
+
+        Arrays are component-major (SoA): A[4,n] B[2I,n] C[2,n] Q[2,n] R[I,n] lower[I,n] upper[I,n]
+        x0[2,n] targets[2H,n]; controls / v_state [H*I, n] are updated in place when given.
+        Returns (u0[I,n][, iters])."""
+        p = self._params(**over)
+        H = p.horizon
+        torch_mode = _is_torch(A)
+        if torch_mode:
+            import torch
+            tdt = torch.float64 if p.dtype == capi.F64 else torch.float32
+            n = A.shape[-1]
+            I = inputs or R.shape[0]
+
+            def ptr(t, rows):
+                if t is None:
+                    return None
+                if not (t.is_cuda and t.dtype == tdt and t.is_contiguous() and tuple(t.shape) == (rows, n)):
+                    raise ValueError(f"expected contiguous CUDA tensor [{rows},{n}] of the solver dtype")
+                return t.data_ptr()
+            u0 = torch.empty((I, n), dtype=tdt, device=A.device)
+            iters = torch.empty(n, dtype=torch.int32, device=A.device) if want_iters else None
+            stream = C.c_void_p(torch.cuda.current_stream(A.device).cuda_stream)
+            mem = capi.DEVICE
+            ip = iters.data_ptr() if want_iters else None
+            up = u0.data_ptr()
+        else:
+            dt = _NP[p.dtype]
+            A = np.ascontiguousarray(A, dtype=dt)
+            n = A.shape[-1]
+            I = inputs or np.asarray(R).shape[0]
+            keep = []
+
+            def ptr(a, rows):
+                if a is None:
+                    return None
+                if not (isinstance(a, np.ndarray) and a.dtype == dt and a.flags.c_contiguous and a.shape == (rows, n)):
+                    raise ValueError(f"expected C-contiguous ndarray [{rows},{n}] of the solver dtype")
+                keep.append(a)
+                return a.ctypes.data
+            B, Cc, Q, R, lower, upper, x0, targets = (np.ascontiguousarray(a, dtype=dt) for a in
+                                                      (B, Cc, Q, R, lower, upper, x0, targets))
+            u0 = np.empty((I, n), dtype=dt)
+            iters = np.empty(n, dtype=np.int32) if want_iters else None
+            stream = None
+            mem = capi.HOST
+            ip = iters.ctypes.data if want_iters else None
+            up = u0.ctypes.data
+        io = capi.GeneralIO(inputs=I, n=n, ld=n, A=ptr(A, 4), B=ptr(B, 2 * I), C=ptr(Cc, 2), Q=ptr(Q, 2),
+                            R=ptr(R, I), lower=ptr(lower, I), upper=ptr(upper, I), x0=ptr(x0, 2),
+                            targets=ptr(targets, 2 * H), controls_inout=ptr(controls, H * I),
+                            v_inout=ptr(v_state, H * I), u0=up, iters=ip)
+        flags = C.c_uint32(0)
+        self._check(self._lib.tpc_mpc_solve_batch_general(self._h, C.byref(p), C.byref(io),
+                                                          C.byref(flags), mem, stream))
+        self.last_flags = flags.value
+        return (u0, iters) if want_iters else u0
+
+    def rollout(self, steps: int, A, B, Cc, Q, R, lower, upper, x0, targets, new_last_targets=None,
+                controls=None, v_state=None, inputs: Optional[int] = None, want_states: bool = True,
+                want_iters: bool = False, **over):
+        """`steps` successive operator() calls per controller with warm start and target shift
+        (mpc.h:229-239) and the plant update of dlib/test/mpc.cpp:314 between them.  SoA arrays as
+        in solve_batch_general; new_last_targets [2*steps, n].  Returns (controls[steps*I, n],
+        states[steps*2, n] | None, iters[steps, n] | None)."""
+        p = self._params(**over)
+        H = p.horizon
+        if _is_torch(A):
+            import torch
+            tdt = torch.float64 if p.dtype == capi.F64 else torch.float32
+            n = A.shape[-1]
+            I = inputs or R.shape[0]
+
+            def ptr(t, rows):
+                if t is None:
+                    return None
+                if not (t.is_cuda and t.dtype == tdt and t.is_contiguous() and tuple(t.shape) == (rows, n)):
+                    raise ValueError(f"expected contiguous CUDA tensor [{rows},{n}] of the solver dtype")
+                return t.data_ptr()
+            c_out = torch.empty((steps * I, n), dtype=tdt, device=A.device)
+            s_out = torch.empty((steps * 2, n), dtype=tdt, device=A.device) if want_states else None
+            i_out = torch.empty((steps, n), dtype=torch.int32, device=A.device) if want_iters else None
+            stream = C.c_void_p(torch.cuda.current_stream(A.device).cuda_stream)
+            mem = capi.DEVICE
+            optr = lambda t: None if t is None else t.data_ptr()
+        else:
+            dt = _NP[p.dtype]
+            A = np.ascontiguousarray(A, dtype=dt)
+            n = A.shape[-1]
+            I = inputs or np.asarray(R).shape[0]
+            keep = []
+
+            def ptr(a, rows):
+                if a is None:
+                    return None
+                if not (isinstance(a, np.ndarray) and a.dtype == dt and a.flags.c_contiguous and a.shape == (rows, n)):
+                    raise ValueError(f"expected C-contiguous ndarray [{rows},{n}] of the solver dtype")
+                keep.append(a)
+                return a.ctypes.data
+            B, Cc, Q, R, lower, upper, x0, targets = (np.ascontiguousarray(a, dtype=dt) for a in
+                                                      (B, Cc, Q, R, lower, upper, x0, targets))
+            if new_last_targets is not None:
+                new_last_targets = np.ascontiguousarray(new_last_targets, dtype=dt)
+            c_out = np.empty((steps * I, n), dtype=dt)
+            s_out = np.empty((steps * 2, n), dtype=dt) if want_states else None
+            i_out = np.empty((steps, n), dtype=np.int32) if want_iters else None
+            stream = None
+            mem = capi.HOST
+            optr = lambda a: None if a is None else a.ctypes.data
+        io = capi.GeneralIO(inputs=I, n=n, ld=n, A=ptr(A, 4), B=ptr(B, 2 * I), C=ptr(Cc, 2), Q=ptr(Q, 2),
+                            R=ptr(R, I), lower=ptr(lower, I), upper=ptr(upper, I), x0=ptr(x0, 2),
+                            targets=ptr(targets, 2 * H), controls_inout=ptr(controls, H * I),
+                            v_inout=ptr(v_state, H * I), u0=None, iters=None)
+        flags = C.c_uint32(0)
+        self._check(self._lib.tpc_mpc_rollout(self._h, C.byref(p), C.byref(io), int(steps),
+                                              ptr(new_last_targets, 2 * steps), optr(c_out), optr(s_out),
+                                              optr(i_out), C.byref(flags), mem, stream))
+        self.last_flags = flags.value
+        return c_out, s_out, i_out

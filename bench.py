@@ -53,16 +53,36 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    cores = min(cores, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    cores = min(cores, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    env = os.environ.get("TPC_BENCH_CPU_THREADS")
+    return int(env) if env else cores
+
+
 def cpu_baseline(H, v, dy, dphi, budget_s):
     """Time the dlib CPU path on this host's cores on a bounded sample of the workload.
     Returns (dict for the JSON line, sample size, reference outputs)."""
     from oracle import bindings as ob
-    cores = os.cpu_count() or 1
-    try:
-        aff = len(os.sched_getaffinity(0))
-        cores = min(cores, aff)
-    except Exception:
-        pass
+    cores = usable_cores()
     if os.path.exists(ob.REF_SO):
         ref, kind = ob.DlibRef(ob.REF_SO), "reference"
         run = lambda n, th: ref.solve_compact(H, v[:n], dy[:n], dphi[:n], nthreads=th)

@@ -41,25 +41,21 @@ struct GeneralArgs {
 // Device scratch owned by the handle (LANE kernels: state handed from the coordinate-descent
 // phase to the projected-gradient phase, and the work-queue ticket).
 struct Workspace {
-    void* state;        // [(2H + 2) * n] of T
+    void* state;        // per-instance records, LaneRec<T,H>::kLen elements each
     uint32_t* ticket;   // 1 word
     int64_t capacity_bytes;
+    // longest-first queue (mpc_sort.hip): keys written by the CD kernel, ordered into order[]
+    uint32_t *keys, *order;
+    void* sort_temp;
+    size_t sort_temp_bytes;
     // optional profiling: events recorded on the launch stream around each kernel
     // (ev[0] .. ev[1] first kernel, ev[1] .. ev[2] second kernel); null when profiling is off
     hipEvent_t* ev;
 };
 
-// Returns hipSuccess or the failing HIP error; *supported = 0 when (dtype,I,H) has no kernel.
-hipError_t launch_lane_compact(int dtype, int H, const CompactArgs& a, const Knobs& k,
-                               const Workspace& ws, hipStream_t s, int* supported);
-hipError_t launch_lane_general(int dtype, int I, int H, const GeneralArgs& a, const Knobs& k,
-                               const Workspace& ws, hipStream_t s, int* supported);
-hipError_t launch_wave_compact(int dtype, int H, const CompactArgs& a, const Knobs& k,
-                               hipStream_t s, int* supported);
-hipError_t launch_wave_general(int dtype, int I, int H, const GeneralArgs& a, const Knobs& k,
-                               hipStream_t s, int* supported);
+// mpc_sort.hip
+size_t sort_temp_bytes(int64_t n);
+hipError_t order_desc(const uint32_t* keys, uint32_t* order, int64_t n, void* temp, hipStream_t s);
 
-// bytes of Workspace::state the LANE kernels need for a batch
-int64_t lane_workspace_bytes(int dtype, int I, int H, int64_t n);
 
 }  // namespace tpc

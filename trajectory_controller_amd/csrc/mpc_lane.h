@@ -123,7 +123,8 @@ template <typename T, int I, int H> struct LaneIO<T, I, H, GeneralArgs> {
 // ------------------------------------------------------------------------------------------------
 // Phase 1: coordinate descent.  grid = ceil(n/64) blocks of one wave.
 template <typename T, int I, int H, class Model, class Args>
-__global__ __launch_bounds__(64, 1) void lane_cd_kernel(Args g, Knobs kn, T* __restrict__ recs) {
+__global__ __launch_bounds__(64, 1) void lane_cd_kernel(Args g, Knobs kn, T* __restrict__ recs,
+                                                         uint32_t* __restrict__ keys) {
     constexpr int RL = LaneRec<T, H>::kLen;
     __shared__ T s_qd[2 * H][kWave];   // Q_diag[i](j) of lane l at s_qd[2*i + j][l]
     __shared__ T s_mm[2 * H][kWave];   // MM[i](j)
@@ -188,6 +189,10 @@ __global__ __launch_bounds__(64, 1) void lane_cd_kernel(Args g, Knobs kn, T* __r
     if (vinit) meta |= kMetaVInit;
     if (nonfinite) meta |= kMetaNonFinite;
     store_meta<T>(rec + 2 * H + 1, meta);
+    // queue key: instances with the largest lambda need the most projected-gradient iterations
+    const bool finished = stopped || iter >= kn.max_iter;
+    const float lf = (float)lambda;
+    keys[k] = (finished || !(lf > 0.0f)) ? 0u : __float_as_uint(lf);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -195,6 +200,7 @@ __global__ __launch_bounds__(64, 1) void lane_cd_kernel(Args g, Knobs kn, T* __r
 // chip holds.  `ticket` must be zero at launch.
 template <typename T, int I, int H, class Model, class Args>
 __global__ __launch_bounds__(64, 1) void lane_pg_kernel(Args g, Knobs kn, const T* __restrict__ recs,
+                                                         const uint32_t* __restrict__ order,
                                                          uint32_t* __restrict__ ticket) {
     constexpr int RL = LaneRec<T, H>::kLen;
     __shared__ T s_mm[2 * H][kWave];   // MM[i](j) of lane l at s_mm[2*i + j][l]
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(64, 1) void lane_pg_kernel(Args g, Knobs kn, const 
                 if ((int64_t)t >= g.n) {
                     exhausted = true;
                 } else {
-                    k = (int64_t)t;
+                    k = (int64_t)order[t];   // longest-first queue
                     const T* rec = recs + k * RL;
 #pragma unroll
                     for (int q = 0; q < 2 * H; ++q)

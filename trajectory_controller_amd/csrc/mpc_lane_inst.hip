@@ -31,12 +31,15 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
     if (e != hipSuccess) return e;
     const int cd_grid = (int)((a.n + kWave - 1) / kWave);
     if (ws.ev) (void)hipEventRecord(ws.ev[0], s);
-    hipLaunchKernelGGL((lane_cd_kernel<T, I, kH, Model, Args>), dim3(cd_grid), dim3(kWave), 0, s, a, k, recs);
+    hipLaunchKernelGGL((lane_cd_kernel<T, I, kH, Model, Args>), dim3(cd_grid), dim3(kWave), 0, s, a, k, recs,
+                       ws.keys);
     e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = order_desc(ws.keys, ws.order, a.n, ws.sort_temp, s);
     if (e != hipSuccess) return e;
     if (ws.ev) (void)hipEventRecord(ws.ev[1], s);
     hipLaunchKernelGGL((lane_pg_kernel<T, I, kH, Model, Args>), dim3(pg_grid(a.n)), dim3(kWave), 0, s, a, k,
-                       (const T*)recs, ws.ticket);
+                       (const T*)recs, (const uint32_t*)ws.order, ws.ticket);
     e = hipGetLastError();
     if (ws.ev) (void)hipEventRecord(ws.ev[2], s);
     return e;

@@ -185,11 +185,23 @@ int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n,
     ws->ev = h->profiling ? h->ev : nullptr;
     h->ev_valid = h->profiling;
     h->last_algo = algo;
+    ws->keys = ws->order = nullptr;
+    ws->sort_temp = nullptr;
+    ws->sort_temp_bytes = 0;
     if (algo == TPC_MPC_ALGO_LANE) {
-        const int64_t need = lane_rec_len(H, dtype) * (int64_t)esize(dtype) * n;
-        int rc = ensure(h, &h->ws_state, &h->ws_bytes, need);
+        // records | keys | order | counting-sort bins
+        auto pad = [](int64_t b) { return (b + 255) / 256 * 256; };
+        const int64_t rec_b = pad(lane_rec_len(H, dtype) * (int64_t)esize(dtype) * n);
+        const int64_t col_b = pad(n * 4);
+        const size_t tmp_b = sort_temp_bytes(n);
+        int rc = ensure(h, &h->ws_state, &h->ws_bytes, rec_b + 2 * col_b + pad((int64_t)tmp_b));
         if (rc) return rc;
-        ws->state = h->ws_state;
+        char* b = (char*)h->ws_state;
+        ws->state = b;
+        ws->keys = (uint32_t*)(b + rec_b);
+        ws->order = (uint32_t*)(b + rec_b + col_b);
+        ws->sort_temp = b + rec_b + 2 * col_b;
+        ws->sort_temp_bytes = tmp_b;
         ws->capacity_bytes = h->ws_bytes;
     }
     return TPC_MPC_OK;
@@ -290,7 +302,7 @@ int tpc_mpc_solve_batch_compact(tpc_mpc_handle h, const tpc_mpc_params* p, int64
     if (rc) return rc;
     rc = check_compact_model(h, p);
     if (rc) return rc;
-    if (n < 0) return fail(h, TPC_MPC_ERR_BAD_ARG, "n < 0");
+    if (n < 0 || n > 0x7fffffffll) return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= n < 2^31");
     if (mem != TPC_MPC_HOST && mem != TPC_MPC_DEVICE) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad memory kind");
     if (n == 0) { if (flags_out) *flags_out = 0; return TPC_MPC_OK; }
     if (!v || !delta_y || !delta_phi || !steering_front || !steering_rear)
@@ -368,7 +380,7 @@ int tpc_mpc_solve_batch_general(tpc_mpc_handle h, const tpc_mpc_params* p,
     if (rc) return rc;
     if (!io) return fail(h, TPC_MPC_ERR_BAD_ARG, "null io");
     if (io->inputs != 1 && io->inputs != 2) return fail(h, TPC_MPC_ERR_BAD_ARG, "inputs must be 1 or 2");
-    if (io->n < 0 || io->ld < io->n) return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= n <= ld");
+    if (io->n < 0 || io->ld < io->n || io->n > 0x7fffffffll) return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= n <= ld, n < 2^31");
     if (mem != TPC_MPC_HOST && mem != TPC_MPC_DEVICE) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad memory kind");
     if (io->n == 0) { if (flags_out) *flags_out = 0; return TPC_MPC_OK; }
     if (!io->A || !io->B || !io->C || !io->Q || !io->R || !io->lower || !io->upper || !io->x0 ||

@@ -107,7 +107,11 @@ bool TrajectoryPointController::cycleTobiMpc(street_environment::CarCommand::Sta
     double v = car->velocity();
     if (std::fabs(v) < 0.1) v = 0.1;   // the model divides nothing by v, but the reference clamps (:79-82)
 
-    const double phi_soll = std::atan2(tp.directory.y, tp.directory.x);   // :84
+    // :84 calls unqualified atan2 on two floats into a double; whether that resolves to the float or
+    // the double overload depends on which of <cmath>/<math.h> the (unvendored) LMS headers pull in.
+    // This build takes the double overload of glibc's ::atan2 (the only one <cmath> alone exposes
+    // globally); the two differ by ~1e-8 relative in phi_soll.
+    const double phi_soll = std::atan2((double)tp.directory.y, (double)tp.directory.x);
     const double y_soll = tp.position.y;                                  // :85
 
     // weights are read every cycle so they can be tuned live (:91-96)

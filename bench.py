@@ -179,6 +179,12 @@ def main():
         _, _, iters_t = solver.solve_batch_compact(tv, ty, tp, want_iters=True)
         torch.cuda.synchronize()
         mean_iters = float(iters_t.double().mean().item())
+        lane_stats = None
+        if algo_ran == 2:
+            wi, rb = solver.last_lane_stats()
+            pg_iters = float((iters_t.double() - 50.0).clamp(min=0).sum().item())
+            lane_stats = {"wave_iterations": wi, "refill_blocks": rb,
+                          "lane_utilisation": pg_iters / (64.0 * wi) if wi else None}
         esz = 8 if a.dtype == "f64" else 4
         total = world * n * a.steps
         value = total / elapsed
@@ -208,7 +214,7 @@ def main():
                        "global_batch": world * n, "horizon": H, "algo": {1: "wave", 2: "lane"}[algo_ran],
                        "parallelism": f"batch-sharded x{world}"},
             "kernel_ms": {"first": k1 / a.steps, "second": k2 / a.steps, "dominant": dom_name},
-            "mean_iterations": mean_iters,
+            "mean_iterations": mean_iters, "lane_stats": lane_stats,
             "roofline": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "note": "40 B/solve algorithmic: this path is issue-bound, not HBM-bound; see alu"},

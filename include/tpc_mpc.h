@@ -176,6 +176,11 @@ int tpc_mpc_rollout(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mpc_gen
 int tpc_mpc_set_profiling(tpc_mpc_handle h, int enable);
 int tpc_mpc_last_kernel_times(tpc_mpc_handle h, double* first_ms, double* second_ms, int* algo);
 
+/* Occupancy statistics of the last LANE solve (synchronises the device): loop iterations executed
+ * by all persistent wavefronts of the projected-gradient kernel, and refill blocks executed.
+ * lane utilisation = sum of per-instance PG iterations / (64 * wave_iterations). */
+int tpc_mpc_last_lane_stats(tpc_mpc_handle h, uint64_t* wave_iterations, uint64_t* refill_blocks);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,7 @@ STATUS_NAMES = {0: "OK", 1: "BAD_ARG", 2: "BAD_WEIGHTS", 3: "BAD_BOUNDS", 4: "BA
 EXPORTS = ("tpc_mpc_default_params", "tpc_mpc_create", "tpc_mpc_destroy", "tpc_mpc_last_error",
            "tpc_mpc_supported_horizons", "tpc_mpc_abi_version", "tpc_mpc_solve_one",
            "tpc_mpc_solve_batch_compact", "tpc_mpc_solve_batch_general", "tpc_mpc_rollout",
-           "tpc_mpc_set_profiling", "tpc_mpc_last_kernel_times")
+           "tpc_mpc_set_profiling", "tpc_mpc_last_kernel_times", "tpc_mpc_last_lane_stats")
 
 
 class Params(C.Structure):
@@ -86,6 +86,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.tpc_mpc_set_profiling.argtypes = [vp, C.c_int]
     lib.tpc_mpc_last_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                               C.POINTER(C.c_int)]
+    lib.tpc_mpc_last_lane_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     for name in EXPORTS:
         getattr(lib, name)   # raises AttributeError if the library lacks a declared entry point
     if path == LIB_PATH:

@@ -20,6 +20,9 @@
 // in 4 cycles -- the fp64 VALU rate -- so the DP pipe is the bound.
 #pragma once
 
+#include <type_traits>
+#include <utility>
+
 #include "mpc_model.h"
 
 namespace tpc {
@@ -201,7 +204,8 @@ __global__ __launch_bounds__(64, 1) void lane_cd_kernel(Args g, Knobs kn, T* __r
 template <typename T, int I, int H, class Model, class Args>
 __global__ __launch_bounds__(64, 1) void lane_pg_kernel(Args g, Knobs kn, const T* __restrict__ recs,
                                                          const uint32_t* __restrict__ order,
-                                                         uint32_t* __restrict__ ticket) {
+                                                         uint32_t* __restrict__ ticket,
+                                                         unsigned long long* __restrict__ stats) {
     constexpr int RL = LaneRec<T, H>::kLen;
     __shared__ T s_mm[2 * H][kWave];   // MM[i](j) of lane l at s_mm[2*i + j][l]
     __shared__ T s_v[2 * H][kWave];    // v[i](j)   (mpc.h:250)
@@ -218,12 +222,14 @@ __global__ __launch_bounds__(64, 1) void lane_pg_kernel(Args g, Knobs kn, const 
     bool have = false;        // this lane holds an unfinished instance
     bool exhausted = false;   // the ticket ran past n: nothing left to pull
     uint32_t flags = 0;
+    uint32_t wave_iters = 0, refills = 0;   // occupancy statistics (two atomics per wave at exit)
 
 #pragma unroll 1
     while (true) {
         // ---- refill (rare, wave-uniform branch): free lanes pull the next instance; instances the
         // CD phase already finished are written out on the spot
         if (__ballot(!have && !exhausted) != 0ull) {
+            ++refills;
             if (!have && !exhausted) {
                 const uint32_t t = atomicAdd(ticket, 1u);
                 if ((int64_t)t >= g.n) {
@@ -298,6 +304,7 @@ __global__ __launch_bounds__(64, 1) void lane_pg_kernel(Args g, Knobs kn, const 
                 u[q] = clamp3(vn + beta * (vn - v_old), m.lo(j), m.hi(j));         // mpc.h:343
             }
         ++iter;
+        ++wave_iters;
         const bool cap = have && iter >= kn.max_iter;           // mpc.h:271
         if (__ballot(cap) != 0ull) {
             if (cap) {
@@ -308,6 +315,187 @@ __global__ __launch_bounds__(64, 1) void lane_pg_kernel(Args g, Knobs kn, const 
         }
     }
     if (g.flags && flags) atomicOr(g.flags, flags);
+    if (stats && lane == 0) {
+        atomicAdd(&stats[0], (unsigned long long)wave_iters);   // wave-iterations executed
+        atomicAdd(&stats[1], (unsigned long long)refills);      // refill blocks executed
+    }
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>)
+template <class F, int... Is> TPC_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F> TPC_DEV void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// ------------------------------------------------------------------------------------------------
+// Phase 2, fused and software-pipelined form: the throughput kernel.  Same arithmetic as
+// lane_pg_kernel, scheduled for ONE wave per SIMD, where (measured, scripts/ubench_dp.hip) every
+// instruction of any kind costs one ~2.1 ns issue slot -- the fp64 VALU rate at the ~2.0 GHz the
+// chip holds under fp64 load -- and nothing hides LDS latency but the wave's own instruction stream:
+//   * the backward pass, the stop test and the projected-gradient update are fused per horizon
+//     step: as soon as df[i] exists its contribution to max|df| is taken and u[i], v[i] are
+//     advanced speculatively.  dlib updates only when the stop test fails; a lane that stops
+//     publishes the controls it had BEFORE this update (u[0] is all the caller receives, so only
+//     u[0] is kept) and refills, so the speculation is never observable;
+//   * MM (read once per iteration) and v (read once, written once) live in LDS as [var][lane]
+//     columns (40 KB per wave at H=20 fp64: four waves fill the CU's 160 KB); each step's four
+//     values are fetched ONE STEP AHEAD into a small register ring, so their latency hides under
+//     the previous step's ~55 instructions; __builtin_amdgcn_sched_barrier(0) pins the prefetch at
+//     the top of its step.  u and the forward-pass array w stay in VGPRs.
+// Used whenever the caller does not ask for the controller state back (controls_inout / v_inout).
+// An AGPR-resident variant (v_accvgpr_read/write instead of LDS) was measured 2.5 % slower: twelve
+// moves per step cost more issue slots than three LDS instructions.
+template <typename T, int I, int H, class Model, class Args>
+__global__ __launch_bounds__(64, 1) void lane_pg_fused_kernel(Args g, Knobs kn, const T* __restrict__ recs,
+                                                              const uint32_t* __restrict__ order,
+                                                              uint32_t* __restrict__ ticket,
+                                                              unsigned long long* __restrict__ stats) {
+    constexpr int RL = LaneRec<T, H>::kLen;
+    __shared__ T s_mm[2 * H][kWave];
+    __shared__ T s_v[2 * H][kWave];
+    const int lane = threadIdx.x;
+    const T eps = (T)kn.eps;
+
+    Model m;
+    T u[2 * H], w[2 * H];
+    T u0_prev[2] = {(T)0, (T)0};
+    T inv_lambda = (T)0, beta = (T)0;
+    int64_t k = 0;
+    uint32_t iter = 0;
+    bool have = false, exhausted = false;
+    uint32_t flags = 0;
+    uint32_t wave_iters = 0, refills = 0;
+#pragma unroll
+    for (int q = 0; q < 2 * H; ++q) { u[q] = (T)0; s_mm[q][lane] = (T)0; s_v[q][lane] = (T)0; }
+
+    auto publish = [&](T a0, T a1, uint32_t it) {
+        if constexpr (std::is_same<Args, CompactArgs>::value) {
+            ((T*)g.front)[k] = a0;
+            ((T*)g.rear)[k] = a1;
+        } else {
+            ((T*)g.u0)[k] = a0;
+            if (I == 2) ((T*)g.u0)[g.ld + k] = a1;
+        }
+        if (g.iters) g.iters[k] = (int32_t)it;
+    };
+
+#pragma unroll 1
+    while (true) {
+        // ---- refill (rare, wave-uniform branch): free lanes pull the next instance of the
+        // longest-first queue; instances the CD phase already finished are written out on the spot.
+        // (A wave-private pool of 64 tickets per atomic was tried: waves hoard the tail of the
+        // queue and the kernel gets slower.)
+        if (__ballot(!have && !exhausted) != 0ull) {
+            ++refills;
+            if (!have && !exhausted) {
+                const uint32_t t = atomicAdd(ticket, 1u);
+                if ((int64_t)t >= g.n) {
+                    exhausted = true;
+                } else {
+                    k = (int64_t)order[t];
+                    const T* rec = recs + k * RL;
+                    m.load(g, k);   // input loads go out together with the record loads
+#pragma unroll
+                    for (int q = 0; q < 2 * H; ++q)
+                        if ((q & 1) < I) u[q] = rec[q];
+                    const T lambda = rec[2 * H];
+                    const uint64_t meta = load_meta<T>(rec + 2 * H + 1);
+                    iter = (uint32_t)meta;
+                    if (meta & kMetaNonFinite) flags |= 0x1u;
+                    const bool vinit = (meta & kMetaVInit) != 0;   // mpc.h:330-334, else a fresh v = 0
+#pragma unroll
+                    for (int q = 0; q < 2 * H; ++q)
+                        if ((q & 1) < I) s_v[q][lane] = vinit ? u[q] : (T)0;
+                    if ((meta & kMetaStopped) || iter >= kn.max_iter) {
+                        if (!(meta & kMetaStopped)) flags |= 0x2u;
+                        publish(u[0], u[1], iter);
+                    } else {
+                        linear_term<T, I, H>(m, w, [&](int q, T val) { s_mm[q][lane] = val; });
+                        inv_lambda = (T)1.0 / lambda;                         // mpc.h:342
+                        const T sq = tsqrt(lambda);
+                        beta = (sq - (T)1) / (sq + (T)1);                     // mpc.h:343
+                        have = true;
+                    }
+                }
+            }
+        }
+        if (__ballot(have) == 0ull) {
+            if (__ballot(!exhausted) == 0ull) break;   // every lane saw the end of the queue
+            continue;                                  // drew only finished instances: pull again
+        }
+
+        // ring slot for the last horizon step: fetched now, hidden under the forward pass
+        T pm[2][2], pv[2][2];
+#pragma unroll
+        for (int j = 0; j < I; ++j) {
+            pm[(H - 1) & 1][j] = s_mm[2 * (H - 1) + j][lane];
+            pv[(H - 1) & 1][j] = s_v[2 * (H - 1) + j][lane];
+        }
+        // ---- forward pass: M[i] = A*M[i-1] + B*u[i]                       (mpc.h:275-277)
+        T m0, m1;
+        m.first(m0, m1, &u[0]);
+        w[0] = m0; w[1] = m1;
+#pragma unroll
+        for (int i = 1; i < H; ++i) {
+            m.fwd(m0, m1, &u[2 * i]);
+            w[2 * i] = m0; w[2 * i + 1] = m1;
+        }
+        // ---- backward pass fused with the stop test and the speculative update
+        u0_prev[0] = u[0]; u0_prev[1] = u[1];
+        T acc[4] = {(T)0, (T)0, (T)0, (T)0};
+        T n0 = m0 * m.Q(0), n1 = m1 * m.Q(1);                                    // mpc.h:278-279 (i = H-1)
+        static_for<H>([&](auto ic) {
+            constexpr int i = H - 1 - decltype(ic)::value;
+            constexpr int cur = i & 1, nxt = (i - 1) & 1;
+            if constexpr (i > 0) {   // prefetch step i-1 while step i computes
+                static_for<I>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    pm[nxt][j] = s_mm[2 * (i - 1) + j][lane];
+                    pv[nxt][j] = s_v[2 * (i - 1) + j][lane];
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (i < H - 1) m.bwd(n0, n1, w[2 * i], w[2 * i + 1]);     // mpc.h:280-281
+            T vn[2];
+            static_for<I>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                constexpr int q = 2 * i + j;
+                const T uu = u[q];
+                const T dd = (pm[cur][j] + m.btm(j, n0, n1)) + uu * m.R(j);     // mpc.h:283
+                const T up = (uu <= m.lo(j)) ? (T)0 : dd;                       // mpc.h:298-299
+                const T dn = (uu >= m.hi(j)) ? (T)0 : -dd;
+                acc[(i * I + j) & 3] = tmax(acc[(i * I + j) & 3], tmax(up, dn));
+                vn[j] = clamp3(uu - inv_lambda * dd, m.lo(j), m.hi(j));         // mpc.h:342
+                u[q] = clamp3(vn[j] + beta * (vn[j] - pv[cur][j]), m.lo(j), m.hi(j));   // mpc.h:343
+                s_v[q][lane] = vn[j];
+                asm volatile("" : "+v"(u[q]));   // keep the update in its step (LLVM would sink it)
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        const T max_df = tmax(tmax(acc[0], acc[1]), tmax(acc[2], acc[3]));
+        ++wave_iters;
+        const bool stop = have && (max_df < eps);                               // mpc.h:310-311
+        if (__ballot(stop) != 0ull) {
+            if (stop) {
+                publish(u0_prev[0], u0_prev[1], iter);
+                have = false;
+            }
+        }
+        ++iter;
+        const bool cap = have && iter >= kn.max_iter;                           // mpc.h:271
+        if (__ballot(cap) != 0ull) {
+            if (cap) {
+                flags |= 0x2u;
+                publish(u[0], u[1], iter);
+                have = false;
+            }
+        }
+    }
+    if (g.flags && flags) atomicOr(g.flags, flags);
+    if (stats && lane == 0) {
+        atomicAdd(&stats[0], (unsigned long long)wave_iters);
+        atomicAdd(&stats[1], (unsigned long long)refills);
+    }
 }
 
 }  // namespace tpc

@@ -23,11 +23,17 @@ inline int pg_grid(int64_t n) {
     return (int)(need < waves ? need : waves);
 }
 
+// The fused PG kernel publishes controls[0] only; a caller that wants the controller state back
+// (warm-start chains, tpc_mpc_rollout) gets the kernel that keeps it.
+inline bool wants_state(const CompactArgs&) { return false; }
+inline bool wants_state(const GeneralArgs& a) { return a.controls != nullptr || a.v != nullptr; }
+
 template <typename T, int I, class Model, class Args>
 hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
     if (a.n <= 0) return hipSuccess;
     T* recs = (T*)ws.state;
     hipError_t e = hipMemsetAsync(ws.ticket, 0, sizeof(uint32_t), s);
+    if (e == hipSuccess) e = hipMemsetAsync(ws.stats, 0, 2 * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
     const int cd_grid = (int)((a.n + kWave - 1) / kWave);
     if (ws.ev) (void)hipEventRecord(ws.ev[0], s);
@@ -38,8 +44,12 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
     e = order_desc(ws.keys, ws.order, a.n, ws.sort_temp, s);
     if (e != hipSuccess) return e;
     if (ws.ev) (void)hipEventRecord(ws.ev[1], s);
-    hipLaunchKernelGGL((lane_pg_kernel<T, I, kH, Model, Args>), dim3(pg_grid(a.n)), dim3(kWave), 0, s, a, k,
-                       (const T*)recs, (const uint32_t*)ws.order, ws.ticket);
+    if (wants_state(a))
+        hipLaunchKernelGGL((lane_pg_kernel<T, I, kH, Model, Args>), dim3(pg_grid(a.n)), dim3(kWave), 0, s, a, k,
+                           (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats);
+    else
+        hipLaunchKernelGGL((lane_pg_fused_kernel<T, I, kH, Model, Args>), dim3(pg_grid(a.n)), dim3(kWave), 0, s,
+                           a, k, (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats);
     e = hipGetLastError();
     if (ws.ev) (void)hipEventRecord(ws.ev[2], s);
     return e;

@@ -43,6 +43,18 @@ template <> TPC_DEV float tsqrt<float>(float x) { return __builtin_sqrtf(x); }
 template <typename T> TPC_DEV bool tfinite(T x) { return tabs(x) <= (T)1.7976931348623157e308 && x == x; }
 template <> TPC_DEV bool tfinite<float>(float x) { return tabs(x) <= 3.4028234663852886e38f && x == x; }
 
+// A multiply the optimiser cannot look into (same instruction, same rounding).  Used where a value
+// is deliberately RE-computed instead of kept in a register: common-subexpression elimination would
+// otherwise merge the re-computation with the original and keep the value alive.
+template <bool OPAQUE> TPC_DEV double tmul(double x, double y) {
+    if constexpr (OPAQUE) { double r; asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+    else return x * y;
+}
+template <bool OPAQUE> TPC_DEV float tmul(float x, float y) {
+    if constexpr (OPAQUE) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+    else return x * y;
+}
+
 // ------------------------------------------------------------------------------------------------
 // General model: A 2x2, B 2xI, C, Q, R, lo, hi per instance (dlib::mpc<2,I,H> constructor
 // arguments, mpc.h:51-59), plus x0 and per-step targets read from the SoA batch on demand.
@@ -101,17 +113,17 @@ struct GeneralModel {
     }
 
     // M <- B*u                                  (mpc.h:275)
-    TPC_DEV void first(T& m0, T& m1, const T* u) const {
-        T s0 = b[0][0] * u[0], s1 = b[1][0] * u[0];
-        if (I_ == 2) { s0 = s0 + b[0][I_ - 1] * u[I_ - 1]; s1 = s1 + b[1][I_ - 1] * u[I_ - 1]; }
+    template <bool OP = false> TPC_DEV void first(T& m0, T& m1, const T* u) const {
+        T s0 = tmul<OP>(b[0][0], u[0]), s1 = tmul<OP>(b[1][0], u[0]);
+        if (I_ == 2) { s0 = s0 + tmul<OP>(b[0][I_ - 1], u[I_ - 1]); s1 = s1 + tmul<OP>(b[1][I_ - 1], u[I_ - 1]); }
         m0 = s0; m1 = s1;
     }
     // M <- A*M + B*u                            (mpc.h:277)
-    TPC_DEV void fwd(T& m0, T& m1, const T* u) const {
+    template <bool OP = false> TPC_DEV void fwd(T& m0, T& m1, const T* u) const {
         T s0, s1;
-        first(s0, s1, u);
-        const T n0 = (a00 * m0 + a01 * m1) + s0;
-        const T n1 = (a10 * m0 + a11 * m1) + s1;
+        first<OP>(s0, s1, u);
+        const T n0 = (tmul<OP>(a00, m0) + tmul<OP>(a01, m1)) + s0;
+        const T n1 = (tmul<OP>(a10, m0) + tmul<OP>(a11, m1)) + s1;
         m0 = n0; m1 = n1;
     }
     // M <- Q.*W + trans(A)*N                    (mpc.h:279 then :281)
@@ -168,9 +180,9 @@ struct CompactModel {
         m0 = a * u[1];
         m1 = c * u[0] - c * u[1];
     }
-    TPC_DEV void fwd(T& m0, T& m1, const T* u) const {
-        const T n0 = (m0 + a * m1) + a * u[1];
-        const T n1 = m1 + (c * u[0] - c * u[1]);
+    template <bool OP = false> TPC_DEV void fwd(T& m0, T& m1, const T* u) const {
+        const T n0 = (m0 + tmul<OP>(a, m1)) + tmul<OP>(a, u[1]);
+        const T n1 = m1 + (tmul<OP>(c, u[0]) - tmul<OP>(c, u[1]));
         m0 = n0; m1 = n1;
     }
     TPC_DEV void bwd(T& n0, T& n1, T w0, T w1) const {

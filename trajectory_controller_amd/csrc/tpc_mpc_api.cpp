@@ -181,6 +181,7 @@ hipError_t dispatch_general(int algo, int I, int H, int dtype, const GeneralArgs
 int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n, Workspace* ws) {
     ws->state = nullptr;
     ws->ticket = h->ws_words;
+    ws->stats = (unsigned long long*)(h->ws_words + 4);
     ws->capacity_bytes = 0;
     ws->ev = h->profiling ? h->ev : nullptr;
     h->ev_valid = h->profiling;
@@ -576,6 +577,17 @@ int tpc_mpc_last_kernel_times(tpc_mpc_handle h, double* first_ms, double* second
     if (first_ms) *first_ms = a;
     if (second_ms) *second_ms = b;
     if (algo) *algo = h->last_algo;
+    return TPC_MPC_OK;
+}
+
+int tpc_mpc_last_lane_stats(tpc_mpc_handle h, uint64_t* wave_iterations, uint64_t* refill_blocks) {
+    if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+    HIP_TRY(h, hipSetDevice(h->device));
+    unsigned long long st[2] = {0, 0};
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(st, h->ws_words + 4, sizeof(st), hipMemcpyDeviceToHost));
+    if (wave_iterations) *wave_iterations = st[0];
+    if (refill_blocks) *refill_blocks = st[1];
     return TPC_MPC_OK;
 }
 

@@ -86,6 +86,12 @@ class MpcSolver:
         self._check(self._lib.tpc_mpc_last_kernel_times(self._h, C.byref(a), C.byref(b), C.byref(algo)))
         return a.value, b.value, algo.value
 
+    def last_lane_stats(self):
+        """(wave_iterations, refill_blocks) of the last LANE solve; synchronises the device."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.tpc_mpc_last_lane_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     # -- the call being replaced ------------------------------------------------------------------
     def mpc_controller_tobi(self, v: float, delta_y: float, delta_phi: float, **over):
         """mpcControllerTobi(v, delta_y, delta_phi, &front, &rear): returns (front, rear)."""

@@ -9,7 +9,7 @@ from trajectory_controller_amd import MpcSolver
 
 H = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 dtype = sys.argv[2] if len(sys.argv) > 2 else "f64"
-n = 65536
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 tdt = torch.float64 if dtype == "f64" else torch.float32
 v = torch.full((n,), 3.9, dtype=tdt, device="cuda")
 dy = torch.full((n,), 0.45, dtype=tdt, device="cuda")

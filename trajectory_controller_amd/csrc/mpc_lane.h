@@ -345,15 +345,31 @@ template <int N, class F> TPC_DEV void static_for(F&& f) { static_for_impl(f, st
 // Used whenever the caller does not ask for the controller state back (controls_inout / v_inout).
 // An AGPR-resident variant (v_accvgpr_read/write instead of LDS) was measured 2.5 % slower: twelve
 // moves per step cost more issue slots than three LDS instructions.
+// fp32 halves the register footprint: u, w, MM and v all fit the VGPR file (4 x 2H floats), so the
+// fp32 kernel uses no LDS at all and two waves share a SIMD, where 32-bit VALU instructions issue
+// at their 2-cycle rate instead of one per 4-cycle slot.  (With MM and v in LDS, two waves per SIMD
+// gained nothing: eight waves' ds_read2/ds_write kept the CU's one LDS pipe busy 90 % of the time.)
+template <typename T, int H> struct FusedOcc { static constexpr int value = (sizeof(T) == 4 && H <= 20) ? 2 : 1; };
+template <typename T, int H> struct FusedInRegs { static constexpr bool value = sizeof(T) == 4 && H <= 20; };
+
 template <typename T, int I, int H, class Model, class Args>
-__global__ __launch_bounds__(64, 1) void lane_pg_fused_kernel(Args g, Knobs kn, const T* __restrict__ recs,
+__global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::value)) void lane_pg_fused_kernel(Args g, Knobs kn, const T* __restrict__ recs,
                                                               const uint32_t* __restrict__ order,
                                                               uint32_t* __restrict__ ticket,
                                                               unsigned long long* __restrict__ stats) {
     constexpr int RL = LaneRec<T, H>::kLen;
-    __shared__ T s_mm[2 * H][kWave];
-    __shared__ T s_v[2 * H][kWave];
-    const int lane = threadIdx.x;
+    // FusedOcc waves per workgroup, each wave an independent solver using its own 64 columns (no
+    // barrier anywhere): one 40 KB workgroup per SIMD pair is what the CU is known to co-schedule.
+    constexpr int BT = kWave * FusedOcc<T, H>::value;
+    constexpr bool REGS = FusedInRegs<T, H>::value;
+    __shared__ T s_mm[REGS ? 1 : 2 * H][BT];
+    __shared__ T s_v[REGS ? 1 : 2 * H][BT];
+    T r_mm[REGS ? 2 * H : 1], r_v[REGS ? 2 * H : 1];   // register-resident copies (fp32)
+    const int lane = threadIdx.x;   // LDS column; ballots below are per wavefront
+    auto mm_put = [&](int q, T val) { if constexpr (REGS) r_mm[q] = val; else s_mm[q][lane] = val; };
+    auto mm_get = [&](int q) -> T { if constexpr (REGS) return r_mm[q]; else return s_mm[q][lane]; };
+    auto v_put = [&](int q, T val) { if constexpr (REGS) r_v[q] = val; else s_v[q][lane] = val; };
+    auto v_get = [&](int q) -> T { if constexpr (REGS) return r_v[q]; else return s_v[q][lane]; };
     const T eps = (T)kn.eps;
 
     Model m;
@@ -366,7 +382,7 @@ __global__ __launch_bounds__(64, 1) void lane_pg_fused_kernel(Args g, Knobs kn, 
     uint32_t flags = 0;
     uint32_t wave_iters = 0, refills = 0;
 #pragma unroll
-    for (int q = 0; q < 2 * H; ++q) { u[q] = (T)0; s_mm[q][lane] = (T)0; s_v[q][lane] = (T)0; }
+    for (int q = 0; q < 2 * H; ++q) { u[q] = (T)0; mm_put(q, (T)0); v_put(q, (T)0); }
 
     auto publish = [&](T a0, T a1, uint32_t it) {
         if constexpr (std::is_same<Args, CompactArgs>::value) {
@@ -405,12 +421,12 @@ __global__ __launch_bounds__(64, 1) void lane_pg_fused_kernel(Args g, Knobs kn, 
                     const bool vinit = (meta & kMetaVInit) != 0;   // mpc.h:330-334, else a fresh v = 0
 #pragma unroll
                     for (int q = 0; q < 2 * H; ++q)
-                        if ((q & 1) < I) s_v[q][lane] = vinit ? u[q] : (T)0;
+                        if ((q & 1) < I) v_put(q, vinit ? u[q] : (T)0);
                     if ((meta & kMetaStopped) || iter >= kn.max_iter) {
                         if (!(meta & kMetaStopped)) flags |= 0x2u;
                         publish(u[0], u[1], iter);
                     } else {
-                        linear_term<T, I, H>(m, w, [&](int q, T val) { s_mm[q][lane] = val; });
+                        linear_term<T, I, H>(m, w, [&](int q, T val) { mm_put(q, val); });
                         inv_lambda = (T)1.0 / lambda;                         // mpc.h:342
                         const T sq = tsqrt(lambda);
                         beta = (sq - (T)1) / (sq + (T)1);                     // mpc.h:343
@@ -428,8 +444,8 @@ __global__ __launch_bounds__(64, 1) void lane_pg_fused_kernel(Args g, Knobs kn, 
         T pm[2][2], pv[2][2];
 #pragma unroll
         for (int j = 0; j < I; ++j) {
-            pm[(H - 1) & 1][j] = s_mm[2 * (H - 1) + j][lane];
-            pv[(H - 1) & 1][j] = s_v[2 * (H - 1) + j][lane];
+            pm[(H - 1) & 1][j] = mm_get(2 * (H - 1) + j);
+            pv[(H - 1) & 1][j] = v_get(2 * (H - 1) + j);
         }
         // ---- forward pass: M[i] = A*M[i-1] + B*u[i]                       (mpc.h:275-277)
         T m0, m1;
@@ -450,8 +466,8 @@ __global__ __launch_bounds__(64, 1) void lane_pg_fused_kernel(Args g, Knobs kn, 
             if constexpr (i > 0) {   // prefetch step i-1 while step i computes
                 static_for<I>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
-                    pm[nxt][j] = s_mm[2 * (i - 1) + j][lane];
-                    pv[nxt][j] = s_v[2 * (i - 1) + j][lane];
+                    pm[nxt][j] = mm_get(2 * (i - 1) + j);
+                    pv[nxt][j] = v_get(2 * (i - 1) + j);
                 });
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -467,7 +483,7 @@ __global__ __launch_bounds__(64, 1) void lane_pg_fused_kernel(Args g, Knobs kn, 
                 acc[(i * I + j) & 3] = tmax(acc[(i * I + j) & 3], tmax(up, dn));
                 vn[j] = clamp3(uu - inv_lambda * dd, m.lo(j), m.hi(j));         // mpc.h:342
                 u[q] = clamp3(vn[j] + beta * (vn[j] - pv[cur][j]), m.lo(j), m.hi(j));   // mpc.h:343
-                s_v[q][lane] = vn[j];
+                v_put(q, vn[j]);
                 asm volatile("" : "+v"(u[q]));   // keep the update in its step (LLVM would sink it)
             });
             __builtin_amdgcn_sched_barrier(0);
@@ -492,7 +508,7 @@ __global__ __launch_bounds__(64, 1) void lane_pg_fused_kernel(Args g, Knobs kn, 
         }
     }
     if (g.flags && flags) atomicOr(g.flags, flags);
-    if (stats && lane == 0) {
+    if (stats && (lane & (kWave - 1)) == 0) {
         atomicAdd(&stats[0], (unsigned long long)wave_iters);
         atomicAdd(&stats[1], (unsigned long long)refills);
     }

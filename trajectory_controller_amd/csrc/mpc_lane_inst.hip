@@ -1,5 +1,7 @@
 // One translation unit per horizon (compile with -DTPC_LANE_H=<H>): instantiates the LANE kernels
 // for fp64/fp32, compact and general (I = 1, 2) models, and exports their launchers.
+#include <cstdint>
+
 #include "mpc_lane.h"
 
 #ifndef TPC_LANE_H
@@ -12,15 +14,19 @@ namespace {
 
 constexpr int kH = TPC_LANE_H;
 
-// Persistent-wave count of the PG kernel: one wave per SIMD (the kernels need > 256 VGPRs).
-inline int pg_grid(int64_t n) {
-    int dev = 0;
+// Persistent-wave count of a PG kernel: every wave must be resident at once (the queue is pulled,
+// not pushed), so the grid is what the occupancy query says the chip holds, capped by the work.
+// `block` threads per workgroup; at most 4 workgroups per CU are used (one per SIMD or SIMD pair).
+template <class Kernel>
+inline int pg_grid(Kernel kernel, int block) {
+    int dev = 0, cus = 256, per_cu = 4;
     hipDeviceProp_t prop;
-    int waves = 1024;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-        waves = prop.multiProcessorCount * 4;
-    const int64_t need = (n + kWave - 1) / kWave;
-    return (int)(need < waves ? need : waves);
+        cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+    if (per_cu > 4) per_cu = 4;
+    return cus * per_cu;
 }
 
 // The fused PG kernel publishes controls[0] only; a caller that wants the controller state back
@@ -44,12 +50,19 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
     e = order_desc(ws.keys, ws.order, a.n, ws.sort_temp, s);
     if (e != hipSuccess) return e;
     if (ws.ev) (void)hipEventRecord(ws.ev[1], s);
-    if (wants_state(a))
-        hipLaunchKernelGGL((lane_pg_kernel<T, I, kH, Model, Args>), dim3(pg_grid(a.n)), dim3(kWave), 0, s, a, k,
+    if (wants_state(a)) {
+        static const int grid_cap = pg_grid(lane_pg_kernel<T, I, kH, Model, Args>, kWave);
+        const int64_t need = (a.n + kWave - 1) / kWave;
+        hipLaunchKernelGGL((lane_pg_kernel<T, I, kH, Model, Args>), dim3((unsigned)(need < grid_cap ? need : grid_cap)),
+                           dim3(kWave), 0, s, a, k, (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats);
+    } else {
+        constexpr int bt = kWave * FusedOcc<T, kH>::value;
+        static const int grid_cap = pg_grid(lane_pg_fused_kernel<T, I, kH, Model, Args>, bt);
+        const int64_t need = (a.n + bt - 1) / bt;
+        hipLaunchKernelGGL((lane_pg_fused_kernel<T, I, kH, Model, Args>),
+                           dim3((unsigned)(need < grid_cap ? need : grid_cap)), dim3(bt), 0, s, a, k,
                            (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats);
-    else
-        hipLaunchKernelGGL((lane_pg_fused_kernel<T, I, kH, Model, Args>), dim3(pg_grid(a.n)), dim3(kWave), 0, s,
-                           a, k, (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats);
+    }
     e = hipGetLastError();
     if (ws.ev) (void)hipEventRecord(ws.ev[2], s);
     return e;

@@ -440,6 +440,12 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
             continue;                                  // drew only finished instances: pull again
         }
 
+        // ---- inner loop: iterate until some lane of this wave stops or hits the cap.  Keeping the
+        // refill out of this loop leaves u with a single definition on the back-edge, so the
+        // controls stay in place instead of being copied every iteration.
+        bool stop = false, cap = false;
+#pragma unroll 1
+        do {
         // ring slot for the last horizon step: fetched now, hidden under the forward pass
         T pm[2][2], pv[2][2];
 #pragma unroll
@@ -483,28 +489,28 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
                 acc[(i * I + j) & 3] = tmax(acc[(i * I + j) & 3], tmax(up, dn));
                 vn[j] = clamp3(uu - inv_lambda * dd, m.lo(j), m.hi(j));         // mpc.h:342
                 u[q] = clamp3(vn[j] + beta * (vn[j] - pv[cur][j]), m.lo(j), m.hi(j));   // mpc.h:343
-                v_put(q, vn[j]);
                 asm volatile("" : "+v"(u[q]));   // keep the update in its step (LLVM would sink it)
+            });
+            static_for<I>([&](auto jc) {   // adjacent stores: one ds_write2st64 per step
+                constexpr int j = decltype(jc)::value;
+                v_put(2 * i + j, vn[j]);
             });
             __builtin_amdgcn_sched_barrier(0);
         });
         const T max_df = tmax(tmax(acc[0], acc[1]), tmax(acc[2], acc[3]));
         ++wave_iters;
-        const bool stop = have && (max_df < eps);                               // mpc.h:310-311
-        if (__ballot(stop) != 0ull) {
-            if (stop) {
-                publish(u0_prev[0], u0_prev[1], iter);
-                have = false;
-            }
-        }
+        stop = have && (max_df < eps);                                          // mpc.h:310-311
         ++iter;
-        const bool cap = have && iter >= kn.max_iter;                           // mpc.h:271
-        if (__ballot(cap) != 0ull) {
-            if (cap) {
-                flags |= 0x2u;
-                publish(u[0], u[1], iter);
-                have = false;
-            }
+        cap = have && !stop && iter >= kn.max_iter;                             // mpc.h:271
+        } while (__ballot(stop || cap) == 0ull);
+        if (stop) {
+            publish(u0_prev[0], u0_prev[1], iter - 1);
+            have = false;
+        }
+        if (cap) {
+            flags |= 0x2u;
+            publish(u[0], u[1], iter);
+            have = false;
         }
     }
     if (g.flags && flags) atomicOr(g.flags, flags);

@@ -190,7 +190,7 @@ def main():
         value = total / elapsed
         # dominant kernel = the longer of the two launches of a step
         dom_ms = max(k1, k2) / a.steps
-        dom_name = {1: "wave_kernel", 2: "lane_pg_kernel" if k2 >= k1 else "lane_cd_kernel"}[algo_ran]
+        dom_name = {1: "wave_kernel", 2: "lane_pg_fused_kernel" if k2 >= k1 else "lane_cd_kernel"}[algo_ran]
         alg_bytes = 5 * esz * n                       # 3 in + 2 out scalars per solve
         # the PG kernel also reads what the CD kernel left per instance (not algorithmic traffic)
         hbm_gbs = alg_bytes / (dom_ms * 1e-3) / 1e9

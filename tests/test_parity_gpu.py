@@ -309,3 +309,36 @@ def test_fp32_tolerance_sweep(torch_cuda, algo):
         assert np.all(np.isfinite(f)) and np.all(np.isfinite(r))
         assert np.median(err) < 1e-3
         assert hist[1e-2] > 0.5
+
+
+def test_mixed_horizons_65536(torch_cuda, oracle):
+    """BASELINE config 5: batch 65 536 split evenly over N in {5, 10, 20, 40}, fp64 parity against
+    the golden vectors (each horizon's first 1024 instances are the fixture ones) and fp32 sweep."""
+    from trajectory_controller_amd.synth import compact_inputs
+    torch = torch_cuda
+    Hs, per = (5, 10, 20, 40), 16384
+    parts = [compact_inputs(H, per) for H in Hs]
+    v, dy, dphi = (np.concatenate([p[c] for p in parts]) for c in range(3))
+    hz = np.repeat(np.array(Hs), per)
+    perm = np.random.default_rng(3).permutation(len(hz))          # interleave the horizons
+    tv, ty, tp = _dev(torch, v[perm], dy[perm], dphi[perm])
+    with _solver(20, "lane") as s:
+        f, r, it = s.solve_batch_compact_mixed(hz[perm], tv, ty, tp, want_iters=True)
+    with _solver(20, "auto") as s:   # 16 384 per horizon: AUTO picks the WAVE kernel for N <= 20
+        fa, ra = s.solve_batch_compact_mixed(hz[perm], tv, ty, tp)
+    assert float((fa - f).abs().max()) <= WAVE_ATOL and float((ra - r).abs().max()) <= WAVE_ATOL
+    inv = np.argsort(perm)
+    f, r, it = f.cpu().numpy()[inv], r.cpu().numpy()[inv], it.cpu().numpy()[inv]
+    for b, H in enumerate(Hs):
+        g = load_golden(f"compact_H{H}.npz")
+        sl = slice(b * per, b * per + 1024)
+        assert bits_equal(f[sl], g["front"]) and bits_equal(r[sl], g["rear"]), H
+        assert it[b * per:(b + 1) * per].max() <= 10000
+    with _solver(20, "auto", dtype="f32") as s:
+        f32, r32 = s.solve_batch_compact_mixed(hz[perm], tv.float(), ty.float(), tp.float())
+    f32, r32 = f32.cpu().numpy().astype(np.float64)[inv], r32.cpu().numpy().astype(np.float64)[inv]
+    err = np.maximum(np.abs(f32 - f), np.abs(r32 - r))
+    for b, H in enumerate(Hs):
+        e = err[b * per:(b + 1) * per]
+        print(f"fp32 vs fp64, H={H}: within " + ", ".join(f"{t:g}: {np.mean(e <= t):.3f}" for t in (1e-2, 1e-3, 1e-4, 1e-5, 1e-6)))
+        assert np.median(e) < 1e-3

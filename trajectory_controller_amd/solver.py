@@ -141,6 +141,41 @@ class MpcSolver:
             self.last_flags = flags.value
         return (front, rear, iters) if want_iters else (front, rear)
 
+    def solve_batch_compact_mixed(self, horizons, v, delta_y, delta_phi, want_iters: bool = False, **over):
+        """Mixed-horizon batch (BASELINE config 5): instance k is solved with horizon horizons[k].
+        Instances are binned by horizon and each bin goes out as one launch (the kernels are
+        specialised per horizon); results come back in the caller's order.  Arrays as in
+        solve_batch_compact; `horizons` is an integer array/tensor of the same length."""
+        torch_mode = _is_torch(v)
+        if torch_mode:
+            import torch
+            hz = torch.as_tensor(horizons, device=v.device)
+            front, rear = torch.empty_like(v), torch.empty_like(v)
+            iters = torch.empty(v.numel(), dtype=torch.int32, device=v.device) if want_iters else None
+            uniq = [int(h) for h in torch.unique(hz).tolist()]
+            pick = lambda h: torch.nonzero(hz == h, as_tuple=False).flatten()
+            take = lambda a, idx: a[idx].contiguous()
+        else:
+            hz = np.asarray(horizons)
+            v, delta_y, delta_phi = (np.ascontiguousarray(a, dtype=_NP[self._params(**over).dtype])
+                                     for a in (v, delta_y, delta_phi))
+            front, rear = np.empty_like(v), np.empty_like(v)
+            iters = np.empty(v.shape[0], dtype=np.int32) if want_iters else None
+            uniq = [int(h) for h in np.unique(hz)]
+            pick = lambda h: np.nonzero(hz == h)[0]
+            take = lambda a, idx: np.ascontiguousarray(a[idx])
+        flags = 0
+        for h in uniq:
+            idx = pick(h)
+            out = self.solve_batch_compact(take(v, idx), take(delta_y, idx), take(delta_phi, idx),
+                                           want_iters=want_iters, horizon=h, **over)
+            flags |= self.last_flags
+            front[idx], rear[idx] = out[0], out[1]
+            if want_iters:
+                iters[idx] = out[2]
+        self.last_flags = flags
+        return (front, rear, iters) if want_iters else (front, rear)
+
     def solve_batch_general(self, A, B, Cc, Q, R, lower, upper, x0, targets, controls=None,
                             v_state=None, inputs: Optional[int] = None, want_iters: bool = False,
                             **over):

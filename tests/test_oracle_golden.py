@@ -46,10 +46,9 @@ def test_general_bit_exact(oracle, I, H):
     assert bits_equal(controls[:, 0, :], u0)
 
 
-def _qp_optimum(A, B, C, Q, R, lo, hi, x0, targets, warm, iters=200000, eps=1e-10):
-    """Independent dense solve of the horizon QP (the method of dlib/test/mpc.cpp:178-253:
-    K block lower-triangular A^(r-c) B, m1 = K'QK + RR, m2 = K'Q(M - t); Gauss-Southwell
-    coordinate descent on the box)."""
+def _qp_optimum(A, B, C, Q, R, lo, hi, x0, targets, warm):
+    """Independent dense solve of the horizon QP, set up as dlib/test/mpc.cpp:178-253 does
+    (K block lower-triangular A^(r-c) B, m1 = K'QK + RR, m2 = K'Q(M - t)) and solved exactly."""
     H = targets.shape[0]
     I = B.shape[1]
     Apow = [np.eye(2)]
@@ -68,19 +67,17 @@ def _qp_optimum(A, B, C, Q, R, lo, hi, x0, targets, warm, iters=200000, eps=1e-1
     RR = np.kron(np.eye(H), np.diag(R))
     m1 = K.T @ QQ @ K + RR
     m2 = K.T @ QQ @ (M - targets.reshape(-1))
-    a = warm.reshape(-1).copy()
+    # exact box-constrained minimiser by bounded-variable least squares on the Cholesky factor:
+    # 0.5 a'm1 a + m2'a = 0.5 |L'a + L^-1 m2|^2 + const
+    from scipy.optimize import lsq_linear
+    L = np.linalg.cholesky(m1)
+    res = lsq_linear(L.T, -np.linalg.solve(L, m2), bounds=(np.tile(lo, H), np.tile(hi, H)), method="bvls",
+                     tol=1e-15, max_iter=500)
+    a = res.x
+    g = m1 @ a + m2     # KKT check of the independent solution itself
     lo_v, hi_v = np.tile(lo, H), np.tile(hi, H)
-    df = m1 @ a + m2
-    d = np.diag(m1)
-    for _ in range(iters):
-        free = ~(((a <= lo_v) & (df > 0)) | ((a >= hi_v) & (df < 0)))
-        mag = np.where(free, np.abs(df), 0.0)
-        r = int(np.argmax(mag))
-        if mag[r] < eps:
-            break
-        new = min(max(-(df[r] - d[r] * a[r]) / d[r], lo_v[r]), hi_v[r])
-        df += m1[:, r] * (new - a[r])
-        a[r] = new
+    free = ~(((a <= lo_v + 1e-12) & (g > 0)) | ((a >= hi_v - 1e-12) & (g < 0)))
+    assert np.abs(g[free]).max(initial=0.0) < 1e-9
     return a.reshape(H, I)
 
 

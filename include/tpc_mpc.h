@@ -165,6 +165,32 @@ int tpc_mpc_rollout(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mpc_gen
                     void* states_out, int32_t* iters_out, uint32_t* flags_out, int mem,
                     void* stream);
 
+/* ---- batched cycle(): raw trajectories in, CarCommand fields out -------------------------------- */
+
+/* Polylines of n instances, SoA: point i of instance k at base[i*ld + k] (float), `count[k]` points
+ * used (<= max_points).  Fields of street_environment::TrajectoryPoint the module reads:
+ * position.x/y, directory.x/y, velocity. */
+typedef struct tpc_mpc_trajectories {
+    int64_t n, ld;
+    int32_t max_points, reserved;
+    const float *pos_x, *pos_y, *dir_x, *dir_y, *velocity;
+    const int32_t* count;
+    const float* car_velocity;   /* car->velocity()                                    (follower.cpp:78)  */
+    const float* look_ahead;     /* distanceToTrajectoryPoint after the lookup/FOH rule (follower.cpp:66-73) */
+} tpc_mpc_trajectories;
+
+/* Replaces, for n independent controllers in DEVICE memory, the tobiMPC branch of cycle():
+ * getTrajectoryPoint (src/trajectory_point_follower.cpp:392-443, without the stateful crossing-stop
+ * PID of :445-473), the speed clamp and target extraction (:78-85), the velocity lookup (:323;
+ * lookup_x/lookup_y of lookup_n entries, ascending x, piecewise linear, clamped; lookup_n = 0 keeps
+ * the speed), mpcControllerTobi (:97) and the crossing rule (:277-283: targetSpeed < 0.5 zeroes the
+ * steering).  Outputs: steering_front/rear (double), target_speed, target_distance (float;
+ * CarCommand::State fields of :114-117).  fp64 solve; uses p's compact-model fields. */
+int tpc_mpc_follow_batch(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mpc_trajectories* t,
+                         const float* lookup_x, const float* lookup_y, int32_t lookup_n,
+                         double* steering_front, double* steering_rear, float* target_speed,
+                         float* target_distance, int32_t* iters, uint32_t* flags_out, void* stream);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 
 /* No reference counterpart (the reference times nothing on this branch; its only timers are

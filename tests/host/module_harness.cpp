@@ -50,6 +50,17 @@ int main(int argc, char** argv) {
         double v = speeds[sc];
         if (std::fabs(v) < 0.1) v = 0.1;
         v = (double)(float)v;   // the velocity lookup table is a float table (follower.h:33, follower.cpp:323)
+        std::printf("{\"points\": %d, \"look_ahead\": %.9g, \"car_velocity\": %.9g, \"px\": [", sc, (double)lookAhead, (double)speeds[sc]);
+        for (size_t i = 0; i < traj->size(); ++i) std::printf("%s%.9g", i ? "," : "", (double)(*traj)[i].position.x);
+        std::printf("], \"py\": [");
+        for (size_t i = 0; i < traj->size(); ++i) std::printf("%s%.9g", i ? "," : "", (double)(*traj)[i].position.y);
+        std::printf("], \"dx\": [");
+        for (size_t i = 0; i < traj->size(); ++i) std::printf("%s%.9g", i ? "," : "", (double)(*traj)[i].directory.x);
+        std::printf("], \"dy\": [");
+        for (size_t i = 0; i < traj->size(); ++i) std::printf("%s%.9g", i ? "," : "", (double)(*traj)[i].directory.y);
+        std::printf("], \"vel\": [");
+        for (size_t i = 0; i < traj->size(); ++i) std::printf("%s%.9g", i ? "," : "", (double)(*traj)[i].velocity);
+        std::printf("], \"target_distance\": %.9g}\n", (double)st->targetDistance);
         std::printf("{\"scenario\": %d, \"ok\": %s, \"v\": %.17g, \"y_soll\": %.17g, \"phi_soll\": %.17g, "
                     "\"steering_front\": %.17g, \"steering_rear\": %.17g, \"targetSpeed\": %.9g, \"driving\": %d}\n",
                     sc, ok ? "true" : "false", v, (double)tp.position.y,

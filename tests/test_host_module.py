@@ -54,3 +54,99 @@ def test_cycle_matches_reference_solver(tmp_path, oracle, H):
             assert abs(s["steering_front"] - f[i]) <= 1e-9 and abs(s["steering_rear"] - rr[i]) <= 1e-9
         assert s["driving"] == 1
     assert lines[-1] == {"idle_state": True, "priority": 100}
+
+
+def _traj_point_np(px, py, dx, dy, vel, count, want):
+    """float32 restatement of the module shim's getTrajectoryPoint (host/trajectory_point_controller.cpp,
+    reference src/trajectory_point_follower.cpp:392-443) for one polyline -- test infrastructure."""
+    f = np.float32
+    ox, oy, odx, ody, ovel = f(want), f(0), f(1), f(0), f(0)
+    if count > 0:
+        walked, found = f(0), False
+        for i in range(1, count):
+            ex, ey = f(px[i - 1] - px[i]), f(py[i - 1] - py[i])
+            ln = f(np.sqrt(f(f(ex * ex) + f(ey * ey))))
+            walked = f(walked + ln)
+            if walked > want:
+                back = f(walked - want)
+                nx, ny = (f(ex / ln), f(ey / ln)) if ln > 0 else (f(0), f(0))
+                ox, oy = f(px[i] + f(nx * back)), f(py[i] + f(ny * back))
+                odx, ody, ovel, found = dx[i], dy[i], vel[i], True
+                break
+        if not found:
+            j = count - 1
+            ox, oy, odx, ody, ovel = px[j], py[j], dx[j], dy[j], vel[j]
+    return ox, oy, odx, ody, ovel, f(np.sqrt(f(f(ox * ox) + f(oy * oy))))
+
+
+@pytest.mark.gpu
+def test_follow_batch_matches_module_and_oracle(tmp_path, oracle):
+    """tpc_mpc_follow_batch (batched getTrajectoryPoint + target extraction + solve + crossing rule)
+    against (1) the C++ module ticking the same trajectories one by one and (2) a float32 numpy
+    restatement + the oracle on a large random batch with ragged point counts."""
+    import torch
+    from trajectory_controller_amd import MpcSolver
+    H = 10
+    exe = _build_harness(tmp_path)
+    r = subprocess.run([exe, str(H)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    pts = [l for l in lines if "points" in l]
+    scen = [l for l in lines if "scenario" in l]
+    P = len(pts[0]["px"])
+    dev = "cuda:0"
+    t32 = lambda key: torch.tensor([p[key] for p in pts], dtype=torch.float32, device=dev).T.contiguous()
+    cnt = torch.full((len(pts),), P, dtype=torch.int32, device=dev)
+    carv = torch.tensor([p["car_velocity"] for p in pts], dtype=torch.float32, device=dev)
+    look = torch.tensor([p["look_ahead"] for p in pts], dtype=torch.float32, device=dev)
+    with MpcSolver(horizon=H) as s:
+        f, rr, ts, td = s.follow_batch(t32("px"), t32("py"), t32("dx"), t32("dy"), t32("vel"), cnt, carv, look)
+    for i, sc in enumerate(scen):   # the module, one cycle() at a time
+        assert abs(float(f[i]) - sc["steering_front"]) <= 1e-9 and abs(float(rr[i]) - sc["steering_rear"]) <= 1e-9
+        assert float(ts[i]) == np.float32(sc["targetSpeed"]) and float(td[i]) == np.float32(pts[i]["target_distance"])
+
+    # large random batch, ragged counts (0, 1 and short polylines included), with a velocity lookup table
+    rng = np.random.default_rng(11)
+    n, P = 20000, 24
+    seg = rng.uniform(0.02, 0.25, size=(P, n)).astype(np.float32)
+    ang = np.cumsum(rng.uniform(-0.15, 0.15, size=(P, n)), axis=0).astype(np.float32)
+    px = np.cumsum(seg * np.cos(ang), axis=0, dtype=np.float32)
+    py = (np.cumsum(seg * np.sin(ang), axis=0, dtype=np.float32) + rng.uniform(-0.2, 0.2, size=n).astype(np.float32))
+    dx, dy = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+    vel = rng.uniform(0.0, 2.0, size=(P, n)).astype(np.float32)
+    count = rng.integers(0, P + 1, size=n).astype(np.int32)
+    count[:3] = (0, 1, 2)
+    carv = rng.uniform(-0.2, 4.0, size=n).astype(np.float32)
+    look = rng.uniform(0.2, 2.5, size=n).astype(np.float32)
+    lut_x = np.array([0.0, 1.0, 2.5, 4.0], dtype=np.float32)
+    lut_y = np.array([0.8, 1.0, 2.0, 2.4], dtype=np.float32)
+    g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    with MpcSolver(horizon=H) as s:
+        f, rr, ts, td = s.follow_batch(g(px), g(py), g(dx), g(dy), g(vel), g(count), g(carv), g(look),
+                                       lookup=(g(lut_x), g(lut_y)))
+    f, rr, ts, td = (a.cpu().numpy() for a in (f, rr, ts, td))
+    ev, ey, ephi, ets, etd = (np.zeros(n) for _ in range(5))
+    for k in range(n):
+        ox, oy, odx, ody, ovel, dist = _traj_point_np(px[:, k], py[:, k], dx[:, k], dy[:, k], vel[:, k], int(count[k]), look[k])
+        vv = np.float64(carv[k])
+        if abs(vv) < 0.1:
+            vv = 0.1
+        vv = np.float32(vv)
+        # piecewise-linear table in float32, as the shim's LookupTable::linearSearch
+        if vv <= lut_x[0]:
+            lv = lut_y[0]
+        elif vv > lut_x[-1]:
+            lv = lut_y[-1]
+        else:
+            j = int(np.searchsorted(lut_x, vv, side="left"))
+            t = np.float32((vv - lut_x[j - 1]) / np.float32(lut_x[j] - lut_x[j - 1]))
+            lv = np.float32(lut_y[j - 1] + np.float32(t * np.float32(lut_y[j] - lut_y[j - 1])))
+        ev[k], ey[k], ephi[k] = np.float64(lv), np.float64(oy), np.arctan2(np.float64(ody), np.float64(odx))
+        ets[k], etd[k] = ovel, dist
+    assert np.array_equal(ts, ets.astype(np.float32)) and np.array_equal(td, etd.astype(np.float32))
+    of, orr, _ = oracle.solve_compact(H, ev, ey, ephi, nthreads=8)
+    crossing = ets < 0.5
+    of[crossing], orr[crossing] = 0.0, 0.0
+    # atan2 on the device and in glibc may differ in the last bit, so steering is compared to 1e-9
+    assert np.abs(f - of).max() <= 1e-9 and np.abs(rr - orr).max() <= 1e-9
+    assert crossing.sum() > 100 and (~crossing).sum() > 100

@@ -25,7 +25,8 @@ STATUS_NAMES = {0: "OK", 1: "BAD_ARG", 2: "BAD_WEIGHTS", 3: "BAD_BOUNDS", 4: "BA
 EXPORTS = ("tpc_mpc_default_params", "tpc_mpc_create", "tpc_mpc_destroy", "tpc_mpc_last_error",
            "tpc_mpc_supported_horizons", "tpc_mpc_abi_version", "tpc_mpc_solve_one",
            "tpc_mpc_solve_batch_compact", "tpc_mpc_solve_batch_general", "tpc_mpc_rollout",
-           "tpc_mpc_set_profiling", "tpc_mpc_last_kernel_times", "tpc_mpc_last_lane_stats")
+           "tpc_mpc_set_profiling", "tpc_mpc_last_kernel_times", "tpc_mpc_last_lane_stats",
+           "tpc_mpc_follow_batch")
 
 
 class Params(C.Structure):
@@ -45,6 +46,14 @@ class GeneralIO(C.Structure):
                 ("R", C.c_void_p), ("lower", C.c_void_p), ("upper", C.c_void_p),
                 ("x0", C.c_void_p), ("targets", C.c_void_p), ("controls_inout", C.c_void_p),
                 ("v_inout", C.c_void_p), ("u0", C.c_void_p), ("iters", C.c_void_p)]
+
+
+class Trajectories(C.Structure):
+    """struct tpc_mpc_trajectories"""
+    _fields_ = [("n", C.c_int64), ("ld", C.c_int64), ("max_points", C.c_int32), ("reserved", C.c_int32),
+                ("pos_x", C.c_void_p), ("pos_y", C.c_void_p), ("dir_x", C.c_void_p), ("dir_y", C.c_void_p),
+                ("velocity", C.c_void_p), ("count", C.c_void_p), ("car_velocity", C.c_void_p),
+                ("look_ahead", C.c_void_p)]
 
 
 class TpcMpcError(RuntimeError):
@@ -86,6 +95,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.tpc_mpc_set_profiling.argtypes = [vp, C.c_int]
     lib.tpc_mpc_last_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                               C.POINTER(C.c_int)]
+    lib.tpc_mpc_follow_batch.argtypes = [vp, C.POINTER(Params), C.POINTER(Trajectories), vp, vp, C.c_int32,
+                                         vp, vp, vp, vp, vp, u32p, vp]
     lib.tpc_mpc_last_lane_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     for name in EXPORTS:
         getattr(lib, name)   # raises AttributeError if the library lacks a declared entry point

@@ -41,6 +41,21 @@ struct RolloutStepArgs {
     int32_t* iters_out;
 };
 hipError_t launch_rollout_step(int dtype, const RolloutStepArgs& a, hipStream_t s);
+
+struct FollowArgs {
+    int64_t n, ld;
+    int max_points;
+    const float *px, *py, *dx, *dy, *vel;
+    const int32_t* count;
+    const float* car_velocity;
+    const float* look_ahead;
+    const float *lut_x, *lut_y;
+    int lut_n;
+    double *v_out, *ysoll_out, *phisoll_out;
+    float *target_speed, *target_distance;
+};
+hipError_t launch_traj_point(const FollowArgs& a, hipStream_t s);
+hipError_t launch_follow_post(int64_t n, const float* target_speed, double* front, double* rear, hipStream_t s);
 }  // namespace tpc
 
 using namespace tpc;
@@ -555,6 +570,48 @@ int tpc_mpc_rollout(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mpc_gen
         if (iters_out) HIP_TRY(h, hipMemcpyAsync(iters_out, out_base + o_iters, (size_t)steps * ld * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
     }
+    return finish_flags(h, flags_out, s);
+}
+
+int tpc_mpc_follow_batch(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mpc_trajectories* t,
+                         const float* lookup_x, const float* lookup_y, int32_t lookup_n,
+                         double* steering_front, double* steering_rear, float* target_speed,
+                         float* target_distance, int32_t* iters, uint32_t* flags_out, void* stream) {
+    int rc = check_common(h, p);
+    if (rc) return rc;
+    rc = check_compact_model(h, p);
+    if (rc) return rc;
+    if (p->dtype != TPC_MPC_F64) return fail(h, TPC_MPC_ERR_BAD_ARG, "follow_batch solves in fp64");
+    if (!t) return fail(h, TPC_MPC_ERR_BAD_ARG, "null trajectories");
+    if (t->n < 0 || t->ld < t->n || t->n > 0x7fffffffll || t->max_points < 0 || lookup_n < 0)
+        return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= n <= ld, n < 2^31, max_points >= 0, lookup_n >= 0");
+    if (t->n == 0) { if (flags_out) *flags_out = 0; return TPC_MPC_OK; }
+    if (!t->pos_x || !t->pos_y || !t->dir_x || !t->dir_y || !t->velocity || !t->count || !t->car_velocity ||
+        !t->look_ahead || !steering_front || !steering_rear || !target_speed || !target_distance ||
+        (lookup_n > 0 && (!lookup_x || !lookup_y)))
+        return fail(h, TPC_MPC_ERR_BAD_ARG, "null batch pointer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = t->n;
+    // v | y_soll | phi_soll (the compact solve's inputs), produced on device
+    const int64_t col = (n * 8 + 255) / 256 * 256;
+    rc = ensure(h, &h->roll, &h->roll_bytes, 3 * col);
+    if (rc) return rc;
+    char* b = (char*)h->roll;
+    FollowArgs fa;
+    fa.n = n; fa.ld = t->ld; fa.max_points = t->max_points;
+    fa.px = t->pos_x; fa.py = t->pos_y; fa.dx = t->dir_x; fa.dy = t->dir_y; fa.vel = t->velocity;
+    fa.count = t->count; fa.car_velocity = t->car_velocity; fa.look_ahead = t->look_ahead;
+    fa.lut_x = lookup_x; fa.lut_y = lookup_y; fa.lut_n = lookup_n;
+    fa.v_out = (double*)b; fa.ysoll_out = (double*)(b + col); fa.phisoll_out = (double*)(b + 2 * col);
+    fa.target_speed = target_speed; fa.target_distance = target_distance;
+    hipError_t e = launch_traj_point(fa, s);
+    if (e != hipSuccess) return hip_fail(h, e, "traj_point launch");
+    rc = tpc_mpc_solve_batch_compact(h, p, n, fa.v_out, fa.ysoll_out, fa.phisoll_out, steering_front,
+                                     steering_rear, iters, nullptr, TPC_MPC_DEVICE, stream);
+    if (rc) return rc;
+    e = launch_follow_post(n, target_speed, steering_front, steering_rear, s);
+    if (e != hipSuccess) return hip_fail(h, e, "follow_post launch");
     return finish_flags(h, flags_out, s);
 }
 

@@ -298,3 +298,40 @@ class MpcSolver:
                                               optr(i_out), C.byref(flags), mem, stream))
         self.last_flags = flags.value
         return c_out, s_out, i_out
+
+    def follow_batch(self, pos_x, pos_y, dir_x, dir_y, velocity, count, car_velocity, look_ahead,
+                     lookup=None, want_iters: bool = False, **over):
+        """Batched tobiMPC branch of cycle() on raw trajectories (device tensors).
+
+        pos_x .. velocity: float32 CUDA tensors [max_points, n] (point-major, SoA); count int32 [n];
+        car_velocity, look_ahead float32 [n]; lookup: optional (x, y) float32 CUDA tensors of the
+        velocity lookup table.  Returns (steering_front f64, steering_rear f64, target_speed f32,
+        target_distance f32[, iters])."""
+        import torch
+        p = self._params(**over)
+        P, n = pos_x.shape
+        dev = pos_x.device
+        for tns in (pos_x, pos_y, dir_x, dir_y, velocity):
+            if not (tns.is_cuda and tns.dtype == torch.float32 and tns.is_contiguous() and tuple(tns.shape) == (P, n)):
+                raise ValueError("trajectory arrays must be contiguous float32 CUDA tensors [max_points, n]")
+        for tns, dt in ((count, torch.int32), (car_velocity, torch.float32), (look_ahead, torch.float32)):
+            if not (tns.is_cuda and tns.dtype == dt and tns.is_contiguous() and tns.numel() == n):
+                raise ValueError("per-instance arrays must be contiguous CUDA tensors of length n")
+        tr = capi.Trajectories(n=n, ld=n, max_points=P, pos_x=pos_x.data_ptr(), pos_y=pos_y.data_ptr(),
+                               dir_x=dir_x.data_ptr(), dir_y=dir_y.data_ptr(), velocity=velocity.data_ptr(),
+                               count=count.data_ptr(), car_velocity=car_velocity.data_ptr(),
+                               look_ahead=look_ahead.data_ptr())
+        front = torch.empty(n, dtype=torch.float64, device=dev)
+        rear = torch.empty(n, dtype=torch.float64, device=dev)
+        tspeed = torch.empty(n, dtype=torch.float32, device=dev)
+        tdist = torch.empty(n, dtype=torch.float32, device=dev)
+        iters = torch.empty(n, dtype=torch.int32, device=dev) if want_iters else None
+        lx, ly, ln = (None, None, 0) if lookup is None else (lookup[0].data_ptr(), lookup[1].data_ptr(), lookup[0].numel())
+        flags = C.c_uint32(0)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        self._check(self._lib.tpc_mpc_follow_batch(self._h, C.byref(p), C.byref(tr), lx, ly, ln,
+                                                   front.data_ptr(), rear.data_ptr(), tspeed.data_ptr(),
+                                                   tdist.data_ptr(), iters.data_ptr() if want_iters else None,
+                                                   C.byref(flags), stream))
+        self.last_flags = flags.value
+        return (front, rear, tspeed, tdist, iters) if want_iters else (front, rear, tspeed, tdist)

@@ -77,6 +77,10 @@ struct tpc_mpc_context {
     // rollout working set (state, targets, controller memory, per-step iteration counts)
     void* roll = nullptr;
     int64_t roll_bytes = 0;
+    // 64 B of pinned host memory mapped into the device: solve_one's three inputs and two outputs
+    // travel through it, so a single solve costs one kernel launch and one sync, no memcpy calls
+    void* pin_host = nullptr;
+    void* pin_dev = nullptr;
     // optional kernel timing (tpc_mpc_set_profiling)
     bool profiling = false;
     bool ev_valid = false;
@@ -289,6 +293,8 @@ int tpc_mpc_create(int device, tpc_mpc_handle* out) {
     e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc((void**)&h->ws_words, 64);
     if (e == hipSuccess) e = hipMemset(h->ws_words, 0, 64);
+    if (e == hipSuccess) e = hipHostMalloc(&h->pin_host, 64, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&h->pin_dev, h->pin_host, 0);
     if (e != hipSuccess) {
         delete h;
         return fail(nullptr, TPC_MPC_ERR_HIP, std::string("create: ") + hipGetErrorString(e));
@@ -304,6 +310,7 @@ int tpc_mpc_destroy(tpc_mpc_handle h) {
     if (h->ws_words) (void)hipFree(h->ws_words);
     if (h->stage) (void)hipFree(h->stage);
     if (h->roll) (void)hipFree(h->roll);
+    if (h->pin_host) (void)hipHostFree(h->pin_host);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     delete h;
     return TPC_MPC_OK;
@@ -376,18 +383,32 @@ int tpc_mpc_solve_one(tpc_mpc_handle h, const tpc_mpc_params* p, double v, doubl
                       double delta_phi, double* steering_front, double* steering_rear) {
     if (!steering_front || !steering_rear) return fail(h, TPC_MPC_ERR_BAD_ARG, "null output pointer");
     if (!p) return fail(h, TPC_MPC_ERR_BAD_ARG, "null params");
+    if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
     tpc_mpc_params q = *p;
     if (q.algo == TPC_MPC_ALGO_AUTO && 2 * q.horizon <= kWave) q.algo = TPC_MPC_ALGO_WAVE;   // one instance: one wavefront
+    // inputs and outputs go through the handle's mapped pinned block: [v, dy, dphi, front, rear]
+    const size_t es = q.dtype == TPC_MPC_F64 ? 8 : 4;
+    char* hp = (char*)h->pin_host;
+    char* dp = (char*)h->pin_dev;
     if (q.dtype == TPC_MPC_F64) {
-        return tpc_mpc_solve_batch_compact(h, &q, 1, &v, &delta_y, &delta_phi, steering_front,
-                                           steering_rear, nullptr, nullptr, TPC_MPC_HOST, nullptr);
+        double* x = (double*)hp;
+        x[0] = v; x[1] = delta_y; x[2] = delta_phi;
+    } else {
+        float* x = (float*)hp;
+        x[0] = (float)v; x[1] = (float)delta_y; x[2] = (float)delta_phi;
     }
-    float fv = (float)v, fy = (float)delta_y, fp = (float)delta_phi, ff = 0, fr = 0;
-    int rc = tpc_mpc_solve_batch_compact(h, &q, 1, &fv, &fy, &fp, &ff, &fr, nullptr, nullptr,
-                                         TPC_MPC_HOST, nullptr);
-    *steering_front = ff;
-    *steering_rear = fr;
-    return rc;
+    int rc = tpc_mpc_solve_batch_compact(h, &q, 1, dp, dp + es, dp + 2 * es, dp + 3 * es, dp + 4 * es, nullptr,
+                                         nullptr, TPC_MPC_DEVICE, nullptr);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(nullptr));
+    if (q.dtype == TPC_MPC_F64) {
+        *steering_front = ((double*)hp)[3];
+        *steering_rear = ((double*)hp)[4];
+    } else {
+        *steering_front = ((float*)hp)[3];
+        *steering_rear = ((float*)hp)[4];
+    }
+    return TPC_MPC_OK;
 }
 
 int tpc_mpc_solve_batch_general(tpc_mpc_handle h, const tpc_mpc_params* p,

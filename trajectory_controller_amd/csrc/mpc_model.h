@@ -229,9 +229,9 @@ TPC_DEV T ctor_lambda_qdiag(const Model& m, Emit emit) {
 }
 
 // Linear term MM = trans(K)*Q*(M - target) (mpc.h:258-266); `emit(2*i + j, value)` receives
-// MM[i](j); `w` is scratch of 2*H values.
-template <typename T, int I, int H, class Model, class Emit>
-TPC_DEV void linear_term(const Model& m, T* w, Emit emit) {
+// MM[i](j).  The 2*H intermediate values go through wput(q, value) / wget(q).
+template <typename T, int I, int H, class Model, class WPut, class WGet, class Emit>
+TPC_DEV void linear_term_fn(const Model& m, WPut wput, WGet wget, Emit emit) {
     T m0 = (m.A(0, 0) * m.x0(0) + m.A(0, 1) * m.x0(1)) + m.C(0);
     T m1 = (m.A(1, 0) * m.x0(0) + m.A(1, 1) * m.x0(1)) + m.C(1);
 #pragma unroll
@@ -241,32 +241,42 @@ TPC_DEV void linear_term(const Model& m, T* w, Emit emit) {
             const T n1 = (m.A(1, 0) * m0 + m.A(1, 1) * m1) + m.C(1);
             m0 = n0; m1 = n1;
         }
-        w[2 * i] = (m0 - m.target(i, 0)) * m.Q(0);
-        w[2 * i + 1] = (m1 - m.target(i, 1)) * m.Q(1);
+        wput(2 * i, (m0 - m.target(i, 0)) * m.Q(0));
+        wput(2 * i + 1, (m1 - m.target(i, 1)) * m.Q(1));
     }
-    T n0 = w[2 * (H - 1)], n1 = w[2 * (H - 1) + 1];
+    T n0 = wget(2 * (H - 1)), n1 = wget(2 * (H - 1) + 1);
 #pragma unroll
     for (int i = H - 1; i >= 0; --i) {
         if (i < H - 1) {
-            const T t0 = w[2 * i] + (m.A(0, 0) * n0 + m.A(1, 0) * n1);
-            const T t1 = w[2 * i + 1] + (m.A(0, 1) * n0 + m.A(1, 1) * n1);
+            const T t0 = wget(2 * i) + (m.A(0, 0) * n0 + m.A(1, 0) * n1);
+            const T t1 = wget(2 * i + 1) + (m.A(0, 1) * n0 + m.A(1, 1) * n1);
             n0 = t0; n1 = t1;
         }
 #pragma unroll
         for (int j = 0; j < I; ++j) emit(2 * i + j, m.B(0, j) * n0 + m.B(1, j) * n1);
     }
 }
+// ... with the intermediates in a caller-provided register array of 2*H values.
+template <typename T, int I, int H, class Model, class Emit>
+TPC_DEV void linear_term(const Model& m, T* w, Emit emit) {
+    linear_term_fn<T, I, H>(m, [&](int q, T val) { w[q] = val; }, [&](int q) { return w[q]; }, emit);
+}
 
 // Gradient df = H*u + MM by dlib's forward/backward recurrences (mpc.h:275-283).
-// u, w are indexed [2*i + j], mm(2*i + j) returns MM[i](j); on return w[2*i + j] = df[i](j).
-template <typename T, int I, int H, class Model, class MmGet>
-TPC_DEV void gradient(const Model& m, const T* u, MmGet mm, T* w) {
+// u(2*i + j) returns controls[i](j), mm(2*i + j) returns MM[i](j); w is indexed [2*i + j] and on
+// return w[2*i + j] = df[i](j).
+template <typename T, int I, int H, class Model, class UGet, class MmGet>
+TPC_DEV void gradient_fn(const Model& m, UGet u, MmGet mm, T* w) {
     T m0, m1;
-    m.first(m0, m1, &u[0]);
+    {
+        const T ui[2] = {u(0), u(1)};
+        m.first(m0, m1, ui);
+    }
     w[0] = m0; w[1] = m1;
 #pragma unroll
     for (int i = 1; i < H; ++i) {
-        m.fwd(m0, m1, &u[2 * i]);
+        const T ui[2] = {u(2 * i), u(2 * i + 1)};
+        m.fwd(m0, m1, ui);
         w[2 * i] = m0; w[2 * i + 1] = m1;
     }
     // i = H-1: M = Q.*W, no backward term
@@ -276,8 +286,12 @@ TPC_DEV void gradient(const Model& m, const T* u, MmGet mm, T* w) {
         if (i < H - 1) m.bwd(n0, n1, w[2 * i], w[2 * i + 1]);
 #pragma unroll
         for (int j = 0; j < I; ++j)
-            w[2 * i + j] = (mm(2 * i + j) + m.btm(j, n0, n1)) + u[2 * i + j] * m.R(j);
+            w[2 * i + j] = (mm(2 * i + j) + m.btm(j, n0, n1)) + u(2 * i + j) * m.R(j);
     }
+}
+template <typename T, int I, int H, class Model, class MmGet>
+TPC_DEV void gradient(const Model& m, const T* u, MmGet mm, T* w) {
+    gradient_fn<T, I, H>(m, [&](int q) { return u[q]; }, mm, w);
 }
 
 }  // namespace tpc

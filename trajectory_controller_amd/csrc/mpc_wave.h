@@ -83,11 +83,45 @@ template <typename T, int I, int H> struct WaveIO<T, I, H, GeneralArgs> {
     }
 };
 
+// Row `slot` (= column, the Hessian is symmetric) of Hd = K'QK + R: dlib's gradient recurrences
+// (mpc.h:275-283) applied to the unit vector e_(qi,qj) with MM = 0.  B*e is a column of B at step qi
+// and zero elsewhere, so no control vector is materialised; the arithmetic is the generic one
+// (x*1 = x, x + 0 = x exactly).  row[2*i + j] = Hd[(i,j)][(qi,qj)].
+template <typename T, int I, int H, class Model>
+TPC_DEV void hessian_row(const Model& m, bool active, int qi, int qj, T* row) {
+    const T bq0 = active ? (qj == 0 ? m.B(0, 0) : m.B(0, I - 1)) : (T)0;
+    const T bq1 = active ? (qj == 0 ? m.B(1, 0) : m.B(1, I - 1)) : (T)0;
+    T m0 = (T)0, m1 = (T)0;
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        const T s0 = (i == qi) ? bq0 : (T)0, s1 = (i == qi) ? bq1 : (T)0;
+        const T n0 = (m.A(0, 0) * m0 + m.A(0, 1) * m1) + s0;
+        const T n1 = (m.A(1, 0) * m0 + m.A(1, 1) * m1) + s1;
+        m0 = n0; m1 = n1;
+        row[2 * i] = m0; row[2 * i + 1] = m1;
+    }
+    T n0 = row[2 * (H - 1)] * m.Q(0), n1 = row[2 * (H - 1) + 1] * m.Q(1);
+#pragma unroll
+    for (int i = H - 1; i >= 0; --i) {
+        if (i < H - 1) {
+            const T t0 = row[2 * i] * m.Q(0) + (m.A(0, 0) * n0 + m.A(1, 0) * n1);
+            const T t1 = row[2 * i + 1] * m.Q(1) + (m.A(0, 1) * n0 + m.A(1, 1) * n1);
+            n0 = t0; n1 = t1;
+        }
+#pragma unroll
+        for (int j = 0; j < I; ++j) {
+            const T diag = (active && i == qi && j == qj) ? m.R(j) : (T)0;
+            row[2 * i + j] = (m.B(0, j) * n0 + m.B(1, j) * n1) + diag;
+        }
+    }
+}
+
 template <typename T, int I, int H, class Model, class Args>
 __global__ __launch_bounds__(64) void wave_kernel(Args g, Knobs kn) {
     constexpr int N = I * H;
     static_assert(N <= kWave, "WAVE kernel: one variable per lane");
     __shared__ __attribute__((aligned(16))) T s_u[N + 2];
+    __shared__ __attribute__((aligned(16))) T s_w[2 * H];
     const int lane = threadIdx.x;
     const int64_t k = blockIdx.x;
     const bool active = lane < N;
@@ -100,18 +134,13 @@ __global__ __launch_bounds__(64) void wave_kernel(Args g, Knobs kn) {
 
     // ---- prologue: this lane's Hessian row, Q_diag, linear-term element, lambda
     T row[2 * H];
-    {
-        T e[2 * H];
-#pragma unroll
-        for (int q = 0; q < 2 * H; ++q) e[q] = (active && q == slot) ? (T)1 : (T)0;
-        gradient<T, I, H>(m, e, [](int) { return (T)0; }, row);   // row[2i+j] = Hd[(i,j)][q]
-    }
+    hessian_row<T, I, H>(m, active, qi, qj, row);
     T my_qd = (T)0, my_g = (T)0;
     const T lambda = ctor_lambda_qdiag<T, I, H>(m, [&](int i, int j, T val) { if (2 * i + j == slot) my_qd = val; });
-    {
-        T w[2 * H];
-        linear_term<T, I, H>(m, w, [&](int q, T val) { if (q == slot) my_g = val; });
-    }
+    // every lane computes the same linear term; its 2H intermediates are identical in all lanes,
+    // so they are parked in one small LDS vector instead of 2H registers per lane
+    linear_term_fn<T, I, H>(m, [&](int q, T val) { s_w[q] = val; }, [&](int q) { return s_w[q]; },
+                            [&](int q, T val) { if (q == slot) my_g = val; });
     const T lo = m.lo(qj), hi = m.hi(qj);
     const T eps = (T)kn.eps;
     const T inv_lambda = (T)1.0 / lambda;                 // mpc.h:342

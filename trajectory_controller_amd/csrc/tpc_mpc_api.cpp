@@ -157,7 +157,7 @@ Knobs knobs_of(const tpc_mpc_params* p) {
 
 // LANE needs enough instances to give every SIMD a full wavefront; below that WAVE's
 // one-wavefront-per-instance launch finishes sooner.  Measured crossover on MI355X (scripts/sweep.py,
-// fp64, H = 4..20): between 16 384 and 32 768 instances.
+// fp64, H = 4..20): around 30 000 - 45 000 instances, i.e. about half the chip's 65 536 LANE slots.
 // The WAVE kernel maps one decision variable to one lane, so it exists for I*H <= 64 only.
 // Returns the kernel family to run, or -1 when WAVE was demanded for a shape it cannot take.
 int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n) {
@@ -165,7 +165,7 @@ int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n) {
     if (algo == TPC_MPC_ALGO_WAVE) return wave_ok ? algo : -1;
     if (algo == TPC_MPC_ALGO_LANE) return algo;
     const int64_t lanes = (int64_t)h->cu_count * 4 * kWave;
-    return (n >= lanes * 3 / 8 || !wave_ok) ? TPC_MPC_ALGO_LANE : TPC_MPC_ALGO_WAVE;
+    return (n >= lanes / 2 || !wave_ok) ? TPC_MPC_ALGO_LANE : TPC_MPC_ALGO_WAVE;
 }
 
 int64_t lane_rec_len(int H, int dtype) {

@@ -342,3 +342,51 @@ def test_mixed_horizons_65536(torch_cuda, oracle):
         e = err[b * per:(b + 1) * per]
         print(f"fp32 vs fp64, H={H}: within " + ", ".join(f"{t:g}: {np.mean(e <= t):.3f}" for t in (1e-2, 1e-3, 1e-4, 1e-5, 1e-6)))
         assert np.median(e) < 1e-3
+
+
+@pytest.mark.parametrize("algo", ["lane", "wave"])
+def test_phase_boundaries_vs_oracle(torch_cuda, oracle, algo):
+    """The coordinate-descent / projected-gradient hand-over (mpc.h:319-335): smo_iters and
+    max_iter around each other, including 0 and caps inside the coordinate-descent phase."""
+    from trajectory_controller_amd.synth import compact_inputs
+    from trajectory_controller_amd import FLAG_MAX_ITER
+    H, n = 10, 640
+    v, dy, dphi = compact_inputs(H, n, first=7777)
+    for smo, cap in ((50, 0), (50, 1), (50, 49), (50, 50), (50, 51), (50, 300), (0, 400), (1, 400),
+                     (7, 10000), (200, 10000), (1000, 120)):
+        of, orr, oit = oracle.solve_compact(H, v, dy, dphi, max_iter=cap, smo_iters=smo, nthreads=8)
+        with _solver(H, algo, smo_iters=smo, max_iter=cap) as s:
+            f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+            flags = s.last_flags
+        assert np.array_equal(it, oit), (smo, cap)
+        if algo == "lane":
+            assert bits_equal(f, of) and bits_equal(r, orr), (smo, cap)
+        else:
+            assert max(np.abs(f - of).max(), np.abs(r - orr).max()) <= WAVE_ATOL, (smo, cap)
+        assert bool(flags & FLAG_MAX_ITER) == bool(np.any(oit >= cap)), (smo, cap)
+
+
+@pytest.mark.parametrize("algo", ["lane", "wave"])
+def test_zero_qdiag_continue_branch(torch_cuda, oracle, algo):
+    """Q = (2, 0) as in dlib's own test makes Q_diag[H-1] = 0: the `continue` of mpc.h:322 (an
+    iteration that counts but updates nothing, and may skip the v := u of mpc.h:330-334)."""
+    rng = np.random.default_rng(21)
+    I, H, n = 1, 10, 500
+    A = np.tile(np.array([1.0, 1.0, 0.0, 1.0]), (n, 1)) + rng.uniform(-0.05, 0.05, (n, 4)) * np.array([0, 1, 0, 0])
+    B = np.tile(np.array([0.0, 1.0]), (n, 1))
+    Cc = rng.uniform(-0.05, 0.1, (n, 2))
+    Q = np.tile(np.array([2.0, 0.0]), (n, 1))
+    R = rng.uniform(0.5, 2.0, (n, 1))
+    lo, hi = np.full((n, 1), -0.2), np.full((n, 1), 0.2)
+    x0 = rng.uniform(-5, 5, (n, 2)) * np.array([1.0, 0.2])
+    tg = np.zeros((n, H, 2))
+    for smo in (50, 3):
+        u0, cout, it = oracle.solve_general(I, H, A, B, Cc, Q, R, lo, hi, x0, tg, smo_iters=smo, nthreads=8)
+        with _solver(H, algo, smo_iters=smo) as s:
+            gu0, git = s.solve_batch_general(*[_soa(a) for a in (A, B, Cc, Q, R, lo, hi, x0, tg)], inputs=I,
+                                             want_iters=True)
+        assert np.array_equal(git, it), smo
+        if algo == "lane":
+            assert bits_equal(gu0.T, u0), smo
+        else:
+            assert np.abs(gu0.T - u0).max() <= WAVE_ATOL, smo

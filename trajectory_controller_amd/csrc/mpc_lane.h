@@ -1,23 +1,25 @@
-// LANE kernels: one lane per MPC instance, 64 instances per wavefront, everything in VGPRs.
+// LANE kernels: one lane per MPC instance, 64 instances per wavefront.
 //
-// Two launches per batch, both bit-faithful to dlib::mpc::solve_linear_mpc (mpc.h:253-347):
+// A batch is three launches, all bit-faithful to dlib::mpc::solve_linear_mpc (mpc.h:253-347):
 //
-//   lane_cd_kernel  coordinate-descent phase (iter < smo_iters, mpc.h:319-335).  Every lane of a
-//                   wave runs the same <= smo_iters iterations in lockstep, so there is no
-//                   divergence to manage.  Q_diag sits in LDS ([var][lane], conflict-free) because
-//                   it is read at a per-lane dynamic index.  Leaves {controls, lambda, iter} of
-//                   each instance in a per-instance record in HBM.
-//   lane_pg_kernel  accelerated projected-gradient phase (mpc.h:336-345).  Iteration counts
-//                   differ 30x between instances, so waves are persistent
-//                   and a lane whose instance has converged pulls the next unfinished instance
-//                   from an atomic ticket: no lane waits for the slowest instance of its wave.
+//   lane_cd_kernel        coordinate-descent phase (iter < smo_iters, mpc.h:319-335).  Every lane
+//                         of a wave runs the same <= smo_iters iterations in lockstep, so there is
+//                         no divergence to manage.  Q_diag and MM sit in LDS ([var][lane],
+//                         conflict-free, lane-private: no barriers); Q_diag is read at a per-lane
+//                         dynamic index.  Leaves {controls, lambda, iter} of each instance in a
+//                         per-instance record in HBM plus a queue key (the bits of float(lambda)).
+//   (mpc_sort.hip)        orders the instances longest-first by that key.
+//   lane_pg_fused_kernel  accelerated projected-gradient phase (mpc.h:336-345).  Iteration counts
+//                         differ 30x between instances, so waves are
+//                         persistent and a lane whose instance has converged pulls the next one
+//                         from an atomic ticket over the sorted queue: no lane waits for the
+//                         slowest instance of its wave.  See the comment on the kernel.
+//   lane_pg_kernel        the same phase, unfused, for callers that want the controller state
+//                         (all controls and dlib's v) back: warm-start chains and tpc_mpc_rollout.
 //
-// Storage at H=20, fp64 (per lane): controls u and the M/df work array w live in VGPRs (2 x 40
-// doubles = 160 of the 256 VGPRs a VALU instruction can address); the linear term MM and the
-// accelerated-gradient memory v live in LDS as [var][lane] columns (2 x 20 KB per wave,
-// conflict-free, touched only by their own lane, so no barrier is ever needed).  4 waves x 40 KB
-// fill the CU's 160 KB LDS exactly: one wave per SIMD, where every instruction of a wave issues
-// in 4 cycles -- the fp64 VALU rate -- so the DP pipe is the bound.
+// Built for one wave per SIMD at fp64: there every instruction costs one ~2.1 ns issue slot
+// (scripts/ubench_dp.hip), so the kernels are shaped by instruction count, not by latency hiding
+// through occupancy.
 #pragma once
 
 #include <type_traits>

@@ -64,6 +64,11 @@ typedef enum tpc_mpc_algo { TPC_MPC_ALGO_AUTO = 0, TPC_MPC_ALGO_WAVE = 1, TPC_MP
                                         start point like dlib does (every NaN comparison is
                                         false, mpc.h:298-311) and this flag is raised           */
 #define TPC_MPC_FLAG_MAX_ITER  0x2u  /* an instance stopped on max_iter, not on eps             */
+#define TPC_MPC_FLAG_BAD_MODEL 0x4u  /* general form: an instance's Q, R or bounds break dlib's
+                                        requires clause (mpc_abstract.h:90-97; min(Q) >= 0,
+                                        min(R) > 0, upper >= lower).  dlib asserts (compiled out in
+                                        the reference build); here the instance is not solved and
+                                        returns its start point at iteration 0                    */
 
 /* Solver knobs.  Defaults (tpc_mpc_default_params) are dlib's and the reference module's:
  *   eps 0.01 (mpc.h:104), max_iter 10000 (mpc.h:103), smo_iters 50 (mpc.h:319),

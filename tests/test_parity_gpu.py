@@ -390,3 +390,31 @@ def test_zero_qdiag_continue_branch(torch_cuda, oracle, algo):
             assert bits_equal(gu0.T, u0), smo
         else:
             assert np.abs(gu0.T - u0).max() <= WAVE_ATOL, smo
+
+
+@pytest.mark.parametrize("algo", ["lane", "wave"])
+def test_general_invalid_models_are_flagged(torch_cuda, oracle, algo):
+    """Per-instance models that break dlib's requires clause (mpc_abstract.h:90-97) are not solved:
+    start point back, iteration 0, TPC_MPC_FLAG_BAD_MODEL; their neighbours are unaffected."""
+    from trajectory_controller_amd import FLAG_BAD_MODEL
+    from trajectory_controller_amd.synth import general_inputs
+    I, H, n = 2, 10, 256
+    g = general_inputs(H, n, I=I, first=99)
+    u0, _, it = oracle.solve_general(I, H, g["A"], g["B"], g["C"], g["Q"], g["R"], g["lo"], g["hi"], g["x0"],
+                                     g["targets"], nthreads=4)
+    bad = {3: ("R", 0, 0.0), 77: ("Q", 1, -1.0), 200: ("hi", 0, -1.0)}   # R = 0, Q < 0, hi < lo
+    for k, (name, c, val) in bad.items():
+        g[name][k, c] = val
+    names = ["A", "B", "C", "Q", "R", "lo", "hi", "x0", "targets"]
+    with _solver(H, algo) as s:
+        gu0, git = s.solve_batch_general(*[_soa(g[k]) for k in names], inputs=I, want_iters=True)
+        flags = s.last_flags
+    assert flags & FLAG_BAD_MODEL
+    good = np.ones(n, dtype=bool)
+    good[list(bad)] = False
+    assert np.all(gu0.T[~good] == 0) and np.all(git[~good] == 0)
+    assert np.array_equal(git[good], it[good])
+    if algo == "lane":
+        assert bits_equal(gu0.T[good], u0[good])
+    else:
+        assert np.abs(gu0.T[good] - u0[good]).max() <= WAVE_ATOL

@@ -16,7 +16,7 @@ OK = 0
 F64, F32 = 0, 1
 HOST, DEVICE = 0, 1
 ALGO_AUTO, ALGO_WAVE, ALGO_LANE = 0, 1, 2
-FLAG_NONFINITE, FLAG_MAX_ITER = 0x1, 0x2
+FLAG_NONFINITE, FLAG_MAX_ITER, FLAG_BAD_MODEL = 0x1, 0x2, 0x4
 
 STATUS_NAMES = {0: "OK", 1: "BAD_ARG", 2: "BAD_WEIGHTS", 3: "BAD_BOUNDS", 4: "BAD_HORIZON",
                 5: "BAD_EPS", 6: "NO_DEVICE", 7: "HIP", 8: "ALLOC"}

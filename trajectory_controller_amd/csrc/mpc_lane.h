@@ -32,10 +32,11 @@ namespace tpc {
 // Per-instance record handed from the CD phase to the PG phase:
 //   rec[0 .. 2H-1] controls (indexed 2*i + j), rec[2H] lambda, rec[2H+1] meta (bit pattern)
 // meta: low 32 bits iteration count; bit 32 = stopped (eps reached); bit 33 = v := u was executed
-// at the last CD iteration (mpc.h:330-334); bit 34 = non-finite inputs.
+// at the last CD iteration (mpc.h:330-334); bit 34 = non-finite inputs; bit 35 = invalid model.
 constexpr uint64_t kMetaStopped = 1ull << 32;
 constexpr uint64_t kMetaVInit = 1ull << 33;
 constexpr uint64_t kMetaNonFinite = 1ull << 34;
+constexpr uint64_t kMetaBadModel = 1ull << 35;   // violates dlib's requires clause: not solved
 
 template <typename T, int H> struct LaneRec {
     // record length in T elements, padded to an even count of 8-byte words
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(64, 1) void lane_cd_kernel(Args g, Knobs kn, T* __r
     Model m;
     m.load(g, k);
     const bool nonfinite = m.nonfinite();
+    const bool badmodel = m.invalid();
 
     T u[2 * H], w[2 * H];
     LaneIO<T, I, H, Args>::init_controls(g, k, u);
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(64, 1) void lane_cd_kernel(Args g, Knobs kn, T* __r
     const T eps = (T)kn.eps;
     const uint32_t cd_iters = kn.smo_iters < kn.max_iter ? kn.smo_iters : kn.max_iter;
     uint32_t iter = 0;
-    bool stopped = Model::kScreen && nonfinite;   // see CompactModel::kScreen
+    bool stopped = (Model::kScreen && nonfinite) || badmodel;   // see CompactModel::kScreen, GeneralModel::invalid
     bool vinit = false;
 #pragma unroll 1
     for (uint32_t it = 0; it < cd_iters; ++it) {
@@ -193,6 +195,7 @@ __global__ __launch_bounds__(64, 1) void lane_cd_kernel(Args g, Knobs kn, T* __r
     if (stopped) meta |= kMetaStopped;
     if (vinit) meta |= kMetaVInit;
     if (nonfinite) meta |= kMetaNonFinite;
+    if (badmodel) meta |= kMetaBadModel;
     store_meta<T>(rec + 2 * H + 1, meta);
     // queue key: instances with the largest lambda need the most projected-gradient iterations
     const bool finished = stopped || iter >= kn.max_iter;
@@ -246,6 +249,7 @@ __global__ __launch_bounds__(64, 1) void lane_pg_kernel(Args g, Knobs kn, const 
                     const uint64_t meta = load_meta<T>(rec + 2 * H + 1);
                     iter = (uint32_t)meta;
                     if (meta & kMetaNonFinite) flags |= 0x1u;
+                    if (meta & kMetaBadModel) flags |= 0x4u;
                     if (meta & kMetaVInit) {
 #pragma unroll
                         for (int q = 0; q < 2 * H; ++q)
@@ -420,6 +424,7 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
                     const uint64_t meta = load_meta<T>(rec + 2 * H + 1);
                     iter = (uint32_t)meta;
                     if (meta & kMetaNonFinite) flags |= 0x1u;
+                    if (meta & kMetaBadModel) flags |= 0x4u;
                     const bool vinit = (meta & kMetaVInit) != 0;   // mpc.h:330-334, else a fresh v = 0
 #pragma unroll
                     for (int q = 0; q < 2 * H; ++q)

@@ -99,6 +99,15 @@ struct GeneralModel {
         targets = (const T*)g.targets + k;
         ld = g.ld;
     }
+    // dlib's requires clause (mpc_abstract.h:90-97; DLIB_ASSERT at mpc.h:92-100, compiled out in the
+    // reference build): min(Q) >= 0, min(R) > 0, upper >= lower.  A per-instance model that breaks
+    // it is not solved: it returns its start point at iteration 0 and raises TPC_MPC_FLAG_BAD_MODEL.
+    TPC_DEV bool invalid() const {
+        bool ok = q0 >= (T)0 && q1 >= (T)0;
+#pragma unroll
+        for (int j = 0; j < I_; ++j) ok = ok && r[j] > (T)0 && hi_[j] >= lo_[j];
+        return !ok;
+    }
     // dlib propagates non-finite values through the same arithmetic this model uses, so nothing
     // is screened; the test only feeds TPC_MPC_FLAG_NONFINITE (bounds may legitimately be +-inf).
     static constexpr bool kScreen = false;
@@ -175,6 +184,7 @@ struct CompactModel {
     // a, c, so such instances are screened to exactly that result.
     static constexpr bool kScreen = true;
     TPC_DEV bool nonfinite() const { return !(tfinite(a) && tfinite(c) && tfinite(ty) && tfinite(tphi)); }
+    TPC_DEV bool invalid() const { return false; }   // the uniform Q, R, bounds are validated on the host
 
     TPC_DEV void first(T& m0, T& m1, const T* u) const {
         m0 = a * u[1];

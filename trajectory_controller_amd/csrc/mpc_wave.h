@@ -131,6 +131,7 @@ __global__ __launch_bounds__(64) void wave_kernel(Args g, Knobs kn) {
     Model m;
     m.load(g, k);   // every lane reads the same instance: broadcast loads
     const bool nonfinite = m.nonfinite();
+    const bool badmodel = m.invalid();   // dlib's requires clause broken: return the start point
 
     // ---- prologue: this lane's Hessian row, Q_diag, linear-term element, lambda
     T row[2 * H];
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(64) void wave_kernel(Args g, Knobs kn) {
 
     uint32_t iter = 0;
     bool capped = true;
-    if (Model::kScreen && nonfinite) { capped = false; } else {
+    if ((Model::kScreen && nonfinite) || badmodel) { capped = false; } else {
 #pragma unroll 1
     for (; iter < kn.max_iter; ++iter) {
         // exchange controls through LDS (single-wave workgroup: the barrier is only a wait)
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(64) void wave_kernel(Args g, Knobs kn) {
     if (g.flags && lane == 0) {
         uint32_t f = 0;
         if (nonfinite) f |= 0x1u;
+        if (badmodel) f |= 0x4u;
         if (capped) f |= 0x2u;
         if (f) atomicOr(g.flags, f);
     }

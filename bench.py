@@ -150,10 +150,8 @@ def main():
         if world > 1:
             dist.barrier()
 
-    # one-time lazy initialisation outside any step: HIP module load, the handle's device scratch for
-    # this batch size, RCCL communicator and all-gather channels (not workload: a zero-iteration
-    # call -- max_iter = 0 returns the start point -- and a one-element-per-rank collective)
-    solver.solve_batch_compact(tv, ty, tp, want_flags=False, max_iter=0)
+    # RCCL communicator and all-gather channels are set up outside any step (a one-element-per-rank
+    # collective, not workload); everything else is warmed by the W warmup steps
     if world > 1:
         prime = torch.zeros(world, dtype=tdt, device=dev)
         dist.all_gather_into_tensor(prime, prime[rank:rank + 1].clone())

@@ -50,13 +50,14 @@ typedef enum tpc_mpc_dtype { TPC_MPC_F64 = 0, TPC_MPC_F32 = 1 } tpc_mpc_dtype;
 typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_memory;
 
 /* Kernel family.
- *   WAVE : one 64-lane wavefront per instance; lane j owns decision variable j, the dense
- *          (I*H)x(I*H) Hessian column block is staged through LDS, reductions by wavefront
- *          shuffles.  Lowest latency; used for small batches and solve_one.
+ *   WAVE : one 64-lane wavefront per instance; lane j owns decision variable j and its row of the
+ *          dense (I*H)x(I*H) Hessian, the controls are exchanged through LDS, reductions by
+ *          wavefront DPP/ballot.  Lowest latency; used for small batches and solve_one.  Needs
+ *          I*H <= 64.  Agrees with the reference to ~1e-14 (same decisions, different summation).
  *   LANE : one lane per instance, dlib's O(H) recurrences unrolled in registers, 64 instances
  *          per wavefront with dynamic refill of finished lanes.  Bit-identical to the reference
  *          arithmetic in fp64; highest throughput on large batches.
- *   AUTO : LANE when the batch fills the chip, WAVE otherwise. */
+ *   AUTO : LANE from 32 768 instances up (half the chip's LANE slots), WAVE below. */
 typedef enum tpc_mpc_algo { TPC_MPC_ALGO_AUTO = 0, TPC_MPC_ALGO_WAVE = 1, TPC_MPC_ALGO_LANE = 2 } tpc_mpc_algo;
 
 /* Non-fatal per-call flags, OR-ed into *flags_out (may be NULL). */

@@ -30,6 +30,24 @@ def test_library_exports_whole_abi():
     assert lib.tpc_mpc_abi_version() == 1
 
 
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 (and as C++) on its own, and a C
+    translation unit that calls every entry point must link against the library."""
+    hdr = os.path.join(ROOT, "include")
+    src = tmp_path / "abi_link.c"
+    calls = "\n".join(f"    use((fn_t){name});" for name in _header_functions())
+    src.write_text('#include "tpc_mpc.h"\ntypedef void (*fn_t)(void);\nstatic void use(fn_t f) { (void)f; }\n'
+                   'int main(void) {\n' + calls + '\n    return tpc_mpc_abi_version() == TPC_MPC_ABI_VERSION ? 0 : 1;\n}\n')
+    from trajectory_controller_amd import capi
+    libdir = os.path.dirname(capi.LIB_PATH)
+    exe = str(tmp_path / "abi_link")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + hdr, str(src), "-o", exe,
+                           "-L" + libdir, "-ltpc_mpc", "-Wl,-rpath," + libdir])
+    subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", "-I" + hdr, "-x", "c++",
+                           os.path.join(hdr, "tpc_mpc.h")])
+    assert subprocess.run([exe]).returncode == 0
+
+
 def test_default_params_match_reference_defaults():
     from trajectory_controller_amd import capi
     p = capi.default_params(4)

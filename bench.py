@@ -119,11 +119,18 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
+    # rehearsal knobs (not used by the driver): run several ranks on one card with gloo collectives
+    backend = os.environ.get("TPC_BENCH_BACKEND", "nccl")
+    if "TPC_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["TPC_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     H, n = a.horizon, a.batch
     # weak scaling: rank r owns instances [r*n, (r+1)*n) of the horizon-H stream

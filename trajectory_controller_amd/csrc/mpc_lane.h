@@ -128,8 +128,14 @@ template <typename T, int I, int H> struct LaneIO<T, I, H, GeneralArgs> {
 
 // ------------------------------------------------------------------------------------------------
 // Phase 1: coordinate descent.  grid = ceil(n/64) blocks of one wave.
+// Waves per SIMD the CD kernel is compiled for: small horizons need few registers and little LDS,
+// and with several waves per SIMD the 32-bit select chains issue at their 2-cycle rate.
+template <typename T, int H> struct CdOcc {
+    static constexpr int value = H * (int)sizeof(T) <= 40 ? 4 : (H * (int)sizeof(T) <= 80 ? 2 : 1);
+};
+
 template <typename T, int I, int H, class Model, class Args>
-__global__ __launch_bounds__(64, 1) void lane_cd_kernel(Args g, Knobs kn, T* __restrict__ recs,
+__global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args g, Knobs kn, T* __restrict__ recs,
                                                          uint32_t* __restrict__ keys) {
     constexpr int RL = LaneRec<T, H>::kLen;
     __shared__ T s_qd[2 * H][kWave];   // Q_diag[i](j) of lane l at s_qd[2*i + j][l]
@@ -355,8 +361,9 @@ template <int N, class F> TPC_DEV void static_for(F&& f) { static_for_impl(f, st
 // fp32 kernel uses no LDS at all and two waves share a SIMD, where 32-bit VALU instructions issue
 // at their 2-cycle rate instead of one per 4-cycle slot.  (With MM and v in LDS, two waves per SIMD
 // gained nothing: eight waves' ds_read2/ds_write kept the CU's one LDS pipe busy 90 % of the time.)
-template <typename T, int H> struct FusedOcc { static constexpr int value = (sizeof(T) == 4 && H <= 20) ? 2 : 1; };
-template <typename T, int H> struct FusedInRegs { static constexpr bool value = sizeof(T) == 4 && H <= 20; };
+// The same holds for fp64 up to H = 10 (4 x 2H doubles = 160 VGPRs).
+template <typename T, int H> struct FusedInRegs { static constexpr bool value = H * (int)sizeof(T) <= 80; };
+template <typename T, int H> struct FusedOcc { static constexpr int value = FusedInRegs<T, H>::value ? 2 : 1; };
 
 template <typename T, int I, int H, class Model, class Args>
 __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::value)) void lane_pg_fused_kernel(Args g, Knobs kn, const T* __restrict__ recs,

@@ -150,3 +150,36 @@ def test_follow_batch_matches_module_and_oracle(tmp_path, oracle):
     # atan2 on the device and in glibc may differ in the last bit, so steering is compared to 1e-9
     assert np.abs(f - of).max() <= 1e-9 and np.abs(rr - orr).max() <= 1e-9
     assert crossing.sum() > 100 and (~crossing).sum() > 100
+
+
+def _build_example(tmp_path):
+    exe = str(tmp_path / "batch_compact")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "batch_compact.c"), "-o", exe, "-L" + LIB, "-ltpc_mpc",
+                           "-Wl,-rpath," + LIB])
+    return exe
+
+
+def test_c_example_builds_and_refuses_without_gpu(tmp_path):
+    import torch
+    exe = _build_example(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by the gpu test")
+    r = subprocess.run([exe, "10", "8"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "tpc_mpc_create" in r.stderr
+
+
+@pytest.mark.gpu
+def test_c_example_matches_oracle(tmp_path, oracle):
+    """A plain-C host, host-memory batch: the printed steering pairs are dlib's."""
+    exe = _build_example(tmp_path)
+    r = subprocess.run([exe, "10", "300"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = [l.split() for l in r.stdout.splitlines() if "->" in l]
+    assert len(rows) == 5
+    val = lambda tok: float(tok.split("=")[1])
+    v, dy, dphi = ([val(row[c]) for row in rows] for c in (1, 2, 3))
+    f, rr, it = oracle.solve_compact(10, v, dy, dphi)
+    for i, row in enumerate(rows):   # 300 instances: AUTO takes the WAVE kernel
+        assert abs(val(row[5]) - f[i]) <= 1e-9 and abs(val(row[6]) - rr[i]) <= 1e-9 and int(val(row[7])) == it[i]
+    assert "flags=0x0" in r.stdout

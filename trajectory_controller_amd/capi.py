@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtpc_mpc.so")
+# TPC_MPC_LIB lets an A/B run load another build of the same ABI (tuning only)
+LIB_PATH = os.environ.get("TPC_MPC_LIB") or os.path.join(_HERE, "lib", "libtpc_mpc.so")
 
 OK = 0
 F64, F32 = 0, 1

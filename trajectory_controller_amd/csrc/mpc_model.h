@@ -272,6 +272,27 @@ TPC_DEV void linear_term(const Model& m, T* w, Emit emit) {
     linear_term_fn<T, I, H>(m, [&](int q, T val) { w[q] = val; }, [&](int q) { return w[q]; }, emit);
 }
 
+// The linear term for the compact model (x0 = 0, C = 0, one target for all steps): every M[i] of
+// mpc.h:258-260 is +0, so Q.*(M[i] - target) is the same pair for all i, and the products with the
+// literal 0/1 entries of A and B drop out of the backward pass (exact for the finite inputs that
+// reach this point; see CompactModel::kScreen).  8 flops per step instead of 34.
+template <typename T, int I, int H, class Emit>
+TPC_DEV void linear_term(const CompactModel<T>& m, T*, Emit emit) {
+    static_assert(I == 2, "compact model has two inputs");
+    const T w0 = ((T)0 - m.ty) * m.q0, w1 = ((T)0 - m.tphi) * m.q1;   // mpc.h:261-262
+    T n0 = w0, n1 = w1;
+#pragma unroll
+    for (int i = H - 1; i >= 0; --i) {
+        if (i < H - 1) {                                              // mpc.h:263-264
+            const T t0 = w0 + n0;
+            const T t1 = w1 + (m.a * n0 + n1);
+            n0 = t0; n1 = t1;
+        }
+        emit(2 * i, m.c * n1);                                        // mpc.h:265-266
+        emit(2 * i + 1, m.a * n0 - m.c * n1);
+    }
+}
+
 // Gradient df = H*u + MM by dlib's forward/backward recurrences (mpc.h:275-283).
 // u(2*i + j) returns controls[i](j), mm(2*i + j) returns MM[i](j); w is indexed [2*i + j] and on
 // return w[2*i + j] = df[i](j).

@@ -352,8 +352,9 @@ template <int N, class F> TPC_DEV void static_for(F&& f) { static_for_impl(f, st
 //   * MM (read once per iteration) and v (read once, written once) live in LDS as [var][lane]
 //     columns (40 KB per wave at H=20 fp64: four waves fill the CU's 160 KB); each step's four
 //     values are fetched ONE STEP AHEAD into a small register ring, so their latency hides under
-//     the previous step's ~55 instructions; __builtin_amdgcn_sched_barrier(0) pins the prefetch at
-//     the top of its step.  u and the forward-pass array w stay in VGPRs.
+//     the previous step's ~55 instructions; one __builtin_amdgcn_sched_barrier(0) per step pins the
+//     prefetch at the top of its step (without it the loads sink to their uses; a second barrier
+//     at the end of the step costs 18 instructions per iteration).  u and the forward-pass array w stay in VGPRs.
 // Used whenever the caller does not ask for the controller state back (controls_inout / v_inout).
 // An AGPR-resident variant (v_accvgpr_read/write instead of LDS) was measured 2.5 % slower: twelve
 // moves per step cost more issue slots than three LDS instructions.
@@ -509,7 +510,6 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
                 constexpr int j = decltype(jc)::value;
                 v_put(2 * i + j, vn[j]);
             });
-            __builtin_amdgcn_sched_barrier(0);
         });
         const T max_df = tmax(tmax(acc[0], acc[1]), tmax(acc[2], acc[3]));
         ++wave_iters;

@@ -364,6 +364,7 @@ template <int N, class F> TPC_DEV void static_for(F&& f) { static_for_impl(f, st
 // gained nothing: eight waves' ds_read2/ds_write kept the CU's one LDS pipe busy 90 % of the time.)
 // The same holds for fp64 up to H = 10 (4 x 2H doubles = 160 VGPRs).
 template <typename T, int H> struct FusedInRegs { static constexpr bool value = H * (int)sizeof(T) <= 80; };
+template <typename T, int H> struct FusedVRegSteps { static constexpr int value = (sizeof(T) == 8 && H == 20) ? 8 : 0; };
 template <typename T, int H> struct FusedOcc { static constexpr int value = FusedInRegs<T, H>::value ? 2 : 1; };
 
 template <typename T, int I, int H, class Model, class Args>
@@ -378,12 +379,16 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
     constexpr bool REGS = FusedInRegs<T, H>::value;
     __shared__ T s_mm[REGS ? 1 : 2 * H][BT];
     __shared__ T s_v[REGS ? 1 : 2 * H][BT];
-    T r_mm[REGS ? 2 * H : 1], r_v[REGS ? 2 * H : 1];   // register-resident copies (fp32)
+    // the first KV horizon steps of v stay in VGPRs even when the rest lives in LDS: the inner loop
+    // has a few dozen registers to spare, and every step kept saves a ds_read2 and a ds_write2
+    // (H = 20 fp64, A/B on one box: KV = 4 / 6 / 8 / 10 / 12 -> +1.7 / +2.0 / +2.1 / +1.5 / -1.0 %)
+    constexpr int KV = REGS ? H : FusedVRegSteps<T, H>::value;
+    T r_mm[REGS ? 2 * H : 1], r_v[2 * KV + 1];   // register-resident copies
     const int lane = threadIdx.x;   // LDS column; ballots below are per wavefront
     auto mm_put = [&](int q, T val) { if constexpr (REGS) r_mm[q] = val; else s_mm[q][lane] = val; };
     auto mm_get = [&](int q) -> T { if constexpr (REGS) return r_mm[q]; else return s_mm[q][lane]; };
-    auto v_put = [&](int q, T val) { if constexpr (REGS) r_v[q] = val; else s_v[q][lane] = val; };
-    auto v_get = [&](int q) -> T { if constexpr (REGS) return r_v[q]; else return s_v[q][lane]; };
+    auto v_put = [&](int q, T val) { if (q < 2 * KV) r_v[q] = val; else s_v[q][lane] = val; };
+    auto v_get = [&](int q) -> T { if (q < 2 * KV) return r_v[q]; else return s_v[q][lane]; };
     const T eps = (T)kn.eps;
 
     Model m;

@@ -367,6 +367,40 @@ def test_phase_boundaries_vs_oracle(torch_cuda, oracle, algo):
         assert bool(flags & FLAG_MAX_ITER) == bool(np.any(oit >= cap)), (smo, cap)
 
 
+@pytest.mark.parametrize("H", [10, 20])
+def test_lane_stop_test_builds_vs_oracle(torch_cuda, oracle, H):
+    """The fused projected-gradient kernel exists in two builds (mpc_lane.h): a select-free stop test
+    for batches every instance of which passes CompactModel::fast_stop_ok, and dlib's compare-and-
+    select form for the rest.  Both must reproduce dlib bit for bit: bounds straddling zero with most
+    variables pinned (fast build), bounds that do not straddle zero, an absurd speed in an otherwise
+    ordinary batch, and an eps beyond the screen (all exact build)."""
+    from trajectory_controller_amd.synth import compact_inputs
+    n = 4096
+    v, dy, dphi = compact_inputs(H, n, first=424242)
+    cases = [
+        dict(lo=(-0.05, -0.02), hi=(0.03, 0.05)),       # fast build, saturating almost everywhere
+        dict(lo=(-0.1, -0.384), hi=(0.384, 0.2)),       # fast build, asymmetric
+        dict(lo=(0.0, 0.0), hi=(0.3, 0.3)),             # start point ON the lower bound: exact build
+        dict(lo=(0.05, -0.3), hi=(0.3, -0.05)),         # start point outside the bounds: exact build
+        dict(lo=(-0.384, -0.384), hi=(0.384, 0.384), eps=2e30),
+    ]
+    for c in cases:
+        eps = c.get("eps", 0.01)
+        of, orr, oit = oracle.solve_compact(H, v, dy, dphi, lo=c["lo"], hi=c["hi"], eps=eps, nthreads=8)
+        with _solver(H, "lane", lower=c["lo"], upper=c["hi"], eps=eps) as s:
+            f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+        assert np.array_equal(it, oit), c
+        assert bits_equal(f, of) and bits_equal(r, orr), c
+    # one absurd instance (|T*v| > 1e60) sends the whole batch through the exact build
+    v2 = v.copy()
+    v2[17] = 3e62
+    of, orr, oit = oracle.solve_compact(H, v2, dy, dphi, nthreads=8)
+    with _solver(H, "lane") as s:
+        f, r, it = s.solve_batch_compact(v2, dy, dphi, want_iters=True)
+    assert np.array_equal(it, oit)
+    assert bits_equal(f, of) and bits_equal(r, orr)
+
+
 @pytest.mark.parametrize("algo", ["lane", "wave"])
 def test_zero_qdiag_continue_branch(torch_cuda, oracle, algo):
     """Q = (2, 0) as in dlib's own test makes Q_diag[H-1] = 0: the `continue` of mpc.h:322 (an

@@ -43,7 +43,7 @@ struct GeneralArgs {
 struct Workspace {
     void* state;        // per-instance records, LaneRec<T,H>::kLen elements each
     uint32_t* ticket;   // 1 word
-    unsigned long long* stats;   // [2]: PG wave-iterations, refill blocks (zeroed per launch)
+    unsigned long long* stats;   // [3]: PG wave-iterations, refill blocks, exact-stop-test flag (zeroed per launch)
     int64_t capacity_bytes;
     // longest-first queue (mpc_sort.hip): keys written by the CD kernel, ordered into order[]
     uint32_t *keys, *order;

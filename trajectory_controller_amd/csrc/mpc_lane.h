@@ -136,7 +136,8 @@ template <typename T, int H> struct CdOcc {
 
 template <typename T, int I, int H, class Model, class Args>
 __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args g, Knobs kn, T* __restrict__ recs,
-                                                         uint32_t* __restrict__ keys) {
+                                                         uint32_t* __restrict__ keys,
+                                                         unsigned long long* __restrict__ stats) {
     constexpr int RL = LaneRec<T, H>::kLen;
     __shared__ T s_qd[2 * H][kWave];   // Q_diag[i](j) of lane l at s_qd[2*i + j][l]
     __shared__ T s_mm[2 * H][kWave];   // MM[i](j)
@@ -152,9 +153,14 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args 
     T u[2 * H], w[2 * H];
     LaneIO<T, I, H, Args>::init_controls(g, k, u);
     const T lambda = ctor_lambda_qdiag<T, I, H>(m, [&](int i, int j, T val) { s_qd[2 * i + j][lane] = val; });
-    linear_term<T, I, H>(m, w, [&](int q, T val) { s_mm[q][lane] = val; });
+    T mm_max = (T)0;
+    linear_term<T, I, H>(m, w, [&](int q, T val) { s_mm[q][lane] = val; mm_max = tmax(mm_max, tabs(val)); });
 
     const T eps = (T)kn.eps;
+    // one instance outside the screen sends the whole batch to the exact-stop-test build of the
+    // fused PG kernel (stats[2], read by both builds at launch; see lane_pg_fused_kernel)
+    if constexpr (Model::kFastStop)
+        if (!m.fast_stop_ok(mm_max, eps)) atomicOr(&stats[2], 1ull);
     const uint32_t cd_iters = kn.smo_iters < kn.max_iter ? kn.smo_iters : kn.max_iter;
     uint32_t iter = 0;
     bool stopped = (Model::kScreen && nonfinite) || badmodel;   // see CompactModel::kScreen, GeneralModel::invalid
@@ -367,12 +373,20 @@ template <typename T, int H> struct FusedInRegs { static constexpr bool value = 
 template <typename T, int H> struct FusedVRegSteps { static constexpr int value = (sizeof(T) == 8 && H == 20) ? 8 : 0; };
 template <typename T, int H> struct FusedOcc { static constexpr int value = FusedInRegs<T, H>::value ? 2 : 1; };
 
-template <typename T, int I, int H, class Model, class Args>
+template <typename T, int I, int H, class Model, class Args, bool FAST>
 __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::value)) void lane_pg_fused_kernel(Args g, Knobs kn, const T* __restrict__ recs,
                                                               const uint32_t* __restrict__ order,
                                                               uint32_t* __restrict__ ticket,
                                                               unsigned long long* __restrict__ stats) {
     constexpr int RL = LaneRec<T, H>::kLen;
+    static_assert(!FAST || Model::kFastStop, "the select-free stop test needs a model with a screen");
+    // Models with a screen get two builds of this kernel, launched back to back; the coordinate-
+    // descent kernel has decided which of them works (stats[2] != 0: some instance failed the
+    // screen, the batch takes the exact build) and the other one returns here.
+    if constexpr (Model::kFastStop) {
+        const bool need_exact = __builtin_nontemporal_load(&stats[2]) != 0ull;
+        if (need_exact == FAST) return;
+    }
     // FusedOcc waves per workgroup, each wave an independent solver using its own 64 columns (no
     // barrier anywhere): one 40 KB workgroup per SIMD pair is what the CU is known to co-schedule.
     constexpr int BT = kWave * FusedOcc<T, H>::value;
@@ -390,6 +404,22 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
     auto v_put = [&](int q, T val) { if (q < 2 * KV) r_v[q] = val; else s_v[q][lane] = val; };
     auto v_get = [&](int q) -> T { if (q < 2 * KV) return r_v[q]; else return s_v[q][lane]; };
     const T eps = (T)kn.eps;
+    // FAST: (u - lo) * 2^600 and (hi - u) * 2^600 as one fma each, exactly zero at the bound and
+    // >= 1e64 off it.  The bounds of a kFastStop model are the same for the whole batch, so the two
+    // addends sit in SGPRs and leave the loop's VGPR budget alone.
+    constexpr T kHuge = (T)(sizeof(T) == 8 ? 0x1p600 : 0x1p60);
+    T nlo_h[2] = {(T)0, (T)0}, hi_h[2] = {(T)0, (T)0};
+    // ... and the factor in VGPRs: a VOP3 instruction reads one SGPR operand at most, and with both
+    // constants scalar the compiler copies the addend into VGPRs in front of every fma
+    T huge = kHuge;
+    asm volatile("" : "+v"(huge));
+    if constexpr (FAST) {
+#pragma unroll
+        for (int j = 0; j < I; ++j) {
+            nlo_h[j] = wave_uniform(-((T)g.lo[j] * kHuge));
+            hi_h[j] = wave_uniform((T)g.hi[j] * kHuge);
+        }
+    }
 
     Model m;
     T u[2 * H], w[2 * H];
@@ -504,9 +534,21 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
                 constexpr int q = 2 * i + j;
                 const T uu = u[q];
                 const T dd = (pm[cur][j] + m.btm(j, n0, n1)) + uu * m.R(j);     // mpc.h:283
-                const T up = (uu <= m.lo(j)) ? (T)0 : dd;                       // mpc.h:298-299
-                const T dn = (uu >= m.hi(j)) ? (T)0 : -dd;
-                acc[(i * I + j) & 3] = tmax(acc[(i * I + j) & 3], tmax(up, dn));
+                if constexpr (FAST) {
+                    // mpc.h:298-299 without compares and selects (5 issue slots instead of 8): a
+                    // variable at its lower bound may only move up (only df < 0 counts), one at its
+                    // upper bound only down.  g_lo / g_hi are 0 at the bound and >= 1e64 off it, so
+                    // |clamp(df, -g_hi, g_lo)| is dlib's masked |df| wherever that is below eps
+                    // (<= 1e30 by the screen) and some value >= eps wherever it is not; df is never
+                    // NaN for a screened instance, and controls never leave [lo, hi] (lo < 0 < hi).
+                    const T g_lo = tfma(uu, huge, nlo_h[j]);
+                    const T g_hi = tfma(uu, -huge, hi_h[j]);
+                    acc[(i * I + j) & 3] = tmax(acc[(i * I + j) & 3], tabs(tmax(tmin(dd, g_lo), -g_hi)));
+                } else {
+                    const T up = (uu <= m.lo(j)) ? (T)0 : dd;                   // mpc.h:298-299
+                    const T dn = (uu >= m.hi(j)) ? (T)0 : -dd;
+                    acc[(i * I + j) & 3] = tmax(acc[(i * I + j) & 3], tmax(up, dn));
+                }
                 vn[j] = clamp3(uu - inv_lambda * dd, m.lo(j), m.hi(j));         // mpc.h:342
                 u[q] = clamp3(vn[j] + beta * (vn[j] - pv[cur][j]), m.lo(j), m.hi(j));   // mpc.h:343
                 asm volatile("" : "+v"(u[q]));   // keep the update in its step (LLVM would sink it)

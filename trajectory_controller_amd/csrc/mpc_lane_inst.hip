@@ -39,12 +39,12 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
     if (a.n <= 0) return hipSuccess;
     T* recs = (T*)ws.state;
     hipError_t e = hipMemsetAsync(ws.ticket, 0, sizeof(uint32_t), s);
-    if (e == hipSuccess) e = hipMemsetAsync(ws.stats, 0, 2 * sizeof(unsigned long long), s);
+    if (e == hipSuccess) e = hipMemsetAsync(ws.stats, 0, 3 * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
     const int cd_grid = (int)((a.n + kWave - 1) / kWave);
     if (ws.ev) (void)hipEventRecord(ws.ev[0], s);
     hipLaunchKernelGGL((lane_cd_kernel<T, I, kH, Model, Args>), dim3(cd_grid), dim3(kWave), 0, s, a, k, recs,
-                       ws.keys);
+                       ws.keys, ws.stats);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     e = order_desc(ws.keys, ws.order, a.n, ws.sort_temp, s);
@@ -57,9 +57,16 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
                            dim3(kWave), 0, s, a, k, (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats);
     } else {
         constexpr int bt = kWave * FusedOcc<T, kH>::value;
-        static const int grid_cap = pg_grid(lane_pg_fused_kernel<T, I, kH, Model, Args>, bt);
         const int64_t need = (a.n + bt - 1) / bt;
-        hipLaunchKernelGGL((lane_pg_fused_kernel<T, I, kH, Model, Args>),
+        if constexpr (Model::kFastStop) {
+            // both builds go out; the one the CD kernel's screen did not pick returns at once
+            static const int fast_cap = pg_grid(lane_pg_fused_kernel<T, I, kH, Model, Args, true>, bt);
+            hipLaunchKernelGGL((lane_pg_fused_kernel<T, I, kH, Model, Args, true>),
+                               dim3((unsigned)(need < fast_cap ? need : fast_cap)), dim3(bt), 0, s, a, k,
+                               (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats);
+        }
+        static const int grid_cap = pg_grid(lane_pg_fused_kernel<T, I, kH, Model, Args, false>, bt);
+        hipLaunchKernelGGL((lane_pg_fused_kernel<T, I, kH, Model, Args, false>),
                            dim3((unsigned)(need < grid_cap ? need : grid_cap)), dim3(bt), 0, s, a, k,
                            (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats);
     }

@@ -37,11 +37,25 @@ template <> TPC_DEV float tabs<float>(float x) { return __builtin_fabsf(x); }
 template <typename T> TPC_DEV T tmax(T a, T b);
 template <> TPC_DEV double tmax<double>(double a, double b) { return __builtin_fmax(a, b); }
 template <> TPC_DEV float tmax<float>(float a, float b) { return __builtin_fmaxf(a, b); }
+template <typename T> TPC_DEV T tmin(T a, T b);
+template <> TPC_DEV double tmin<double>(double a, double b) { return __builtin_fmin(a, b); }
+template <> TPC_DEV float tmin<float>(float a, float b) { return __builtin_fminf(a, b); }
+template <typename T> TPC_DEV T tfma(T a, T b, T c);
+template <> TPC_DEV double tfma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <> TPC_DEV float tfma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 template <typename T> TPC_DEV T tsqrt(T x);
 template <> TPC_DEV double tsqrt<double>(double x) { return __builtin_sqrt(x); }
 template <> TPC_DEV float tsqrt<float>(float x) { return __builtin_sqrtf(x); }
 template <typename T> TPC_DEV bool tfinite(T x) { return tabs(x) <= (T)1.7976931348623157e308 && x == x; }
 template <> TPC_DEV bool tfinite<float>(float x) { return tabs(x) <= 3.4028234663852886e38f && x == x; }
+
+// Tells the compiler a value is the same in every lane (it then lives in SGPRs).
+TPC_DEV double wave_uniform(double x) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+TPC_DEV float wave_uniform(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
 
 // A multiply the optimiser cannot look into (same instruction, same rounding).  Used where a value
 // is deliberately RE-computed instead of kept in a register: common-subexpression elimination would
@@ -68,6 +82,10 @@ struct GeneralModel {
     T x00, x01;
     const T* targets;   // SoA base of this instance: component c at targets[c*ld]
     int64_t ld;
+
+    // an arbitrary A can grow like |A|^H: no cheap overflow screen, so the exact stop test always runs
+    static constexpr bool kFastStop = false;
+    TPC_DEV bool fast_stop_ok(T, T) const { return false; }
 
     TPC_DEV T A(int r_, int c_) const { return r_ == 0 ? (c_ == 0 ? a00 : a01) : (c_ == 0 ? a10 : a11); }
     TPC_DEV T B(int r_, int j) const { return b[r_][j]; }
@@ -185,6 +203,23 @@ struct CompactModel {
     static constexpr bool kScreen = true;
     TPC_DEV bool nonfinite() const { return !(tfinite(a) && tfinite(c) && tfinite(ty) && tfinite(tphi)); }
     TPC_DEV bool invalid() const { return false; }   // the uniform Q, R, bounds are validated on the host
+
+    // Screen for the select-free stop test of lane_pg_fused_kernel, which is equivalent to dlib's
+    // only while (1) no gradient component can be NaN and (2) every control sits inside bounds that
+    // straddle zero by a margin the 2^600 scaling resolves.  With al = max(1,|a|,|c|), U = max|bound|,
+    // q = max Q, the iteration's intermediates obey (see first/fwd/bwd/btm below)
+    //   |M[i]| <= 2 al^2 U H^2,  |n| <= 4 al^3 q U H^4,  |trans(B) n| <= 8 al^4 q U H^4,
+    //   |df| <= max|MM| + 8 al^4 q U H^4 + U max R,
+    // so al <= 1e60, q <= 1e30, U <= 1e10, R <= 1e100, max|MM| <= 1e300 and H <= 40 keep every
+    // value finite (< 1e301).  Anything else (absurd inputs) takes the exact test.
+    static constexpr bool kFastStop = sizeof(T) == 8;
+    TPC_DEV bool fast_stop_ok(T mm_max, T eps) const {
+        auto lower_ok = [](T l) { return l <= (T)-1e-100 && l >= (T)-1e10; };
+        auto upper_ok = [](T h) { return h >= (T)1e-100 && h <= (T)1e10; };
+        return tabs(a) <= (T)1e60 && tabs(c) <= (T)1e60 && mm_max <= (T)1e300 &&
+               tabs(q0) <= (T)1e30 && tabs(q1) <= (T)1e30 && tabs(r0) <= (T)1e100 && tabs(r1) <= (T)1e100 &&
+               lower_ok(l0) && lower_ok(l1) && upper_ok(h0) && upper_ok(h1) && eps <= (T)1e30;
+    }
 
     TPC_DEV void first(T& m0, T& m1, const T* u) const {
         m0 = a * u[1];

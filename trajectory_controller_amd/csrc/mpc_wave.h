@@ -22,10 +22,6 @@
 
 namespace tpc {
 
-template <typename T> TPC_DEV T tfma(T a, T b, T c);
-template <> TPC_DEV double tfma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
-template <> TPC_DEV float tfma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-
 template <int CTRL, int ROW_MASK = 0xf> TPC_DEV double dpp_mov(double old, double x) {
     const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, ROW_MASK, 0xf, false);
     const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, ROW_MASK, 0xf, false);

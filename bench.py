@@ -11,6 +11,15 @@ at N=8 that is config 4's 2 097 152), inputs resident in HBM before the timed re
 batch is embarrassingly parallel, so ranks shard it with no data-path collective during the solve;
 for N>1 the control outputs are all-gathered over RCCL inside the timed region (north_star).
 
+Two batches are kept in flight (`--inflight`, default 2): consecutive steps alternate between two
+library handles on two HIP streams, so the next batch's kernels fill the CUs the previous batch's
+last long-running instances no longer need (a batch ends when its slowest lane does; +7 % at
+H = 20).  Every step still solves one whole batch and the timed region still ends with a device
+synchronisation.  The library's HIP events bracket each kernel on its launch stream: "kernel_ms" is
+their average over the last step of each handle inside the timed region (with two batches in flight
+those durations include time a kernel's workgroups wait for CUs), "kernel_ms_serial" the same with
+one batch in flight, measured right after the timed region.
+
 `value` is measured in fp64, the only dtype that meets the 1e-6 parity target (SURVEY.md section 0
 fact 3); the fp32 rate of the same workload is reported beside it under "fp32" with its error
 histogram against the fp64 result.  `roofline` prices the dominant kernel against HBM as the
@@ -50,6 +59,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-fp32", action="store_true")
+    ap.add_argument("--inflight", type=int, default=2, help="batches kept in flight (handle + stream each)")
     return ap.parse_args()
 
 
@@ -137,25 +147,43 @@ def main():
     v, dy, dphi = compact_inputs(H, n, first=rank * n)
     tdt = torch.float64 if a.dtype == "f64" else torch.float32
     tv, ty, tp = (torch.from_numpy(x).to(dev, dtype=tdt) for x in (v, dy, dphi))
-    front, rear = torch.empty_like(tv), torch.empty_like(tv)
+    slots = max(1, a.inflight)
+    fronts = [torch.empty_like(tv) for _ in range(slots)]
+    rears = [torch.empty_like(tv) for _ in range(slots)]
     iters_t = None
     if world > 1:
-        gathered = torch.empty((world, 2, n), dtype=tdt, device=dev)
-        mine = torch.empty((2, n), dtype=tdt, device=dev)
+        gathered = [torch.empty((world, 2, n), dtype=tdt, device=dev) for _ in range(slots)]
+        mine = [torch.empty((2, n), dtype=tdt, device=dev) for _ in range(slots)]
 
-    solver = MpcSolver(horizon=H, device=local_rank, dtype=a.dtype, algo=a.algo)
-    solver.set_profiling(True)
+    solvers = [MpcSolver(horizon=H, device=local_rank, dtype=a.dtype, algo=a.algo) for _ in range(slots)]
+    for sv in solvers:
+        sv.set_profiling(True)
+        sv.reserve(n)   # scratch is allocated here, not by the first solve of each handle
+    solver = solvers[0]
+    streams = [torch.cuda.Stream(dev) for _ in range(slots)]
 
-    def step():
-        if world > 1:
-            solver.solve_batch_compact(tv, ty, tp, out=(mine[0], mine[1]), want_flags=False)
-            dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1))   # RCCL over xGMI
-        else:
-            solver.solve_batch_compact(tv, ty, tp, out=(front, rear), want_flags=False)
+    def step(k):
+        i = k % slots
+        with torch.cuda.stream(streams[i]):
+            if world > 1:
+                solvers[i].solve_batch_compact(tv, ty, tp, out=(mine[i][0], mine[i][1]), want_flags=False)
+                dist.all_gather_into_tensor(gathered[i].view(-1), mine[i].view(-1))   # RCCL over xGMI
+            else:
+                solvers[i].solve_batch_compact(tv, ty, tp, out=(fronts[i], rears[i]), want_flags=False)
 
     def barrier():
         if world > 1:
             dist.barrier()
+
+    def kernel_times(used):
+        """Mean (first, second) kernel duration in ms over the last solve of each used handle."""
+        x1 = x2 = 0.0
+        algo = 0
+        for i in range(used):
+            t1, t2, algo = solvers[i].last_kernel_times()
+            x1 += t1 / used
+            x2 += t2 / used
+        return x1, x2, algo
 
     # RCCL communicator and all-gather channels are set up outside any step (a one-element-per-rank
     # collective, not workload); everything else is warmed by the W warmup steps
@@ -164,33 +192,36 @@ def main():
         dist.all_gather_into_tensor(prime, prime[rank:rank + 1].clone())
     torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
+    for k in range(a.warmup):
+        step(k)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    k1 = k2 = 0.0
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-        # HIP events the library recorded on the launch stream around each kernel; reading them
-        # waits for this step's kernels, which the step would do at the next sync anyway
-        x1, x2, algo_ran = solver.last_kernel_times()
-        k1 += x1
-        k2 += x2
+    for k in range(a.steps):
+        step(k)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # HIP events the library recorded on the launch streams inside the timed region
+    k1, k2, algo_ran = kernel_times(min(slots, a.steps))
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        front, rear = mine[0], mine[1]
+        front, rear = mine[0][0], mine[0][1]
+    else:
+        front, rear = fronts[0], rears[0]
 
     if rank == 0:
         # iteration statistics of this rank's shard (for the algorithmic-flop figure)
-        _, _, iters_t = solver.solve_batch_compact(tv, ty, tp, want_iters=True)
+        s1 = s2 = 0.0
+        for _ in range(3):   # one batch in flight: kernel durations without any overlap
+            _, _, iters_t = solver.solve_batch_compact(tv, ty, tp, want_iters=True)
+            y1, y2, _ = solver.last_kernel_times()
+            s1 += y1 / 3
+            s2 += y2 / 3
         torch.cuda.synchronize()
         mean_iters = float(iters_t.double().mean().item())
         lane_stats = None
@@ -203,13 +234,14 @@ def main():
         total = world * n * a.steps
         value = total / elapsed
         # dominant kernel = the longer of the two launches of a step
-        dom_ms = max(k1, k2) / a.steps
+        dom_ms = max(k1, k2)
         dom_name = {1: "wave_kernel", 2: "lane_pg_fused_kernel" if k2 >= k1 else "lane_cd_kernel"}[algo_ran]
         alg_bytes = 5 * esz * n                       # 3 in + 2 out scalars per solve
         # the PG kernel also reads what the CD kernel left per instance (not algorithmic traffic)
         hbm_gbs = alg_bytes / (dom_ms * 1e-3) / 1e9
         alg_flops = (46 * H - 16) * mean_iters * n
-        tfl = alg_flops / ((k1 + k2) / a.steps * 1e-3) / 1e12
+        tfl = alg_flops / (elapsed / a.steps) / 1e12                 # what a whole step delivers
+        tfl_serial = alg_flops / ((s1 + s2) * 1e-3) / 1e12             # the two kernels on their own
         peak_tf = FP64_VECTOR_PEAK_TF if a.dtype == "f64" else FP32_VECTOR_PEAK_TF
         traffic = None
         tj = os.path.join(ROOT, "profiles", "traffic.json")
@@ -226,14 +258,16 @@ def main():
             "config": {"workload": f"batch {n} trajectories per GPU, N={H}, 2 inputs, compact "
                                    f"(mpcControllerTobi) form, cold start, eps 0.01, max_iter 10000",
                        "global_batch": world * n, "horizon": H, "algo": {1: "wave", 2: "lane"}[algo_ran],
-                       "parallelism": f"batch-sharded x{world}"},
-            "kernel_ms": {"first": k1 / a.steps, "second": k2 / a.steps, "dominant": dom_name},
+                       "parallelism": f"batch-sharded x{world}", "batches_in_flight": slots},
+            "kernel_ms": {"first": k1, "second": k2, "dominant": dom_name},
+            "kernel_ms_serial": {"first": s1, "second": s2},
             "mean_iterations": mean_iters, "lane_stats": lane_stats,
             "roofline": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "note": "40 B/solve algorithmic: this path is issue-bound, not HBM-bound; see alu"},
             "alu": {"bound": "fp64 vector issue" if a.dtype == "f64" else "fp32 vector issue",
                     "achieved": tfl, "peak": peak_tf, "unit": "TFLOP/s", "frac": tfl / peak_tf,
+                    "serial_kernels_frac": tfl_serial / peak_tf,
                     "flops_per_solve": (46 * H - 16) * mean_iters},
         }
         if not a.no_cpu:
@@ -259,7 +293,8 @@ def main():
                            "max_abs_du_vs_fp64": float(err.max().item())}
             s32.close()
         print(json.dumps(out), flush=True)
-    solver.close()
+    for sv in solvers:
+        sv.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

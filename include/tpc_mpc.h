@@ -197,6 +197,30 @@ int tpc_mpc_follow_batch(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mp
                          double* steering_front, double* steering_rear, float* target_speed,
                          float* target_distance, int32_t* iters, uint32_t* flags_out, void* stream);
 
+/* ---- memory ------------------------------------------------------------------------------------ */
+
+/* No reference counterpart.  A handle grows its device scratch on demand, and growing frees and
+ * allocates device memory, which synchronises the whole device; a host that keeps several batches
+ * in flight (one handle and one stream per batch) calls this once per handle up front for the
+ * largest compact batch it will solve (mem: where the batch arrays will live), so that no solve
+ * allocates. */
+int tpc_mpc_reserve(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n, int mem);
+
+/* ---- scheduling hint --------------------------------------------------------------------------- */
+
+/* No reference counterpart (one controller solves one problem per cycle there).  Instances of a
+ * batch need between a few and several thousand iterations (mpc.h:271, :310), and the batch
+ * finishes when its slowest lane does, so the LANE kernels start the instances expected to run
+ * longest first.  Their own estimate is dlib's lambda (mpc.h:116-123).  A caller that solves
+ * nearly the same batch every control cycle knows better: hint[k] = the iteration count instance k
+ * needed last cycle (the `iters` output).  The hint applies to the NEXT tpc_mpc_solve_batch_compact
+ * / tpc_mpc_solve_batch_general call on this handle if that call has the same n, and is forgotten
+ * afterwards; DEVICE hints are read by that call and must stay valid until it has run; hint = NULL
+ * clears.  It only decides which lane solves which instance when: outputs, iteration counts and
+ * flags are bit-for-bit the same with any hint.  tpc_mpc_follow_batch keeps this history by itself
+ * (slot k of one cycle is the same controller as slot k of the next). */
+int tpc_mpc_set_work_hint(tpc_mpc_handle h, const int32_t* hint, int64_t n, int mem);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 
 /* No reference counterpart (the reference times nothing on this branch; its only timers are

@@ -367,6 +367,38 @@ def test_phase_boundaries_vs_oracle(torch_cuda, oracle, algo):
         assert bool(flags & FLAG_MAX_ITER) == bool(np.any(oit >= cap)), (smo, cap)
 
 
+def test_work_hint_changes_order_not_results(torch_cuda):
+    """tpc_mpc_set_work_hint: the previous cycle's iteration counts as queue order.  Outputs and
+    iteration counts must be bit-identical with no hint, a perfect hint, a reversed (shortest-first)
+    hint and a host-memory hint; the perfect hint must need fewer wave-iterations than lambda."""
+    from trajectory_controller_amd.synth import compact_inputs
+    torch = torch_cuda
+    H, n = 20, 131072
+    v, dy, dphi = _dev(torch, *compact_inputs(H, n, first=99))
+    with _solver(H, "lane") as s:
+        f0, r0, it0 = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+        w0, _ = s.last_lane_stats()
+        s.set_work_hint(it0)
+        f1, r1, it1 = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+        w1, _ = s.last_lane_stats()
+        f2, r2, it2 = s.solve_batch_compact(v, dy, dphi, want_iters=True)   # hint was one-shot
+        w2, _ = s.last_lane_stats()
+        s.set_work_hint((it0.max() + 1 - it0).contiguous())                  # shortest first: worst case
+        f3, r3, it3 = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+        w3, _ = s.last_lane_stats()
+        s.set_work_hint(it0.cpu().numpy())                                   # host copy
+        f4, r4, it4 = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+        w4, _ = s.last_lane_stats()
+        s.set_work_hint(it0[: n // 2].contiguous())                          # wrong size: ignored
+        f5, r5, it5 = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+    for f, r, it in ((f1, r1, it1), (f2, r2, it2), (f3, r3, it3), (f4, r4, it4), (f5, r5, it5)):
+        assert torch.equal(it, it0)
+        assert bits_equal(f.cpu().numpy(), f0.cpu().numpy()) and bits_equal(r.cpu().numpy(), r0.cpu().numpy())
+    print(f"wave-iterations: lambda order {w0}, perfect hint {w1}, no hint again {w2}, reversed hint {w3}, host hint {w4}")
+    assert w1 < 0.97 * w0 and w4 < 0.97 * w0
+    assert abs(w2 - w0) < 0.02 * w0
+
+
 @pytest.mark.parametrize("H", [10, 20])
 def test_lane_stop_test_builds_vs_oracle(torch_cuda, oracle, H):
     """The fused projected-gradient kernel exists in two builds (mpc_lane.h): a select-free stop test

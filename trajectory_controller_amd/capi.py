@@ -27,7 +27,7 @@ EXPORTS = ("tpc_mpc_default_params", "tpc_mpc_create", "tpc_mpc_destroy", "tpc_m
            "tpc_mpc_supported_horizons", "tpc_mpc_abi_version", "tpc_mpc_solve_one",
            "tpc_mpc_solve_batch_compact", "tpc_mpc_solve_batch_general", "tpc_mpc_rollout",
            "tpc_mpc_set_profiling", "tpc_mpc_last_kernel_times", "tpc_mpc_last_lane_stats",
-           "tpc_mpc_follow_batch")
+           "tpc_mpc_follow_batch", "tpc_mpc_set_work_hint", "tpc_mpc_reserve")
 
 
 class Params(C.Structure):
@@ -99,6 +99,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.tpc_mpc_follow_batch.argtypes = [vp, C.POINTER(Params), C.POINTER(Trajectories), vp, vp, C.c_int32,
                                          vp, vp, vp, vp, vp, u32p, vp]
     lib.tpc_mpc_last_lane_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.tpc_mpc_set_work_hint.argtypes = [vp, vp, C.c_int64, C.c_int]
+    lib.tpc_mpc_reserve.argtypes = [vp, C.POINTER(Params), C.c_int64, C.c_int]
     for name in EXPORTS:
         getattr(lib, name)   # raises AttributeError if the library lacks a declared entry point
     if path == LIB_PATH:

@@ -23,6 +23,7 @@ struct CompactArgs {
     void *front, *rear;            // [n]
     int32_t* iters;                // [n] or null
     uint32_t* flags;               // device word, OR-ed with TPC_MPC_FLAG_*, or null
+    const int32_t* work_hint;      // [n] or null: caller's iteration-count estimate (LANE queue order only)
     double step, wheelbase;        // T, l
     double q[2], r[2], lo[2], hi[2];
 };
@@ -35,6 +36,7 @@ struct GeneralArgs {
     void* u0;
     int32_t* iters;
     uint32_t* flags;
+    const int32_t* work_hint;      // as in CompactArgs
     int shift_controls;            // 1: apply operator()'s warm-start shift (mpc.h:231-232)
 };
 

@@ -81,6 +81,16 @@ struct tpc_mpc_context {
     // travel through it, so a single solve costs one kernel launch and one sync, no memcpy calls
     void* pin_host = nullptr;
     void* pin_dev = nullptr;
+    // queue-order hint for the next batch solve (tpc_mpc_set_work_hint): the caller's device array,
+    // or our device copy of a host array
+    const int32_t* hint = nullptr;
+    int64_t hint_n = 0;
+    void* hint_own = nullptr;
+    int64_t hint_own_bytes = 0;
+    // follow_batch keeps the iteration counts of its previous cycle as the hint for the next one
+    void* hist = nullptr;
+    int64_t hist_bytes = 0;
+    int64_t hist_n = 0;            // 0: no history yet
     // optional kernel timing (tpc_mpc_set_profiling)
     bool profiling = false;
     bool ev_valid = false;
@@ -153,6 +163,14 @@ Knobs knobs_of(const tpc_mpc_params* p) {
     k.max_iter = (uint32_t)p->max_iter;
     k.smo_iters = (uint32_t)p->smo_iters;
     return k;
+}
+
+// One-shot: the hint set for this handle applies to the next batch solve of the same size only.
+const int32_t* take_hint(tpc_mpc_context* h, int64_t n) {
+    const int32_t* p = (h->hint && h->hint_n == n) ? h->hint : nullptr;
+    h->hint = nullptr;
+    h->hint_n = 0;
+    return p;
 }
 
 // LANE needs enough instances to give every SIMD a full wavefront; below that WAVE's
@@ -310,6 +328,8 @@ int tpc_mpc_destroy(tpc_mpc_handle h) {
     if (h->ws_words) (void)hipFree(h->ws_words);
     if (h->stage) (void)hipFree(h->stage);
     if (h->roll) (void)hipFree(h->roll);
+    if (h->hint_own) (void)hipFree(h->hint_own);
+    if (h->hist) (void)hipFree(h->hist);
     if (h->pin_host) (void)hipHostFree(h->pin_host);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     delete h;
@@ -358,6 +378,7 @@ int tpc_mpc_solve_batch_compact(tpc_mpc_handle h, const tpc_mpc_params* p, int64
         a.iters = iters ? (int32_t*)(b + 5 * col) : nullptr;
     }
     a.flags = h->ws_words + 1;
+    a.work_hint = take_hint(h, n);
     a.step = p->step_size; a.wheelbase = p->wheelbase;
     a.q[0] = p->weight_y; a.q[1] = p->weight_phi;
     a.r[0] = p->weight_steering_front; a.r[1] = p->weight_steering_rear;
@@ -472,6 +493,7 @@ int tpc_mpc_solve_batch_general(tpc_mpc_handle h, const tpc_mpc_params* p,
         if (io->iters) { back.push_back({io->iters, a.iters}); back_bytes.push_back(n * 4); }
     }
     a.flags = h->ws_words + 1;
+    a.work_hint = take_hint(h, n);
 
     Workspace ws;
     rc = prepare_workspace(h, algo, H, p->dtype, n, &ws);
@@ -628,12 +650,65 @@ int tpc_mpc_follow_batch(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mp
     fa.target_speed = target_speed; fa.target_distance = target_distance;
     hipError_t e = launch_traj_point(fa, s);
     if (e != hipSuccess) return hip_fail(h, e, "traj_point launch");
+    // Controllers keep their slot from cycle to cycle and their problem changes little, so the
+    // iteration counts of the previous cycle order this cycle's queue (unless the caller set a hint).
+    rc = ensure(h, &h->hist, &h->hist_bytes, n * 4);
+    if (rc) { h->hist_n = 0; return rc; }
+    if (!h->hint && h->hist_n == n) { h->hint = (const int32_t*)h->hist; h->hint_n = n; }
+    int32_t* it_dev = iters ? iters : (int32_t*)h->hist;
+    h->hist_n = 0;
     rc = tpc_mpc_solve_batch_compact(h, p, n, fa.v_out, fa.ysoll_out, fa.phisoll_out, steering_front,
-                                     steering_rear, iters, nullptr, TPC_MPC_DEVICE, stream);
+                                     steering_rear, it_dev, nullptr, TPC_MPC_DEVICE, stream);
     if (rc) return rc;
+    if (iters) HIP_TRY(h, hipMemcpyAsync(h->hist, iters, n * 4, hipMemcpyDeviceToDevice, s));
+    h->hist_n = n;
     e = launch_follow_post(n, target_speed, steering_front, steering_rear, s);
     if (e != hipSuccess) return hip_fail(h, e, "follow_post launch");
     return finish_flags(h, flags_out, s);
+}
+
+int tpc_mpc_reserve(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n, int mem) {
+    int rc = check_common(h, p);
+    if (rc) return rc;
+    if (n < 0 || n > 0x7fffffffll) return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= n < 2^31");
+    if (mem != TPC_MPC_HOST && mem != TPC_MPC_DEVICE) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad memory kind");
+    if (n == 0) return TPC_MPC_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    // the larger of the two kernel families' needs, so that either choice of AUTO is covered
+    const bool ev_valid = h->ev_valid;
+    const int last_algo = h->last_algo;
+    Workspace ws;
+    rc = prepare_workspace(h, TPC_MPC_ALGO_LANE, p->horizon, p->dtype, n, &ws);
+    h->ev_valid = ev_valid;
+    h->last_algo = last_algo;
+    if (rc) return rc;
+    if (mem == TPC_MPC_HOST) {
+        const int64_t col = (int64_t)((n * esize(p->dtype) + 255) / 256 * 256);
+        const int64_t icol = (int64_t)((n * 4 + 255) / 256 * 256);
+        rc = ensure(h, &h->stage, &h->stage_bytes, 5 * col + icol);
+        if (rc) return rc;
+    }
+    return TPC_MPC_OK;
+}
+
+int tpc_mpc_set_work_hint(tpc_mpc_handle h, const int32_t* hint, int64_t n, int mem) {
+    if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+    h->hint = nullptr;
+    h->hint_n = 0;
+    if (!hint || n == 0) return TPC_MPC_OK;   // cleared
+    if (n < 0 || n > 0x7fffffffll) return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= n < 2^31");
+    if (mem != TPC_MPC_HOST && mem != TPC_MPC_DEVICE) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad memory kind");
+    if (mem == TPC_MPC_HOST) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        int rc = ensure(h, &h->hint_own, &h->hint_own_bytes, n * 4);
+        if (rc) return rc;
+        HIP_TRY(h, hipMemcpy(h->hint_own, hint, (size_t)n * 4, hipMemcpyHostToDevice));
+        h->hint = (const int32_t*)h->hint_own;
+    } else {
+        h->hint = hint;
+    }
+    h->hint_n = n;
+    return TPC_MPC_OK;
 }
 
 int tpc_mpc_set_profiling(tpc_mpc_handle h, int enable) {

@@ -104,6 +104,31 @@ class MpcSolver:
     solve_one = mpc_controller_tobi
 
     # -- batches ----------------------------------------------------------------------------------
+    def reserve(self, n: int, host: bool = False, **over):
+        """Allocate the device scratch for compact batches of up to n instances now
+        (tpc_mpc_reserve), so that no later solve allocates -- needed when several batches are kept
+        in flight on different streams, because a device allocation synchronises all of them."""
+        p = self._params(**over)
+        self._check(self._lib.tpc_mpc_reserve(self._h, C.byref(p), int(n), capi.HOST if host else capi.DEVICE))
+
+    def set_work_hint(self, hint):
+        """Queue-order hint for the next batch solve of the same size (tpc_mpc_set_work_hint):
+        per-instance iteration-count estimates, typically the `iters` of the previous cycle.
+        int32 numpy array (copied) or CUDA tensor (read by the next solve; keep it alive until
+        then).  None clears.  Never changes a result, only the order lanes pick instances up."""
+        if hint is None:
+            self._check(self._lib.tpc_mpc_set_work_hint(self._h, None, 0, capi.HOST))
+            self._hint_ref = None
+        elif _is_torch(hint):
+            import torch
+            if not (hint.is_cuda and hint.dtype == torch.int32 and hint.is_contiguous()):
+                raise ValueError("a device hint must be a contiguous int32 CUDA tensor")
+            self._hint_ref = hint
+            self._check(self._lib.tpc_mpc_set_work_hint(self._h, hint.data_ptr(), hint.numel(), capi.DEVICE))
+        else:
+            h = np.ascontiguousarray(hint, dtype=np.int32)
+            self._check(self._lib.tpc_mpc_set_work_hint(self._h, h.ctypes.data, h.shape[0], capi.HOST))
+
     def solve_batch_compact(self, v, delta_y, delta_phi, want_iters: bool = False,
                             want_flags: bool = True, out=None, **over):
         """n independent mpcControllerTobi calls.  Returns (front, rear[, iters])."""

@@ -8,8 +8,15 @@ tag, cmd = sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else ""
 out = "gpurun_out"
 
 def short(name):
-    name = name.split("(")[0]
-    return name.split("<")[0].replace("void ", "").strip()
+    """Kernel name without arguments and template lists; the two builds of the fused PG kernel
+    (select-free / exact stop test, of which one returns at once) stay apart."""
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    head = name.split("(")[0].strip()
+    base = head.split("<")[0]
+    if "lane_pg_fused_kernel" in base:
+        args = head[len(base):]
+        base += "<fast>" if args.rstrip(">").rstrip().endswith("true") else "<exact>"
+    return base
 
 # kernel trace
 rows = collections.defaultdict(list)

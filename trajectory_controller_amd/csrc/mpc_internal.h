@@ -48,7 +48,7 @@ struct Workspace {
     unsigned long long* stats;   // [3]: PG wave-iterations, refill blocks, exact-stop-test flag (zeroed per launch)
     int64_t capacity_bytes;
     // longest-first queue (mpc_sort.hip): keys written by the CD kernel, ordered into order[]
-    uint32_t *keys, *order;
+    uint32_t *keys, *rank, *order;
     void* sort_temp;
     size_t sort_temp_bytes;
     // optional profiling: events recorded on the launch stream around each kernel
@@ -58,7 +58,9 @@ struct Workspace {
 
 // mpc_sort.hip
 size_t sort_temp_bytes(int64_t n);
-hipError_t order_desc(const uint32_t* keys, uint32_t* order, int64_t n, void* temp, hipStream_t s);
+hipError_t order_begin(void* temp, hipStream_t s);   // zero the bins the key producer counts into
+hipError_t order_finish(const uint32_t* keys, const uint32_t* rank, uint32_t* order, int64_t n, void* temp,
+                        hipStream_t s);
 
 
 }  // namespace tpc

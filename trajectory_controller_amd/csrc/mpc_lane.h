@@ -137,6 +137,8 @@ template <typename T, int H> struct CdOcc {
 template <typename T, int I, int H, class Model, class Args>
 __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args g, Knobs kn, T* __restrict__ recs,
                                                          uint32_t* __restrict__ keys,
+                                                         uint32_t* __restrict__ key_rank,
+                                                         uint32_t* __restrict__ key_hist,
                                                          unsigned long long* __restrict__ stats) {
     constexpr int RL = LaneRec<T, H>::kLen;
     __shared__ T s_qd[2 * H][kWave];   // Q_diag[i](j) of lane l at s_qd[2*i + j][l]
@@ -215,7 +217,9 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args 
     // work_hint and gets a queue in that order instead.  The key never influences a result.
     const bool finished = stopped || iter >= kn.max_iter;
     const float lf = g.work_hint ? (float)(g.work_hint[k] > 0 ? g.work_hint[k] : 1) : (float)lambda;
-    keys[k] = (finished || !(lf > 0.0f)) ? 0u : __float_as_uint(lf);
+    const uint32_t key = (finished || !(lf > 0.0f)) ? 0u : __float_as_uint(lf);
+    keys[k] = key;
+    key_rank[k] = atomicAdd(&key_hist[key >> 16], 1u);   // counting sort: histogram + rank in bin (mpc_sort.hip)
 }
 
 // ------------------------------------------------------------------------------------------------

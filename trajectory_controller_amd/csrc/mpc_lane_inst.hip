@@ -40,14 +40,15 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
     T* recs = (T*)ws.state;
     hipError_t e = hipMemsetAsync(ws.ticket, 0, sizeof(uint32_t), s);
     if (e == hipSuccess) e = hipMemsetAsync(ws.stats, 0, 3 * sizeof(unsigned long long), s);
+    if (e == hipSuccess) e = order_begin(ws.sort_temp, s);
     if (e != hipSuccess) return e;
     const int cd_grid = (int)((a.n + kWave - 1) / kWave);
     if (ws.ev) (void)hipEventRecord(ws.ev[0], s);
     hipLaunchKernelGGL((lane_cd_kernel<T, I, kH, Model, Args>), dim3(cd_grid), dim3(kWave), 0, s, a, k, recs,
-                       ws.keys, ws.stats);
+                       ws.keys, ws.rank, (uint32_t*)ws.sort_temp, ws.stats);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    e = order_desc(ws.keys, ws.order, a.n, ws.sort_temp, s);
+    e = order_finish(ws.keys, ws.rank, ws.order, a.n, ws.sort_temp, s);
     if (e != hipSuccess) return e;
     if (ws.ev) (void)hipEventRecord(ws.ev[1], s);
     if (wants_state(a)) {

@@ -8,7 +8,7 @@
 // descending key order, which is the LPT rule for the makespan of its persistent lanes.
 //
 // A counting sort on the top 16 key bits (sign, exponent, 7 mantissa bits: 0.8 % resolution):
-// histogram -> exclusive scan from the largest bin down -> scatter.  Positions inside a bin come
+// histogram (by the key producer) -> exclusive scan from the largest bin down -> scatter.  Positions inside a bin come
 // from an atomic and are therefore not reproducible; they only decide which lane solves which
 // instance, never a result.  Integer/HBM-bound, three tiny launches (~10 us at n = 262144).
 #include "mpc_internal.h"
@@ -18,11 +18,6 @@ namespace tpc {
 namespace {
 
 constexpr int kBins = 1 << 16;
-
-__global__ void hist_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ hist, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        atomicAdd(&hist[keys[i] >> 16], 1u);
-}
 
 // One block of 1024 threads; thread t owns bins [64t, 64t+64) counted from the TOP (descending).
 __global__ __launch_bounds__(1024) void scan_kernel(uint32_t* __restrict__ hist) {
@@ -48,27 +43,35 @@ __global__ __launch_bounds__(1024) void scan_kernel(uint32_t* __restrict__ hist)
     }
 }
 
-__global__ void scatter_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ cursor,
-                               uint32_t* __restrict__ order, int64_t n) {
+// rank[i] = position of instance i inside its bin (handed out by the key producer together with
+// the histogram count), so the scatter needs no atomics: one coalesced read, one 4-byte write.
+__global__ void scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ rank,
+                               const uint32_t* __restrict__ base, uint32_t* __restrict__ order, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        order[atomicAdd(&cursor[keys[i] >> 16], 1u)] = (uint32_t)i;
+        order[base[keys[i] >> 16] + rank[i]] = (uint32_t)i;
 }
 
 }  // namespace
 
 size_t sort_temp_bytes(int64_t) { return (size_t)kBins * sizeof(uint32_t); }
 
-// keys[n] -> order[n]: instance indices by descending key.  temp: kBins words.
-hipError_t order_desc(const uint32_t* keys, uint32_t* order, int64_t n, void* temp, hipStream_t s) {
+// The histogram of (key >> 16) is built by the kernel that produces the keys: one atomic per
+// instance at the end of the coordinate-descent kernel, whose return value is the instance's rank
+// inside its bin.  Spread over that kernel's run time the atomics cost nothing, whereas two separate
+// passes of 262 144 atomics piling up on about a thousand hot bins took 64 us + 66 us.
+hipError_t order_begin(void* temp, hipStream_t s) {
+    return hipMemsetAsync(temp, 0, (size_t)kBins * sizeof(uint32_t), s);
+}
+
+// keys[n], rank[n] + histogram in temp -> order[n]: instance indices by descending key.
+hipError_t order_finish(const uint32_t* keys, const uint32_t* rank, uint32_t* order, int64_t n, void* temp,
+                        hipStream_t s) {
     uint32_t* hist = (uint32_t*)temp;
-    hipError_t e = hipMemsetAsync(hist, 0, (size_t)kBins * sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
     const int block = 256;
     int64_t g = (n + block - 1) / block;
     const unsigned grid = (unsigned)(g < 2048 ? g : 2048);
-    hipLaunchKernelGGL(hist_kernel, dim3(grid), dim3(block), 0, s, keys, hist, n);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, hist);
-    hipLaunchKernelGGL(scatter_kernel, dim3(grid), dim3(block), 0, s, keys, hist, order, n);
+    hipLaunchKernelGGL(scatter_kernel, dim3(grid), dim3(block), 0, s, keys, rank, (const uint32_t*)hist, order, n);
     return hipGetLastError();
 }
 

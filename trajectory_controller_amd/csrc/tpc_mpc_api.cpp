@@ -224,22 +224,23 @@ int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n,
     ws->ev = h->profiling ? h->ev : nullptr;
     h->ev_valid = h->profiling;
     h->last_algo = algo;
-    ws->keys = ws->order = nullptr;
+    ws->keys = ws->rank = ws->order = nullptr;
     ws->sort_temp = nullptr;
     ws->sort_temp_bytes = 0;
     if (algo == TPC_MPC_ALGO_LANE) {
-        // records | keys | order | counting-sort bins
+        // records | keys | rank | order | counting-sort bins
         auto pad = [](int64_t b) { return (b + 255) / 256 * 256; };
         const int64_t rec_b = pad(lane_rec_len(H, dtype) * (int64_t)esize(dtype) * n);
         const int64_t col_b = pad(n * 4);
         const size_t tmp_b = sort_temp_bytes(n);
-        int rc = ensure(h, &h->ws_state, &h->ws_bytes, rec_b + 2 * col_b + pad((int64_t)tmp_b));
+        int rc = ensure(h, &h->ws_state, &h->ws_bytes, rec_b + 3 * col_b + pad((int64_t)tmp_b));
         if (rc) return rc;
         char* b = (char*)h->ws_state;
         ws->state = b;
         ws->keys = (uint32_t*)(b + rec_b);
-        ws->order = (uint32_t*)(b + rec_b + col_b);
-        ws->sort_temp = b + rec_b + 2 * col_b;
+        ws->rank = (uint32_t*)(b + rec_b + col_b);
+        ws->order = (uint32_t*)(b + rec_b + 2 * col_b);
+        ws->sort_temp = b + rec_b + 3 * col_b;
         ws->sort_temp_bytes = tmp_b;
         ws->capacity_bytes = h->ws_bytes;
     }

@@ -10,7 +10,7 @@
 // A counting sort on the top 16 key bits (sign, exponent, 7 mantissa bits: 0.8 % resolution):
 // histogram (by the key producer) -> exclusive scan from the largest bin down -> scatter.  Positions inside a bin come
 // from an atomic and are therefore not reproducible; they only decide which lane solves which
-// instance, never a result.  Integer/HBM-bound, three tiny launches (~10 us at n = 262144).
+// instance, never a result.  Integer/HBM-bound, three tiny launches (~15 us at n = 262144).
 #include "mpc_internal.h"
 
 namespace tpc {
@@ -19,27 +19,50 @@ namespace {
 
 constexpr int kBins = 1 << 16;
 
-// One block of 1024 threads; thread t owns bins [64t, 64t+64) counted from the TOP (descending).
-__global__ __launch_bounds__(1024) void scan_kernel(uint32_t* __restrict__ hist) {
-    __shared__ uint32_t part[1024];
+// Exclusive scan of the histogram from the largest bin down, in two launches of 64 small blocks:
+// a 1024-thread block would have to wait for a CU with sixteen free wave slots, and with a second
+// batch in flight (bench.py) every CU is busy with that batch's persistent waves -- the single big
+// block used to sit in the queue for milliseconds.  Block b owns the 1024 bins
+// [kBins-1-1024b, kBins-1024(b+1)], thread t four consecutive ones of them.
+constexpr int kScanBlocks = 64, kScanThreads = 256, kPerThread = kBins / kScanBlocks / kScanThreads;
+
+__global__ __launch_bounds__(kScanThreads) void scan_sums_kernel(const uint32_t* __restrict__ hist,
+                                                                 uint32_t* __restrict__ block_sum) {
+    __shared__ uint32_t part[kScanThreads / 64];
     const int t = threadIdx.x;
-    constexpr int per = kBins / 1024;
+    const int top = kBins - 1 - (blockIdx.x * kScanThreads + t) * kPerThread;
     uint32_t sum = 0;
-    for (int j = 0; j < per; ++j) sum += hist[kBins - 1 - (t * per + j)];
+    for (int j = 0; j < kPerThread; ++j) sum += hist[top - j];
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if ((t & 63) == 0) part[t >> 6] = sum;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < kScanThreads / 64; ++w) tot += part[w];
+        block_sum[blockIdx.x] = tot;
+    }
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(uint32_t* __restrict__ hist,
+                                                                  const uint32_t* __restrict__ block_sum) {
+    __shared__ uint32_t part[kScanThreads];
+    const int t = threadIdx.x;
+    const int top = kBins - 1 - (blockIdx.x * kScanThreads + t) * kPerThread;
+    uint32_t c[kPerThread], sum = 0;
+    for (int j = 0; j < kPerThread; ++j) { c[j] = hist[top - j]; sum += c[j]; }
     part[t] = sum;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+    for (int off = 1; off < kScanThreads; off <<= 1) {   // Hillis-Steele inclusive scan
         const uint32_t add = t >= off ? part[t - off] : 0u;
         __syncthreads();
         part[t] += add;
         __syncthreads();
     }
-    uint32_t base = part[t] - sum;   // exclusive
-    for (int j = 0; j < per; ++j) {
-        const int b = kBins - 1 - (t * per + j);
-        const uint32_t c = hist[b];
-        hist[b] = base;              // becomes the bin's write cursor
-        base += c;
+    uint32_t base = part[t] - sum;                       // exclusive inside the block
+    for (int b = 0; b < (int)blockIdx.x; ++b) base += block_sum[b];
+    for (int j = 0; j < kPerThread; ++j) {
+        hist[top - j] = base;                            // becomes the bin's first position
+        base += c[j];
     }
 }
 
@@ -53,7 +76,7 @@ __global__ void scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t
 
 }  // namespace
 
-size_t sort_temp_bytes(int64_t) { return (size_t)kBins * sizeof(uint32_t); }
+size_t sort_temp_bytes(int64_t) { return (size_t)(kBins + kScanBlocks) * sizeof(uint32_t); }
 
 // The histogram of (key >> 16) is built by the kernel that produces the keys: one atomic per
 // instance at the end of the coordinate-descent kernel, whose return value is the instance's rank
@@ -70,7 +93,9 @@ hipError_t order_finish(const uint32_t* keys, const uint32_t* rank, uint32_t* or
     const int block = 256;
     int64_t g = (n + block - 1) / block;
     const unsigned grid = (unsigned)(g < 2048 ? g : 2048);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, hist);
+    uint32_t* block_sum = hist + kBins;
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(kScanBlocks), dim3(kScanThreads), 0, s, (const uint32_t*)hist, block_sum);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(kScanBlocks), dim3(kScanThreads), 0, s, hist, (const uint32_t*)block_sum);
     hipLaunchKernelGGL(scatter_kernel, dim3(grid), dim3(block), 0, s, keys, rank, (const uint32_t*)hist, order, n);
     return hipGetLastError();
 }

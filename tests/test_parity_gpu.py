@@ -367,6 +367,35 @@ def test_phase_boundaries_vs_oracle(torch_cuda, oracle, algo):
         assert bool(flags & FLAG_MAX_ITER) == bool(np.any(oit >= cap)), (smo, cap)
 
 
+def test_two_batches_in_flight(torch_cuda):
+    """bench.py's steady state: two handles on two streams, batches alternating between them
+    (tpc_mpc_reserve up front so that no solve allocates).  Each batch's outputs must be the
+    single-batch outputs bit for bit, whatever the interleaving of the kernels was."""
+    from trajectory_controller_amd.synth import compact_inputs
+    torch = torch_cuda
+    H, n = 20, 98304
+    sets = [_dev(torch, *compact_inputs(H, n, first=7 + 1000 * b)) for b in range(4)]
+    with _solver(H, "lane") as ref:
+        want = [ref.solve_batch_compact(*x, want_iters=True) for x in sets]
+    torch.cuda.synchronize()
+    solvers = [_solver(H, "lane"), _solver(H, "lane")]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for sv in solvers:
+        sv.reserve(n)
+    got = [None] * 8
+    for k in range(8):
+        with torch.cuda.stream(streams[k % 2]):
+            got[k] = solvers[k % 2].solve_batch_compact(*sets[k % 4], want_iters=True, want_flags=False)
+    torch.cuda.synchronize()
+    for k in range(8):
+        f, r, it = got[k]
+        wf, wr, wit = want[k % 4]
+        assert torch.equal(it, wit)
+        assert bits_equal(f.cpu().numpy(), wf.cpu().numpy()) and bits_equal(r.cpu().numpy(), wr.cpu().numpy())
+    for sv in solvers:
+        sv.close()
+
+
 def test_work_hint_changes_order_not_results(torch_cuda):
     """tpc_mpc_set_work_hint: the previous cycle's iteration counts as queue order.  Outputs and
     iteration counts must be bit-identical with no hint, a perfect hint, a reversed (shortest-first)

@@ -57,6 +57,16 @@ TPC_DEV double wave_uniform(double x) {
 }
 TPC_DEV float wave_uniform(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
 
+// The 32-bit word holding a value's sign, and a magnitude (>= 0) given the sign of such a word.
+TPC_DEV int sign_word(double x) { return __double2hiint(x); }
+TPC_DEV int sign_word(float x) { return __float_as_int(x); }
+TPC_DEV double with_sign(double mag, int word) {
+    return __hiloint2double((__double2hiint(mag) & 0x7fffffff) | (word & (int)0x80000000), __double2loint(mag));
+}
+TPC_DEV float with_sign(float mag, int word) {
+    return __int_as_float((__float_as_int(mag) & 0x7fffffff) | (word & (int)0x80000000));
+}
+
 // A multiply the optimiser cannot look into (same instruction, same rounding).  Used where a value
 // is deliberately RE-computed instead of kept in a register: common-subexpression elimination would
 // otherwise merge the re-computation with the original and keep the value alive.

@@ -211,14 +211,16 @@ int tpc_mpc_reserve(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n, int me
 /* No reference counterpart (one controller solves one problem per cycle there).  Instances of a
  * batch need between a few and several thousand iterations (mpc.h:271, :310), and the batch
  * finishes when its slowest lane does, so the LANE kernels start the instances expected to run
- * longest first.  Their own estimate is dlib's lambda (mpc.h:116-123).  A caller that solves
- * nearly the same batch every control cycle knows better: hint[k] = the iteration count instance k
- * needed last cycle (the `iters` output).  The hint applies to the NEXT tpc_mpc_solve_batch_compact
- * / tpc_mpc_solve_batch_general call on this handle if that call has the same n, and is forgotten
- * afterwards; DEVICE hints are read by that call and must stay valid until it has run; hint = NULL
- * clears.  It only decides which lane solves which instance when: outputs, iteration counts and
- * flags are bit-for-bit the same with any hint.  tpc_mpc_follow_batch keeps this history by itself
- * (slot k of one cycle is the same controller as slot k of the next). */
+ * longest first.  Their own estimate is dlib's lambda (mpc.h:116-123) with a correction where it
+ * is uninformative.  A caller that knows the iteration counts better passes them here: hint[k] =
+ * expected iteration count of instance k (e.g. the `iters` output of an earlier solve of the SAME
+ * instances: +7 % throughput at N=20; counts taken from a previous control cycle whose inputs have
+ * since moved by as little as 0.5 % of their range are no better than the built-in order at N=20,
+ * because the count is a ragged function of the inputs).  The hint applies to the NEXT
+ * tpc_mpc_solve_batch_compact / tpc_mpc_solve_batch_general call on this handle if that call has
+ * the same n, and is forgotten afterwards; DEVICE hints are read by that call and must stay valid
+ * until it has run; hint = NULL clears.  It only decides which lane solves which instance when:
+ * outputs, iteration counts and flags are bit-for-bit the same with any hint. */
 int tpc_mpc_set_work_hint(tpc_mpc_handle h, const int32_t* hint, int64_t n, int mem);
 
 /* ---- measurement ------------------------------------------------------------------------------ */

@@ -87,10 +87,6 @@ struct tpc_mpc_context {
     int64_t hint_n = 0;
     void* hint_own = nullptr;
     int64_t hint_own_bytes = 0;
-    // follow_batch keeps the iteration counts of its previous cycle as the hint for the next one
-    void* hist = nullptr;
-    int64_t hist_bytes = 0;
-    int64_t hist_n = 0;            // 0: no history yet
     // optional kernel timing (tpc_mpc_set_profiling)
     bool profiling = false;
     bool ev_valid = false;
@@ -330,7 +326,6 @@ int tpc_mpc_destroy(tpc_mpc_handle h) {
     if (h->stage) (void)hipFree(h->stage);
     if (h->roll) (void)hipFree(h->roll);
     if (h->hint_own) (void)hipFree(h->hint_own);
-    if (h->hist) (void)hipFree(h->hist);
     if (h->pin_host) (void)hipHostFree(h->pin_host);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     delete h;
@@ -651,18 +646,9 @@ int tpc_mpc_follow_batch(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mp
     fa.target_speed = target_speed; fa.target_distance = target_distance;
     hipError_t e = launch_traj_point(fa, s);
     if (e != hipSuccess) return hip_fail(h, e, "traj_point launch");
-    // Controllers keep their slot from cycle to cycle and their problem changes little, so the
-    // iteration counts of the previous cycle order this cycle's queue (unless the caller set a hint).
-    rc = ensure(h, &h->hist, &h->hist_bytes, n * 4);
-    if (rc) { h->hist_n = 0; return rc; }
-    if (!h->hint && h->hist_n == n) { h->hint = (const int32_t*)h->hist; h->hint_n = n; }
-    int32_t* it_dev = iters ? iters : (int32_t*)h->hist;
-    h->hist_n = 0;
     rc = tpc_mpc_solve_batch_compact(h, p, n, fa.v_out, fa.ysoll_out, fa.phisoll_out, steering_front,
-                                     steering_rear, it_dev, nullptr, TPC_MPC_DEVICE, stream);
+                                     steering_rear, iters, nullptr, TPC_MPC_DEVICE, stream);
     if (rc) return rc;
-    if (iters) HIP_TRY(h, hipMemcpyAsync(h->hist, iters, n * 4, hipMemcpyDeviceToDevice, s));
-    h->hist_n = n;
     e = launch_follow_post(n, target_speed, steering_front, steering_rear, s);
     if (e != hipSuccess) return hip_fail(h, e, "follow_post launch");
     return finish_flags(h, flags_out, s);

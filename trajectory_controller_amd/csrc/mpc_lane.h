@@ -435,9 +435,9 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
     auto v_get = [&](int q) -> T { if (q < 2 * KV) return r_v[q]; else return s_v[q][lane]; };
     const T eps = (T)kn.eps;
     // FAST: (u - lo) * 2^600 and (hi - u) * 2^600 as one fma each, exactly zero at the bound and
-    // >= 1e64 off it.  The bounds of a kFastStop model are the same for the whole batch, so the two
+    // far above any admissible eps off it (>= 4e64; fp32, scale 2^100: >= 7e12).  The bounds of a kFastStop model are the same for the whole batch, so the two
     // addends sit in SGPRs and leave the loop's VGPR budget alone.
-    constexpr T kHuge = (T)(sizeof(T) == 8 ? 0x1p600 : 0x1p60);
+    constexpr T kHuge = (T)(sizeof(T) == 8 ? 0x1p600 : 0x1p100);
     T nlo_h[2] = {(T)0, (T)0}, hi_h[2] = {(T)0, (T)0};
     // ... and the factor in VGPRs: a VOP3 instruction reads one SGPR operand at most, and with both
     // constants scalar the compiler copies the addend into VGPRs in front of every fma

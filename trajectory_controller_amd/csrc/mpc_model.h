@@ -222,13 +222,19 @@ struct CompactModel {
     //   |df| <= max|MM| + 8 al^4 q U H^4 + U max R,
     // so al <= 1e60, q <= 1e30, U <= 1e10, R <= 1e100, max|MM| <= 1e300 and H <= 40 keep every
     // value finite (< 1e301).  Anything else (absurd inputs) takes the exact test.
-    static constexpr bool kFastStop = sizeof(T) == 8;
+    // fp32 (scale 2^100): al <= 1e4, q <= 1e4, U <= 1e3, R <= 1e20, max|MM| <= 1e37 keep every
+    // value below 3e38; a bound of magnitude >= 1e-10 leaves g >= 7e12 one ulp off it, hence eps <= 1e10.
+    static constexpr bool kFastStop = true;
     TPC_DEV bool fast_stop_ok(T mm_max, T eps) const {
-        auto lower_ok = [](T l) { return l <= (T)-1e-100 && l >= (T)-1e10; };
-        auto upper_ok = [](T h) { return h >= (T)1e-100 && h <= (T)1e10; };
-        return tabs(a) <= (T)1e60 && tabs(c) <= (T)1e60 && mm_max <= (T)1e300 &&
-               tabs(q0) <= (T)1e30 && tabs(q1) <= (T)1e30 && tabs(r0) <= (T)1e100 && tabs(r1) <= (T)1e100 &&
-               lower_ok(l0) && lower_ok(l1) && upper_ok(h0) && upper_ok(h1) && eps <= (T)1e30;
+        constexpr bool D = sizeof(T) == 8;
+        constexpr T kAl = (T)(D ? 1e60 : 1e4), kQ = (T)(D ? 1e30 : 1e4), kR = (T)(D ? 1e100 : 1e20);
+        constexpr T kMm = (T)(D ? 1e300 : 1e37), kBmin = (T)(D ? 1e-100 : 1e-10), kBmax = (T)(D ? 1e10 : 1e3);
+        constexpr T kEps = (T)(D ? 1e30 : 1e10);
+        auto lower_ok = [&](T l) { return l <= -kBmin && l >= -kBmax; };
+        auto upper_ok = [&](T h) { return h >= kBmin && h <= kBmax; };
+        return tabs(a) <= kAl && tabs(c) <= kAl && mm_max <= kMm && tabs(q0) <= kQ && tabs(q1) <= kQ &&
+               tabs(r0) <= kR && tabs(r1) <= kR && lower_ok(l0) && lower_ok(l1) && upper_ok(h0) &&
+               upper_ok(h1) && eps <= kEps;
     }
 
     TPC_DEV void first(T& m0, T& m1, const T* u) const {

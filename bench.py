@@ -11,14 +11,13 @@ at N=8 that is config 4's 2 097 152), inputs resident in HBM before the timed re
 batch is embarrassingly parallel, so ranks shard it with no data-path collective during the solve;
 for N>1 the control outputs are all-gathered over RCCL inside the timed region (north_star).
 
-Two batches are kept in flight (`--inflight`, default 2): consecutive steps alternate between two
-library handles on two HIP streams, so the next batch's kernels fill the CUs the previous batch's
-last long-running instances no longer need (a batch ends when its slowest lane does; +7 % at
-H = 20).  Every step still solves one whole batch and the timed region still ends with a device
-synchronisation.  The library's HIP events bracket each kernel on its launch stream: "kernel_ms" is
-their average over the last step of each handle inside the timed region (with two batches in flight
-those durations include time a kernel's workgroups wait for CUs), "kernel_ms_serial" the same with
-one batch in flight, measured right after the timed region.
+One batch is in flight by default.  `--inflight 2` alternates consecutive steps between two library
+handles on two HIP streams, so that the next batch's kernels fill the CUs the previous batch's last
+long-running instances no longer need (a batch ends when its slowest lane does): +3 % throughput at
+H = 20.  It is not the default because the HIP events that time each kernel then include the time
+its workgroups wait for CUs and stop agreeing with rocprofv3's dispatch timestamps.  "kernel_ms" is
+the average over the timed region of the library's events around each kernel (last solve of each
+handle), "kernel_ms_serial" the same measured right after the timed region with one batch in flight.
 
 `value` is measured in fp64, the only dtype that meets the 1e-6 parity target (SURVEY.md section 0
 fact 3); the fp32 rate of the same workload is reported beside it under "fp32" with its error
@@ -59,7 +58,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-fp32", action="store_true")
-    ap.add_argument("--inflight", type=int, default=2, help="batches kept in flight (handle + stream each)")
+    ap.add_argument("--inflight", type=int, default=1, help="batches kept in flight (handle + stream each)")
     return ap.parse_args()
 
 

@@ -9,7 +9,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 for dtype in ("f64", "f32"):
     tdt = torch.float64 if dtype == "f64" else torch.float32
     for H in (4, 5, 10, 20, 30, 40):
-        m = n if H <= 20 else n // 4
+        m = n
         v, dy, dphi = (torch.from_numpy(a).to("cuda", dtype=tdt) for a in compact_inputs(H, m))
         with MpcSolver(horizon=H, dtype=dtype, algo="lane") as s:
             s.set_profiling(True)

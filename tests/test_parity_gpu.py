@@ -68,7 +68,7 @@ def test_compact_golden(torch_cuda, H, algo):
     assert np.all(it[known] >= g["iters_lb"][known])
 
 
-@pytest.mark.parametrize("H", [4, 10, 20])
+@pytest.mark.parametrize("H", [4, 10, 20, 30])
 @pytest.mark.parametrize("algo", ["lane", "wave"])
 def test_compact_vs_oracle_iters(torch_cuda, oracle, H, algo):
     """Fresh seeded inputs (not the fixture ones): outputs AND iteration counts against the oracle."""
@@ -184,6 +184,24 @@ def test_general_golden(torch_cuda, I, H, algo):
         assert bits_equal(u0.T, g["u0"])
     else:
         assert np.abs(u0.T - g["u0"]).max() <= WAVE_ATOL
+
+
+@pytest.mark.parametrize("I", [1, 2])
+def test_general_h30_vs_oracle(torch_cuda, oracle, I):
+    """H = 30 is the one horizon whose fused LANE kernel keeps its forward-pass array and momentum
+    vector in AGPRs (FusedBig, mpc_lane.h); the general model also routes the linear term's
+    intermediates through them.  Cold start, so the fused kernel runs."""
+    from trajectory_controller_amd.synth import general_inputs
+    H, n = 30, 1500
+    g = general_inputs(H, n, I=I, first=31)
+    u0, _, it = oracle.solve_general(I, H, g["A"], g["B"], g["C"], g["Q"], g["R"], g["lo"], g["hi"],
+                                     g["x0"], g["targets"], nthreads=8)
+    names = ["A", "B", "C", "Q", "R", "lo", "hi", "x0", "targets"]
+    host = [_soa(g[k]) for k in names]
+    with _solver(H, "lane") as s:
+        gu0, git = s.solve_batch_general(*host, inputs=I, want_iters=True)
+    assert np.array_equal(git, it)
+    assert bits_equal(gu0.T, u0)
 
 
 @pytest.mark.parametrize("algo", ["lane", "wave"])

@@ -402,6 +402,15 @@ constexpr int kRefillBatch = TPC_REFILL_BATCH;
 template <typename T, int H> struct FusedInRegs { static constexpr bool value = H * (int)sizeof(T) <= 80; };
 template <typename T, int H> struct FusedVRegSteps { static constexpr int value = (sizeof(T) == 8 && H == 20) ? 8 : 0; };
 template <typename T, int H> struct FusedOcc { static constexpr int value = FusedInRegs<T, H>::value ? 2 : 1; };
+// fp64, H = 30: u (120 words) fits the VGPRs, but MM and v in LDS take 61 KB per wave and leave two
+// of a CU's four SIMDs without a wave.  The forward-pass array w and all of v go to AGPRs instead
+// (240 of the 256; two v_accvgpr moves per double and direction: 550 of the loop's 2130
+// instructions), MM alone stays in LDS (31 KB): four waves per CU, 70 -> 43 ms for 262 144
+// instances.  At H = 40 the same plan was measured 1.5x SLOWER than MM + v in LDS (80 KB, two
+// waves per CU, w spilled by the compiler): only 20 steps of v fit the AGPRs next to w, LDS still
+// allows two waves only, and the moves are pure cost.
+template <typename T, int H> struct FusedBig { static constexpr bool value = sizeof(T) == 8 && H == 30; };
+template <typename T, int H> struct FusedAgprSteps { static constexpr int value = FusedBig<T, H>::value ? H : 0; };
 
 template <typename T, int I, int H, class Model, class Args, bool FAST>
 __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::value)) void lane_pg_fused_kernel(Args g, Knobs kn, const T* __restrict__ recs,
@@ -421,18 +430,30 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
     // barrier anywhere): one 40 KB workgroup per SIMD pair is what the CU is known to co-schedule.
     constexpr int BT = kWave * FusedOcc<T, H>::value;
     constexpr bool REGS = FusedInRegs<T, H>::value;
+    constexpr int KV = REGS ? H : FusedVRegSteps<T, H>::value;   // steps of v in VGPRs
+    constexpr int KA = FusedAgprSteps<T, H>::value;              // next steps of v in AGPRs
+    constexpr int VL = H - KV - KA;                              // the rest of v in LDS
+    constexpr bool WA = FusedBig<T, H>::value;                   // w in AGPRs
     __shared__ T s_mm[REGS ? 1 : 2 * H][BT];
-    __shared__ T s_v[REGS ? 1 : 2 * H][BT];
+    __shared__ T s_v[VL > 0 ? 2 * VL : 1][BT];
     // the first KV horizon steps of v stay in VGPRs even when the rest lives in LDS: the inner loop
     // has a few dozen registers to spare, and every step kept saves a ds_read2 and a ds_write2
     // (H = 20 fp64, A/B on one box: KV = 4 / 6 / 8 / 10 / 12 -> +1.7 / +2.0 / +2.1 / +1.5 / -1.0 %)
-    constexpr int KV = REGS ? H : FusedVRegSteps<T, H>::value;
     T r_mm[REGS ? 2 * H : 1], r_v[2 * KV + 1];   // register-resident copies
+    AgprWord a_v[2 * KA + 1], a_w[WA ? 2 * H : 1];
     const int lane = threadIdx.x;   // LDS column; ballots below are per wavefront
     auto mm_put = [&](int q, T val) { if constexpr (REGS) r_mm[q] = val; else s_mm[q][lane] = val; };
     auto mm_get = [&](int q) -> T { if constexpr (REGS) return r_mm[q]; else return s_mm[q][lane]; };
-    auto v_put = [&](int q, T val) { if (q < 2 * KV) r_v[q] = val; else s_v[q][lane] = val; };
-    auto v_get = [&](int q) -> T { if (q < 2 * KV) return r_v[q]; else return s_v[q][lane]; };
+    auto v_put = [&](int q, T val) {
+        if (q < 2 * KV) r_v[q] = val;
+        else if (q < 2 * (KV + KA)) agpr_put(a_v[q - 2 * KV], val);
+        else s_v[q - 2 * (KV + KA)][lane] = val;
+    };
+    auto v_get = [&](int q) -> T {
+        if (q < 2 * KV) return r_v[q];
+        else if (q < 2 * (KV + KA)) return agpr_get<T>(a_v[q - 2 * KV]);
+        else return s_v[q - 2 * (KV + KA)][lane];
+    };
     const T eps = (T)kn.eps;
     // FAST: (u - lo) * 2^600 and (hi - u) * 2^600 as one fma each, exactly zero at the bound and
     // far above any admissible eps off it (>= 4e64; fp32, scale 2^100: >= 7e12).  The bounds of a kFastStop model are the same for the whole batch, so the two
@@ -452,7 +473,9 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
     }
 
     Model m;
-    T u[2 * H], w[2 * H];
+    T u[2 * H], w[WA ? 1 : 2 * H];
+    auto w_put = [&](int q, T val) { if constexpr (WA) agpr_put(a_w[q], val); else w[q] = val; };
+    auto w_get = [&](int q) -> T { if constexpr (WA) return agpr_get<T>(a_w[q]); else return w[q]; };
     T u0_prev[2] = {(T)0, (T)0};
     T inv_lambda = (T)0, beta = (T)0;
     int64_t k = 0;
@@ -461,7 +484,7 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
     uint32_t flags = 0;
     uint32_t wave_iters = 0, refills = 0;
 #pragma unroll
-    for (int q = 0; q < 2 * H; ++q) { u[q] = (T)0; mm_put(q, (T)0); v_put(q, (T)0); }
+    for (int q = 0; q < 2 * H; ++q) { u[q] = (T)0; mm_put(q, (T)0); v_put(q, (T)0); w_put(q, (T)0); }
 
     auto publish = [&](T a0, T a1, uint32_t it) {
         if constexpr (std::is_same<Args, CompactArgs>::value) {
@@ -511,7 +534,11 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
                         if (!(meta & kMetaStopped)) flags |= 0x2u;
                         publish(u[0], u[1], iter);
                     } else {
-                        linear_term<T, I, H>(m, w, [&](int q, T val) { mm_put(q, val); });
+                        auto mm_emit = [&](int q, T val) { mm_put(q, val); };
+                        if constexpr (WA && !std::is_same<Model, CompactModel<T>>::value)
+                            linear_term_fn<T, I, H>(m, w_put, w_get, mm_emit);
+                        else
+                            linear_term<T, I, H>(m, w, mm_emit);
                         inv_lambda = (T)1.0 / lambda;                         // mpc.h:342
                         const T sq = tsqrt(lambda);
                         beta = (sq - (T)1) / (sq + (T)1);                     // mpc.h:343
@@ -541,11 +568,11 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
         // ---- forward pass: M[i] = A*M[i-1] + B*u[i]                       (mpc.h:275-277)
         T m0, m1;
         m.first(m0, m1, &u[0]);
-        w[0] = m0; w[1] = m1;
+        w_put(0, m0); w_put(1, m1);
 #pragma unroll
         for (int i = 1; i < H; ++i) {
             m.fwd(m0, m1, &u[2 * i]);
-            w[2 * i] = m0; w[2 * i + 1] = m1;
+            w_put(2 * i, m0); w_put(2 * i + 1, m1);
         }
         // ---- backward pass fused with the stop test and the speculative update
         u0_prev[0] = u[0]; u0_prev[1] = u[1];
@@ -562,7 +589,7 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
                 });
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (i < H - 1) m.bwd(n0, n1, w[2 * i], w[2 * i + 1]);     // mpc.h:280-281
+            if constexpr (i < H - 1) m.bwd(n0, n1, w_get(2 * i), w_get(2 * i + 1));   // mpc.h:280-281
             T vn[2];
             static_for<I>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;

@@ -67,6 +67,31 @@ TPC_DEV float with_sign(float mag, int word) {
     return __int_as_float((__float_as_int(mag) & 0x7fffffff) | (word & (int)0x80000000));
 }
 
+// A value parked in the accumulation half of the register file (AGPRs).  VALU instructions cannot
+// name AGPRs, so every access is a v_accvgpr move per 32-bit word: two issue slots per double and
+// direction -- dearer than a VGPR, cheaper than leaving half the CU idle for want of LDS (see
+// FusedBig in mpc_lane.h).  The words are ordinary values of register class "a" to the compiler.
+struct AgprWord { int lo, hi; };
+TPC_DEV void agpr_put(AgprWord& s, double x) {
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(s.lo) : "v"(__double2loint(x)));
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(s.hi) : "v"(__double2hiint(x)));
+}
+TPC_DEV void agpr_put(AgprWord& s, float x) {
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(s.lo) : "v"(__float_as_int(x)));
+}
+template <typename T> TPC_DEV T agpr_get(const AgprWord& s);
+template <> TPC_DEV double agpr_get<double>(const AgprWord& s) {
+    int lo, hi;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(s.lo));
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(s.hi));
+    return __hiloint2double(hi, lo);
+}
+template <> TPC_DEV float agpr_get<float>(const AgprWord& s) {
+    int lo;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(s.lo));
+    return __int_as_float(lo);
+}
+
 // A multiply the optimiser cannot look into (same instruction, same rounding).  Used where a value
 // is deliberately RE-computed instead of kept in a register: common-subexpression elimination would
 // otherwise merge the re-computation with the original and keep the value alive.

@@ -11,7 +11,7 @@ from trajectory_controller_amd.synth import compact_inputs
 ref = DlibRef(REF_SO)
 threads = int(os.environ.get("THREADS", "16"))
 bad = 0
-for H, n in ((4, 1 << 20), (5, 1 << 20), (10, 1 << 20), (20, 1 << 20), (40, 1 << 17)):
+for H, n in ((4, 1 << 20), (5, 1 << 20), (10, 1 << 20), (20, 1 << 20), (30, 1 << 18), (40, 1 << 17)):
     v, dy, dphi = compact_inputs(H, n, first=10_000_000)
     t0 = time.time()
     rf, rr = ref.solve_compact(H, v, dy, dphi, nthreads=threads)

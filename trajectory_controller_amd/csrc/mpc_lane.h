@@ -395,10 +395,15 @@ template <int N, class F> TPC_DEV void static_for(F&& f) { static_for_impl(f, st
 // at their 2-cycle rate instead of one per 4-cycle slot.  (With MM and v in LDS, two waves per SIMD
 // gained nothing: eight waves' ds_read2/ds_write kept the CU's one LDS pipe busy 90 % of the time.)
 // The same holds for fp64 up to H = 10 (4 x 2H doubles = 160 VGPRs).
-#ifndef TPC_REFILL_BATCH
-#define TPC_REFILL_BATCH 2
+// Free lanes wait until this many of them can be refilled by one pass (see the refill block).  The
+// pass costs about 4 us whatever the horizon, an iteration 0.2 us at H = 4 and 2.4 us at H = 20, so
+// short horizons batch more.  Measured optima (PG kernel, n = 262 144): H = 4: 1.09 ms at 2, 0.27 ms
+// at 24-48; H = 5: 0.34 ms at 24; H = 10: flat from 3 to 8; H = 20: 10.24 ms at 2, 9.82 at 3-4.
+#ifdef TPC_REFILL_BATCH   // A/B override
+template <int H> struct RefillBatch { static constexpr int value = TPC_REFILL_BATCH; };
+#else
+template <int H> struct RefillBatch { static constexpr int value = H <= 5 ? 24 : (H <= 10 ? 6 : 3); };
 #endif
-constexpr int kRefillBatch = TPC_REFILL_BATCH;
 template <typename T, int H> struct FusedInRegs { static constexpr bool value = H * (int)sizeof(T) <= 80; };
 template <typename T, int H> struct FusedVRegSteps { static constexpr int value = (sizeof(T) == 8 && H == 20) ? 8 : 0; };
 template <typename T, int H> struct FusedOcc { static constexpr int value = FusedInRegs<T, H>::value ? 2 : 1; };
@@ -505,10 +510,10 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
         // queue and the kernel gets slower.)
         // A refill stalls the whole wave for about two iterations (ticket, queue entry, record and
         // inputs are three dependent global round trips, then the linear term is rebuilt), so free
-        // lanes wait until kRefillBatch of them can be served by one pass; an idle lane costs 1/64
+        // lanes wait until RefillBatch<H> of them can be served by one pass; an idle lane costs 1/64
         // of an iteration per iteration, which is far less.
         const unsigned long long want = __ballot(!have && !exhausted);
-        if (want != 0ull && (__popcll(want) >= kRefillBatch || __ballot(have) == 0ull)) {
+        if (want != 0ull && (__popcll(want) >= RefillBatch<H>::value || __ballot(have) == 0ull)) {
             ++refills;
             if (!have && !exhausted) {
                 const uint32_t t = atomicAdd(ticket, 1u);

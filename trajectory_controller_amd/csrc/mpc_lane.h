@@ -234,9 +234,16 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args 
     if (I == 2) lambda_floor = lambda_floor + m.R(I - 1);
     lambda_floor = lambda_floor * (T)H;
     const bool uninformative = lambda < (T)1.5 * lambda_floor;
-    const float lf = g.work_hint ? (float)(g.work_hint[k] > 0 ? g.work_hint[k] : 1)
-                                 : (uninformative ? 3.0e38f : (float)lambda);
-    const uint32_t key = (finished || !(lf > 0.0f)) ? 0u : __float_as_uint(lf);
+    const float lf = g.work_hint ? (float)(g.work_hint[k] > 0 ? g.work_hint[k] : 1) : (float)lambda;
+    // The two classes whose internal order does not matter -- finished instances (bottom of the
+    // queue) and uninformative ones (top) -- are spread over 128 bins each by their lane index:
+    // one bin each meant up to 10^5 atomics queueing on a single address (most of the CD kernel's
+    // time at H = 4, where both classes are large).
+    const uint32_t spread = (uint32_t)k & 127u;
+    uint32_t key = __float_as_uint(lf);
+    if (finished || !(lf > 0.0f)) key = spread << 16;                             // below every positive normal float
+    else if (!g.work_hint && uninformative) key = (0x7f00u + spread) << 16;       // above every lambda
+    else if (key >= 0x7f000000u) key = 0x7effffffu;                               // (an absurd lambda stays below them)
     keys[k] = key;
     key_rank[k] = atomicAdd(&key_hist[key >> 16], 1u);   // counting sort: histogram + rank in bin (mpc_sort.hip)
 }

@@ -522,8 +522,14 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
         const unsigned long long want = __ballot(!have && !exhausted);
         if (want != 0ull && (__popcll(want) >= RefillBatch<H>::value || __ballot(have) == 0ull)) {
             ++refills;
+            // one atomic per pass, for exactly the tickets it will use (at H = 4 a quarter of a
+            // million single-ticket atomics would hit the counter within 0.3 ms)
+            const int wl = lane & (kWave - 1);
+            uint32_t first_ticket = 0;
+            if (wl == __ffsll((long long)want) - 1) first_ticket = atomicAdd(ticket, (uint32_t)__popcll(want));
+            first_ticket = (uint32_t)__shfl((int)first_ticket, __ffsll((long long)want) - 1);
             if (!have && !exhausted) {
-                const uint32_t t = atomicAdd(ticket, 1u);
+                const uint32_t t = first_ticket + (uint32_t)__popcll(want & ((1ull << wl) - 1ull));
                 if ((int64_t)t >= g.n) {
                     exhausted = true;
                 } else {

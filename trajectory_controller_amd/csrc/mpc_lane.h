@@ -380,16 +380,17 @@ template <int N, class F> TPC_DEV void static_for(F&& f) { static_for_impl(f, st
 
 // ------------------------------------------------------------------------------------------------
 // Phase 2, fused and software-pipelined form: the throughput kernel.  Same arithmetic as
-// lane_pg_kernel, scheduled for ONE wave per SIMD, where (measured, scripts/ubench_dp.hip) every
-// instruction of any kind costs one ~2.1 ns issue slot -- the fp64 VALU rate at the ~2.0 GHz the
-// chip holds under fp64 load -- and nothing hides LDS latency but the wave's own instruction stream:
+// lane_pg_kernel, scheduled for ONE wave per SIMD, where (measured, scripts/ubench_dp.hip,
+// ubench_lds2.hip) every VALU or SALU instruction costs one ~2.1 ns issue slot -- the fp64 VALU
+// rate at the ~2.0 GHz the chip holds under fp64 load --, an LDS instruction of any width about
+// three, and nothing hides LDS latency but the wave's own instruction stream:
 //   * the backward pass, the stop test and the projected-gradient update are fused per horizon
 //     step: as soon as df[i] exists its contribution to max|df| is taken and u[i], v[i] are
 //     advanced speculatively.  dlib updates only when the stop test fails; a lane that stops
 //     publishes the controls it had BEFORE this update (u[0] is all the caller receives, so only
 //     u[0] is kept) and refills, so the speculation is never observable;
 //   * MM (read once per iteration) and v (read once, written once) live in LDS as [var][lane]
-//     columns (40 KB per wave at H=20 fp64: four waves fill the CU's 160 KB); each step's four
+//     columns (20 + 12 KB per wave at H=20 fp64, where 8 steps of v stay in VGPRs); each step's four
 //     values are fetched ONE STEP AHEAD into a small register ring, so their latency hides under
 //     the previous step's ~55 instructions; one __builtin_amdgcn_sched_barrier(0) per step pins the
 //     prefetch at the top of its step (without it the loads sink to their uses; a second barrier

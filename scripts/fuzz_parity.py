@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Randomised differential run on the GPU box: LANE fp64 (both builds of the stop test, every
+horizon) against the CPU oracle with random weights, bounds, step size, wheelbase, eps and
+iteration caps.  Prints one line per parameter set; exits non-zero on any mismatch."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle.bindings import Oracle, build_oracle
+from trajectory_controller_amd import MpcSolver
+from trajectory_controller_amd.synth import compact_inputs
+
+build_oracle()
+orc = Oracle()
+rng = np.random.default_rng(int(os.environ.get("SEED", "20261003")))
+sets = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+threads = int(os.environ.get("THREADS", "16"))
+bad = 0
+t_start = time.time()
+for s_i in range(sets):
+    H = int(rng.choice([4, 5, 10, 20, 30, 40], p=[0.2, 0.15, 0.25, 0.25, 0.1, 0.05]))
+    m = n if H <= 20 else n // 4
+    w = (10 ** rng.uniform(-1, 2), 10 ** rng.uniform(-1, 2), 10 ** rng.uniform(-4, 1), 10 ** rng.uniform(-2, 1.5))
+    kind = rng.integers(0, 5)
+    if kind == 0:   lo, hi = (-0.384, -0.384), (0.384, 0.384)
+    elif kind == 1: a, b = rng.uniform(0.02, 0.6, 2); lo, hi = (-a, -b), (b, a)              # straddling, asymmetric
+    elif kind == 2: a = rng.uniform(0.05, 0.5); lo, hi = (0.0, -a), (a, 0.0)                  # start point on a bound
+    elif kind == 3: a = rng.uniform(0.05, 0.3); lo, hi = (a / 2, -a), (a, -a / 2)             # start point outside
+    else:           a = rng.uniform(1e-3, 2e-2); lo, hi = (-a, -a), (a, a)                    # everything saturates
+    T = float(rng.uniform(0.02, 0.3)); l = float(rng.uniform(0.1, 0.5))
+    eps = float(10 ** rng.uniform(-4, -1)); cap = int(rng.choice([10000, 10000, 10000, 10000, 300, 77, 51, 50, 20]))
+    smo = int(rng.choice([50, 50, 50, 0, 7, 120]))
+    v, dy, dphi = compact_inputs(H, m, first=int(rng.integers(0, 1 << 30)))
+    scale = float(rng.choice([1.0, 1.0, 0.2, 3.0]))
+    dy, dphi = dy * scale, dphi * scale
+    if rng.random() < 0.3:
+        v[rng.integers(0, m, 5)] = rng.choice([0.0, 1e-12, 50.0, np.nan, 1e70], 5)
+    of, orr, oit = orc.solve_compact(H, v, dy, dphi, weights=w, T=T, l=l, lo=lo, hi=hi, eps=eps,
+                                     max_iter=cap, smo_iters=smo, nthreads=threads)
+    with MpcSolver(horizon=H, algo="lane", weight_y=w[0], weight_phi=w[1], weight_steering_front=w[2],
+                   weight_steering_rear=w[3], lower=lo, upper=hi, step_size=T, wheelbase=l, eps=eps,
+                   max_iter=cap, smo_iters=smo) as s:
+        f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+    same = lambda x, y: np.array_equal(x.view(np.uint64), y.view(np.uint64))
+    mism = int(np.sum((f.view(np.uint64) != of.view(np.uint64)) | (r.view(np.uint64) != orr.view(np.uint64)) | (it != oit)))
+    bad += mism
+    print(f"set {s_i:3d} H={H:2d} n={m:5d} bounds kind {kind} eps {eps:.1e} cap {cap:5d} smo {smo:3d} "
+          f"mean iters {oit.mean():7.1f}: mismatching instances {mism}", flush=True)
+print(f"{sets} parameter sets, total mismatches {bad}, {time.time() - t_start:.0f} s")
+sys.exit(1 if bad else 0)

@@ -7,6 +7,8 @@
 
 #include <cmath>
 #include <cstdio>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -87,6 +89,8 @@ struct tpc_mpc_context {
     int64_t hint_n = 0;
     void* hint_own = nullptr;
     int64_t hint_own_bytes = 0;
+    // solve_one has no flags output: it skips the flag word's memset and the kernels' atomicOr
+    bool collect_flags = true;
     // optional kernel timing (tpc_mpc_set_profiling)
     bool profiling = false;
     bool ev_valid = false;
@@ -375,7 +379,7 @@ int tpc_mpc_solve_batch_compact(tpc_mpc_handle h, const tpc_mpc_params* p, int64
         a.front = b + 3 * col; a.rear = b + 4 * col;
         a.iters = iters ? (int32_t*)(b + 5 * col) : nullptr;
     }
-    a.flags = h->ws_words + 1;
+    a.flags = h->collect_flags ? h->ws_words + 1 : nullptr;
     a.work_hint = take_hint(h, n);
     a.step = p->step_size; a.wheelbase = p->wheelbase;
     a.q[0] = p->weight_y; a.q[1] = p->weight_phi;
@@ -385,7 +389,7 @@ int tpc_mpc_solve_batch_compact(tpc_mpc_handle h, const tpc_mpc_params* p, int64
     Workspace ws;
     rc = prepare_workspace(h, algo, p->horizon, p->dtype, n, &ws);
     if (rc) return rc;
-    HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
+    if (a.flags) HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
     hipError_t e = dispatch_compact(algo, p->horizon, p->dtype, a, knobs_of(p), ws, s);
     if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
 
@@ -416,10 +420,35 @@ int tpc_mpc_solve_one(tpc_mpc_handle h, const tpc_mpc_params* p, double v, doubl
         float* x = (float*)hp;
         x[0] = (float)v; x[1] = (float)delta_y; x[2] = (float)delta_phi;
     }
+    // The outputs are pre-set to a NaN with a payload no solve produces; the kernel's two stores
+    // into the mapped block are the completion signal the host polls for (a stream synchronise
+    // costs 10-20 us more than the solve itself at N = 4).  Bounded: after 2 ms of polling, or if
+    // the pattern is still there when the stream has drained, fall back to the stream's verdict.
+    const uint64_t sentinel64 = 0x7ff8dead5eedc0deull;
+    const uint32_t sentinel32 = 0x7fc5eed1u;
+    if (q.dtype == TPC_MPC_F64) { std::memcpy(hp + 3 * es, &sentinel64, 8); std::memcpy(hp + 4 * es, &sentinel64, 8); }
+    else { std::memcpy(hp + 3 * es, &sentinel32, 4); std::memcpy(hp + 4 * es, &sentinel32, 4); }
+    h->collect_flags = false;
     int rc = tpc_mpc_solve_batch_compact(h, &q, 1, dp, dp + es, dp + 2 * es, dp + 3 * es, dp + 4 * es, nullptr,
                                          nullptr, TPC_MPC_DEVICE, nullptr);
+    h->collect_flags = true;
     if (rc) return rc;
-    HIP_TRY(h, hipStreamSynchronize(nullptr));
+    bool done = false;
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int it = 0; !done; ++it) {
+            if (q.dtype == TPC_MPC_F64) {
+                const volatile uint64_t* o = (const volatile uint64_t*)(hp + 3 * es);
+                done = o[0] != sentinel64 && o[1] != sentinel64;
+            } else {
+                const volatile uint32_t* o = (const volatile uint32_t*)(hp + 3 * es);
+                done = o[0] != sentinel32 && o[1] != sentinel32;
+            }
+            if (!done && (it & 255) == 255 &&
+                std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+    }
+    if (!done) HIP_TRY(h, hipStreamSynchronize(nullptr));
     if (q.dtype == TPC_MPC_F64) {
         *steering_front = ((double*)hp)[3];
         *steering_rear = ((double*)hp)[4];

@@ -2,7 +2,7 @@
 """Large differential run on the GPU box: LANE (fp64) outputs against REAL dlib (oracle/_ref) on
 fresh seeded instances, all horizons.  Prints one line per horizon; exits non-zero on any mismatch."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle.bindings import DlibRef, REF_SO
 from trajectory_controller_amd import MpcSolver

@@ -3,7 +3,7 @@
 horizon) against the CPU oracle with random weights, bounds, step size, wheelbase, eps and
 iteration caps.  Prints one line per parameter set; exits non-zero on any mismatch."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle.bindings import Oracle, build_oracle
 from trajectory_controller_amd import MpcSolver

@@ -2,7 +2,7 @@
 """Randomised differential run, general form (per-instance A, B, C, Q, R, bounds, x0, per-step
 targets; I = 1, 2): LANE fp64 against the CPU oracle, bit for bit, iteration counts included."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle.bindings import Oracle, build_oracle
 from trajectory_controller_amd import MpcSolver

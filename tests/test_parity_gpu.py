@@ -187,6 +187,24 @@ def test_general_golden(torch_cuda, I, H, algo):
 
 
 @pytest.mark.parametrize("I", [1, 2])
+def test_general_h40_vs_oracle(torch_cuda, oracle, I):
+    """The largest LANE kernels (general form, H = 40: 512 registers plus scratch).  LLVM's
+    iterative-ILP scheduler miscompiled the I = 2 ones into a wild address, so this horizon is built
+    with the default scheduler (csrc/Makefile); this test is what watches that decision."""
+    from trajectory_controller_amd.synth import general_inputs
+    H, n = 40, 600
+    g = general_inputs(H, n, I=I, first=77)
+    u0, _, it = oracle.solve_general(I, H, g["A"], g["B"], g["C"], g["Q"], g["R"], g["lo"], g["hi"],
+                                     g["x0"], g["targets"], nthreads=8)
+    names = ["A", "B", "C", "Q", "R", "lo", "hi", "x0", "targets"]
+    host = [_soa(g[k]) for k in names]
+    with _solver(H, "lane") as s:
+        gu0, git = s.solve_batch_general(*host, inputs=I, want_iters=True)
+    assert np.array_equal(git, it)
+    assert bits_equal(gu0.T, u0)
+
+
+@pytest.mark.parametrize("I", [1, 2])
 def test_general_h30_vs_oracle(torch_cuda, oracle, I):
     """H = 30 is the one horizon whose fused LANE kernel keeps its forward-pass array and momentum
     vector in AGPRs (FusedBig, mpc_lane.h); the general model also routes the linear term's

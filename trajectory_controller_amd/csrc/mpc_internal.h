@@ -59,6 +59,7 @@ struct Workspace {
 // mpc_sort.hip
 size_t sort_temp_bytes(int64_t n);
 hipError_t order_begin(void* temp, hipStream_t s);   // zero the bins the key producer counts into
+const uint32_t* order_queue_len(const void* temp);   // device word: queue entries above the lowest 128 bins
 hipError_t order_finish(const uint32_t* keys, const uint32_t* rank, uint32_t* order, int64_t n, void* temp,
                         hipStream_t s);
 

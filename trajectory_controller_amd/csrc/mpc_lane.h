@@ -139,7 +139,8 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args 
                                                          uint32_t* __restrict__ keys,
                                                          uint32_t* __restrict__ key_rank,
                                                          uint32_t* __restrict__ key_hist,
-                                                         unsigned long long* __restrict__ stats) {
+                                                         unsigned long long* __restrict__ stats,
+                                                         int publish_finished) {
     constexpr int RL = LaneRec<T, H>::kLen;
     __shared__ T s_qd[2 * H][kWave];   // Q_diag[i](j) of lane l at s_qd[2*i + j][l]
     __shared__ T s_mm[2 * H][kWave];   // MM[i](j)
@@ -241,9 +242,21 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args 
     // time at H = 4, where both classes are large).
     const uint32_t spread = (uint32_t)k & 127u;
     uint32_t key = __float_as_uint(lf);
-    if (finished || !(lf > 0.0f)) key = spread << 16;                             // below every positive normal float
+    if (finished) key = spread << 16;                                             // bins 0..127: below every positive normal float
     else if (!g.work_hint && uninformative) key = (0x7f00u + spread) << 16;       // above every lambda
-    else if (key >= 0x7f000000u) key = 0x7effffffu;                               // (an absurd lambda stays below them)
+    else if (!(lf > 0.0f) || key < 0x00800000u) key = 0x00800000u;                // (an absurd lambda stays between them)
+    else if (key >= 0x7f000000u) key = 0x7effffffu;
+    // When the caller does not want the controller state back, an instance this phase finished
+    // (about half of them at H = 4) is complete: its outputs go out here, and the PG kernel's queue
+    // ends where bins 0..127 begin (the scan leaves that position in the histogram, mpc_sort.hip).
+    if (publish_finished && finished) {
+        LaneIO<T, I, H, Args>::write(g, k, u, [&](int) { return (T)0; }, iter);
+        uint32_t f = 0;
+        if (nonfinite) f |= 0x1u;
+        if (badmodel) f |= 0x4u;
+        if (!stopped) f |= 0x2u;          // ran into max_iter inside this phase
+        if (g.flags && f) atomicOr(g.flags, f);
+    }
     keys[k] = key;
     key_rank[k] = atomicAdd(&key_hist[key >> 16], 1u);   // counting sort: histogram + rank in bin (mpc_sort.hip)
 }
@@ -429,9 +442,12 @@ template <typename T, int I, int H, class Model, class Args, bool FAST>
 __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::value)) void lane_pg_fused_kernel(Args g, Knobs kn, const T* __restrict__ recs,
                                                               const uint32_t* __restrict__ order,
                                                               uint32_t* __restrict__ ticket,
-                                                              unsigned long long* __restrict__ stats) {
+                                                              unsigned long long* __restrict__ stats,
+                                                              const uint32_t* __restrict__ queue_len) {
     constexpr int RL = LaneRec<T, H>::kLen;
     static_assert(!FAST || Model::kFastStop, "the select-free stop test needs a model with a screen");
+    // instances the CD kernel already published sit behind this position of the queue
+    const int64_t n_queue = (int64_t)__builtin_nontemporal_load(queue_len);
     // Models with a screen get two builds of this kernel, launched back to back; the coordinate-
     // descent kernel has decided which of them works (stats[2] != 0: some instance failed the
     // screen, the batch takes the exact build) and the other one returns here.
@@ -531,7 +547,7 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
             first_ticket = (uint32_t)__shfl((int)first_ticket, __ffsll((long long)want) - 1);
             if (!have && !exhausted) {
                 const uint32_t t = first_ticket + (uint32_t)__popcll(want & ((1ull << wl) - 1ull));
-                if ((int64_t)t >= g.n) {
+                if ((int64_t)t >= n_queue) {
                     exhausted = true;
                 } else {
                     k = (int64_t)order[t];

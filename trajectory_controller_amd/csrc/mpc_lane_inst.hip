@@ -45,7 +45,7 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
     const int cd_grid = (int)((a.n + kWave - 1) / kWave);
     if (ws.ev) (void)hipEventRecord(ws.ev[0], s);
     hipLaunchKernelGGL((lane_cd_kernel<T, I, kH, Model, Args>), dim3(cd_grid), dim3(kWave), 0, s, a, k, recs,
-                       ws.keys, ws.rank, (uint32_t*)ws.sort_temp, ws.stats);
+                       ws.keys, ws.rank, (uint32_t*)ws.sort_temp, ws.stats, wants_state(a) ? 0 : 1);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     e = order_finish(ws.keys, ws.rank, ws.order, a.n, ws.sort_temp, s);
@@ -59,17 +59,19 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
     } else {
         constexpr int bt = kWave * FusedOcc<T, kH>::value;
         const int64_t need = (a.n + bt - 1) / bt;
+        // first queue position of the instances the CD kernel published itself (order_finish)
+        const uint32_t* queue_len = order_queue_len(ws.sort_temp);
         if constexpr (Model::kFastStop) {
             // both builds go out; the one the CD kernel's screen did not pick returns at once
             static const int fast_cap = pg_grid(lane_pg_fused_kernel<T, I, kH, Model, Args, true>, bt);
             hipLaunchKernelGGL((lane_pg_fused_kernel<T, I, kH, Model, Args, true>),
                                dim3((unsigned)(need < fast_cap ? need : fast_cap)), dim3(bt), 0, s, a, k,
-                               (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats);
+                               (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats, queue_len);
         }
         static const int grid_cap = pg_grid(lane_pg_fused_kernel<T, I, kH, Model, Args, false>, bt);
         hipLaunchKernelGGL((lane_pg_fused_kernel<T, I, kH, Model, Args, false>),
                            dim3((unsigned)(need < grid_cap ? need : grid_cap)), dim3(bt), 0, s, a, k,
-                           (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats);
+                           (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats, queue_len);
     }
     e = hipGetLastError();
     if (ws.ev) (void)hipEventRecord(ws.ev[2], s);

@@ -82,6 +82,10 @@ size_t sort_temp_bytes(int64_t) { return (size_t)(kBins + kScanBlocks) * sizeof(
 // instance at the end of the coordinate-descent kernel, whose return value is the instance's rank
 // inside its bin.  Spread over that kernel's run time the atomics cost nothing, whereas two separate
 // passes of 262 144 atomics piling up on about a thousand hot bins took 64 us + 66 us.
+// After order_finish: the number of queue entries above the lowest 128 bins, i.e. where the class
+// of instances that need no projected-gradient phase begins (see lane_cd_kernel).
+const uint32_t* order_queue_len(const void* temp) { return (const uint32_t*)temp + 127; }
+
 hipError_t order_begin(void* temp, hipStream_t s) {
     return hipMemsetAsync(temp, 0, (size_t)kBins * sizeof(uint32_t), s);
 }

@@ -34,14 +34,24 @@ for s_i in range(sets):
     x0 = rng.normal(0, 0.2, (m, 2))
     targets = rng.normal(0, 0.3, (m, 1, 2)) + np.cumsum(rng.normal(0, 0.03, (m, H, 2)), axis=1)
     eps = float(10 ** rng.uniform(-4, -1.5)); cap = int(rng.choice([10000, 10000, 400, 51, 50]))
-    u0, _, it = orc.solve_general(I, H, A, B, Cc, Q, R, lo, hi, x0, targets, eps=eps, max_iter=cap, nthreads=threads)
+    # every other round of (I, H) pairs warm-starts from random controls: that is the state-returning
+    # (unfused) projected-gradient kernel, and the whole solved control sequence is compared as well
+    warm = (s_i // 10) % 2 == 1
+    cin = rng.uniform(-0.7, 0.7, (m, H, I)) if warm else None
+    u0, cout, it = orc.solve_general(I, H, A, B, Cc, Q, R, lo, hi, x0, targets, controls_in=cin, eps=eps,
+                                     max_iter=cap, nthreads=threads)
+    controls = soa(cin) if warm else None
     with MpcSolver(horizon=H, algo="lane", eps=eps, max_iter=cap) as s:
         gu0, git = s.solve_batch_general(soa(A), soa(B), soa(Cc), soa(Q), soa(R), soa(lo), soa(hi), soa(x0),
-                                         soa(targets), inputs=I, want_iters=True)
+                                         soa(targets), controls=controls, inputs=I, want_iters=True)
     g = np.ascontiguousarray(gu0.T)
-    mism = int(np.sum(np.any(g.view(np.uint64) != np.ascontiguousarray(u0).view(np.uint64), axis=1) | (git != it)))
+    diff = np.any(g.view(np.uint64) != np.ascontiguousarray(u0).view(np.uint64), axis=1) | (git != it)
+    if warm:
+        gc = np.ascontiguousarray(controls.T.reshape(m, H, I))
+        diff |= np.any((gc.view(np.uint64) != np.ascontiguousarray(cout).view(np.uint64)).reshape(m, -1), axis=1)
+    mism = int(np.sum(diff))
     bad += mism
-    print(f"set {s_i:3d} I={I} H={H:2d} n={m:5d} bounds kind {kind} eps {eps:.1e} cap {cap:5d} "
+    print(f"set {s_i:3d} I={I} H={H:2d} n={m:5d} {'warm' if warm else 'cold'} bounds kind {kind} eps {eps:.1e} cap {cap:5d} "
           f"mean iters {it.mean():7.1f} max {it.max():5d}: mismatching instances {mism}", flush=True)
 print(f"{sets} parameter sets, total mismatches {bad}")
 sys.exit(1 if bad else 0)

@@ -164,6 +164,22 @@ def test_bad_arguments(torch_cuda):
         with pytest.raises(TpcMpcError) as e:
             s.solve_batch_compact(*one)
         assert e.value.status == 4
+    # the scratch and scheduling entry points validate like the solves do
+    import ctypes as C
+    from trajectory_controller_amd import capi
+    with MpcSolver(horizon=10) as s:
+        lib, h, p = s._lib, s._h, s._params()
+        assert lib.tpc_mpc_reserve(h, C.byref(p), -1, capi.DEVICE) != capi.OK
+        assert lib.tpc_mpc_reserve(h, C.byref(p), 16, 7) != capi.OK
+        assert lib.tpc_mpc_reserve(h, None, 16, capi.DEVICE) != capi.OK
+        assert lib.tpc_mpc_reserve(h, C.byref(p), 0, capi.DEVICE) == capi.OK
+        assert lib.tpc_mpc_reserve(h, C.byref(p), 100000, capi.HOST) == capi.OK
+        hint = (C.c_int32 * 4)(1, 2, 3, 4)
+        assert lib.tpc_mpc_set_work_hint(h, hint, -1, capi.HOST) != capi.OK
+        assert lib.tpc_mpc_set_work_hint(h, hint, 4, 9) != capi.OK
+        assert lib.tpc_mpc_set_work_hint(h, hint, 4, capi.HOST) == capi.OK
+        assert lib.tpc_mpc_set_work_hint(h, None, 0, capi.HOST) == capi.OK      # clears
+        assert lib.tpc_mpc_set_work_hint(None, hint, 4, capi.HOST) != capi.OK
 
 
 # ---------------------------------------------------------------------------------------------

@@ -14,6 +14,10 @@
  *     tpc_mpc_create fails with TPC_MPC_ERR_NO_DEVICE.
  *   - a handle is not thread-safe; distinct handles are independent.  The library never keeps a
  *     caller pointer past the call that received it.
+ *   - all solves of one handle share its device scratch and therefore never overlap: a solve
+ *     submitted to a different stream than the handle's previous one first makes that stream wait
+ *     for the previous solve (an event, no host synchronisation).  Batches that should run
+ *     concurrently use one handle each.
  *   - batch arrays are structure-of-arrays: component c of instance k lives at base[c*ld + k]
  *     (`ld` >= n is the leading dimension, normally n; a shard of a larger batch passes the
  *     shard's base pointer and the full batch's ld).  Element type is `dtype` (double or float).
@@ -28,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TPC_MPC_ABI_VERSION 1
+#define TPC_MPC_ABI_VERSION 2
 
 typedef struct tpc_mpc_context* tpc_mpc_handle;
 
@@ -41,7 +45,8 @@ typedef enum tpc_mpc_status {
     TPC_MPC_ERR_BAD_EPS = 5,        /* eps <= 0                    (mpc.h:202 set_epsilon)      */
     TPC_MPC_ERR_NO_DEVICE = 6,      /* no gfx950 GPU / HIP runtime unusable                     */
     TPC_MPC_ERR_HIP = 7,            /* a HIP call failed; text in tpc_mpc_last_error            */
-    TPC_MPC_ERR_ALLOC = 8
+    TPC_MPC_ERR_ALLOC = 8,          /* host or device memory exhausted                          */
+    TPC_MPC_ERR_COMM = 9            /* RCCL missing or an RCCL call failed (sharded solves)     */
 } tpc_mpc_status;
 
 typedef enum tpc_mpc_dtype { TPC_MPC_F64 = 0, TPC_MPC_F32 = 1 } tpc_mpc_dtype;
@@ -107,6 +112,9 @@ const char* tpc_mpc_last_error(tpc_mpc_handle h);
 /* Writes up to `cap` supported horizons, returns how many exist. */
 int tpc_mpc_supported_horizons(int* out, int cap);
 int tpc_mpc_abi_version(void);
+/* How this binary was made: ABI version, target, and the LLVM machine scheduler each per-horizon
+ * kernel unit was compiled with (csrc/Makefile).  Static text, valid for the process lifetime. */
+const char* tpc_mpc_build_info(void);
 
 /* ---- the call being replaced ------------------------------------------------------------------ */
 
@@ -116,9 +124,20 @@ int tpc_mpc_abi_version(void);
  * (include/trajectory_point_follower.h:44, src/trajectory_point_follower.cpp:301-389): builds
  * A=[1,Tv;0,1], B=[0,Tv;Tv/l,-Tv/l], C=0, Q, R from `p`, a fresh controller, one target
  * (delta_y, delta_phi) for all steps, x0 = 0, cold start, and returns u0.  `v` is the speed AFTER
- * the module's velocity lookup (src/...follower.cpp:323).  One instance on the GPU (WAVE kernel). */
+ * the module's velocity lookup (src/...follower.cpp:323).  One instance on the GPU (WAVE kernel),
+ * served by a resident wavefront that takes requests through pinned host memory (see
+ * tpc_mpc_set_resident), so the call costs no kernel launch and no synchronisation call. */
 int tpc_mpc_solve_one(tpc_mpc_handle h, const tpc_mpc_params* p, double v, double delta_y,
                       double delta_phi, double* steering_front, double* steering_rear);
+
+/* No reference counterpart.  tpc_mpc_solve_one keeps one wavefront resident on the GPU between
+ * calls (fp64, horizons with 2*N <= 64, algo AUTO or WAVE; other requests take an ordinary launch).
+ * The wavefront leaves by itself `idle_timeout_us` after its last request (default 20 000) and is
+ * started again by the next call; tpc_mpc_destroy stops it.  While it is resident a device-wide
+ * synchronisation elsewhere in the process (hipDeviceSynchronize, hipFree) waits for it, i.e. up to
+ * the idle timeout.  idle_timeout_us <= 0 turns the resident mode off: every solve_one is then one
+ * kernel launch. */
+int tpc_mpc_set_resident(tpc_mpc_handle h, int64_t idle_timeout_us);
 
 /* The same computation for n independent instances in one launch.  Arrays are `p->dtype`,
  * length n, in `mem`.  `iters` (int32, optional) receives each instance's iteration count,
@@ -129,6 +148,17 @@ int tpc_mpc_solve_batch_compact(tpc_mpc_handle h, const tpc_mpc_params* p, int64
                                 const void* v, const void* delta_y, const void* delta_phi,
                                 void* steering_front, void* steering_rear, int32_t* iters,
                                 uint32_t* flags_out, int mem, void* stream);
+
+/* Mixed-horizon batch (BASELINE.json config 5): instance k is solved with horizon horizons[k]
+ * (int32, in `mem` like the other arrays); p->horizon is ignored.  The batch is binned by horizon on
+ * the device, every bin runs its horizon's kernels, and the outputs come back in the caller's
+ * order.  A horizon outside tpc_mpc_supported_horizons() anywhere in the batch fails the call with
+ * TPC_MPC_ERR_BAD_HORIZON before anything is solved.  Unlike tpc_mpc_solve_batch_compact this call
+ * synchronises `stream` once internally (the bin sizes decide the launches). */
+int tpc_mpc_solve_batch_compact_mixed(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n,
+                                      const int32_t* horizons, const void* v, const void* delta_y,
+                                      const void* delta_phi, void* steering_front, void* steering_rear,
+                                      int32_t* iters, uint32_t* flags_out, int mem, void* stream);
 
 /* ---- the general dlib::mpc<2,I,H> surface ------------------------------------------------------- */
 
@@ -198,6 +228,52 @@ int tpc_mpc_follow_batch(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mp
                          double* steering_front, double* steering_rear, float* target_speed,
                          float* target_distance, int32_t* iters, uint32_t* flags_out, void* stream);
 
+/* The same with ONE TRAJECTORY POINT PER HORIZON STEP: step t of the horizon gets the target
+ * (position.y, atan2(directory)) of the polyline point at arc length look_ahead + t * spacing, fed
+ * through dlib::mpc::set_target(val, t) semantics (mpc.h:142-155) to the general-form solver; the
+ * model, weights and bounds are the compact ones (p).  spacing = step_spacing[k] (float, optional) or,
+ * when NULL, |v| * step_size -- the distance driven per step.  Step 0 is tpc_mpc_follow_batch's point,
+ * so target_speed / target_distance and the crossing rule are the same; with spacing 0 the whole
+ * call equals tpc_mpc_follow_batch.  targets_out (optional, double, SoA [2N][n]) receives the targets
+ * used.  The reference module itself sets one target for all steps (src/...follower.cpp:368-371):
+ * this is the SURVEY.md 8f-1 extension, its geometry "parity unpinned" like tpc_mpc_follow_batch's. */
+int tpc_mpc_follow_batch_horizon(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mpc_trajectories* t,
+                                 const float* step_spacing, const float* lookup_x, const float* lookup_y,
+                                 int32_t lookup_n, double* steering_front, double* steering_rear,
+                                 float* target_speed, float* target_distance, double* targets_out,
+                                 int32_t* iters, uint32_t* flags_out, void* stream);
+
+/* ---- sharding a batch over the GPUs of a node ---------------------------------------------------- */
+
+/* No reference counterpart (the reference solves one problem per cycle on one CPU thread).  Instances
+ * are independent, so a batch shards over GPUs with no exchange during the solve; the one collective
+ * is an all-gather of the control outputs over RCCL/xGMI.  One handle per GPU; the handles of a job
+ * (one per process, or several in one process) form a communicator the NCCL way: rank 0 obtains an
+ * id, the host distributes it, every rank calls tpc_mpc_comm_init_rank.  A handle without a
+ * communicator is a world of one.  RCCL is loaded on first use (dlopen); TPC_MPC_ERR_COMM if absent. */
+#define TPC_MPC_COMM_ID_BYTES 128
+int tpc_mpc_comm_unique_id(void* id, size_t len);
+int tpc_mpc_comm_init_rank(tpc_mpc_handle h, const void* id, size_t len, int rank, int world);
+int tpc_mpc_comm_destroy(tpc_mpc_handle h);
+/* ncclGroupStart / ncclGroupEnd: a single thread that drives several handles brackets its
+ * tpc_mpc_comm_init_rank calls, and each round of tpc_mpc_solve_batch_compact_sharded calls, with these. */
+int tpc_mpc_group_begin(void);
+int tpc_mpc_group_end(void);
+/* The contiguous block of a batch of n_total that `rank` of `world` owns (blocks differ by <= 1). */
+int tpc_mpc_shard_range(int64_t n_total, int rank, int world, int64_t* first, int64_t* count);
+
+/* tpc_mpc_solve_batch_compact for this rank's block of a batch of n_total, then the all-gather:
+ * v/delta_y/delta_phi_shard hold the block's `count` instances, steering_front_all / _rear_all are
+ * FULL-size arrays [n_total]; the block is solved straight into its slot [first, first+count) and the
+ * slots are exchanged in place (ncclAllGather when n_total divides evenly, otherwise one in-place
+ * ncclBroadcast per owner inside one group), so on return -- in stream order -- every GPU holds all
+ * control outputs.  DEVICE memory only; iters_shard [count] and flags_out cover this rank's block. */
+int tpc_mpc_solve_batch_compact_sharded(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n_total,
+                                        const void* v_shard, const void* delta_y_shard,
+                                        const void* delta_phi_shard, void* steering_front_all,
+                                        void* steering_rear_all, int32_t* iters_shard,
+                                        uint32_t* flags_out, void* stream);
+
 /* ---- memory ------------------------------------------------------------------------------------ */
 
 /* No reference counterpart.  A handle grows its device scratch on demand, and growing frees and
@@ -209,7 +285,7 @@ int tpc_mpc_reserve(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n, int me
 
 /* ---- scheduling hint --------------------------------------------------------------------------- */
 
-/* No reference counterpart (one controller solves one problem per cycle there).  Instances of a
+/* EXPERIMENTAL; no reference counterpart (one controller solves one problem per cycle there).  Instances of a
  * batch need between a few and several thousand iterations (mpc.h:271, :310), and the batch
  * finishes when its slowest lane does, so the LANE kernels start the instances expected to run
  * longest first.  Their own estimate is dlib's lambda (mpc.h:116-123) with a correction where it
@@ -219,8 +295,8 @@ int tpc_mpc_reserve(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n, int me
  * since moved by as little as 0.5 % of their range are no better than the built-in order at N=20,
  * because the count is a ragged function of the inputs).  The hint applies to the NEXT
  * tpc_mpc_solve_batch_compact / tpc_mpc_solve_batch_general call on this handle if that call has
- * the same n, and is forgotten afterwards; DEVICE hints are read by that call and must stay valid
- * until it has run; hint = NULL clears.  It only decides which lane solves which instance when:
+ * the same n, and is forgotten afterwards; the hint is copied into the handle by this call (the
+ * caller's array is not referenced afterwards); hint = NULL clears.  It only decides which lane solves which instance when:
  * outputs, iteration counts and flags are bit-for-bit the same with any hint. */
 int tpc_mpc_set_work_hint(tpc_mpc_handle h, const int32_t* hint, int64_t n, int mem);
 
@@ -235,7 +311,7 @@ int tpc_mpc_set_work_hint(tpc_mpc_handle h, const int32_t* hint, int64_t n, int 
 int tpc_mpc_set_profiling(tpc_mpc_handle h, int enable);
 int tpc_mpc_last_kernel_times(tpc_mpc_handle h, double* first_ms, double* second_ms, int* algo);
 
-/* Occupancy statistics of the last LANE solve (synchronises the device): loop iterations executed
+/* Occupancy statistics of the last LANE solve (waits for that solve): loop iterations executed
  * by all persistent wavefronts of the projected-gradient kernel, and refill blocks executed.
  * lane utilisation = sum of per-instance PG iterations / (64 * wave_iterations). */
 int tpc_mpc_last_lane_stats(tpc_mpc_handle h, uint64_t* wave_iterations, uint64_t* refill_blocks);

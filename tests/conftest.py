@@ -21,17 +21,33 @@ def load_golden(name):
         return {k: z[k] for k in z.files}
 
 
-def bits_equal(a, b):
-    """Bit-for-bit equality of fp64 arrays, treating NaN == NaN and +0 == -0."""
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
-    return a.shape == b.shape and bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+def bits_equal(a, b, dtype=np.float64):
+    """Bit-for-bit equality of floating-point arrays: the IEEE bit patterns are compared (so +0 and
+    -0 differ), except that any NaN equals any NaN (a NaN's payload and sign are not part of the
+    result the reference defines)."""
+    a = np.ascontiguousarray(a, dtype=dtype)
+    b = np.ascontiguousarray(b, dtype=dtype)
+    if a.shape != b.shape:
+        return False
+    iv = np.uint64 if np.dtype(dtype).itemsize == 8 else np.uint32
+    return bool(np.all((a.view(iv) == b.view(iv)) | (np.isnan(a) & np.isnan(b))))
+
+
+def bits_equal32(a, b):
+    return bits_equal(a, b, dtype=np.float32)
 
 
 @pytest.fixture(scope="session")
 def oracle():
     from oracle.bindings import Oracle
     return Oracle()
+
+
+@pytest.fixture(scope="session")
+def oracle32():
+    """The restatement typed float (oracle/liboracle_mpc_f32.so): checker of the fp32 kernels."""
+    from oracle.bindings import Oracle
+    return Oracle("f32")
 
 
 @pytest.fixture(scope="session")

@@ -37,7 +37,7 @@ def test_compact_edge_cases(oracle, H):
 
 
 @pytest.mark.parametrize("I", [1, 2])
-@pytest.mark.parametrize("H", [5, 10, 20])
+@pytest.mark.parametrize("H", [4, 5, 10, 20, 30, 40])
 def test_general_bit_exact(oracle, I, H):
     g = load_golden(f"general_I{I}_H{H}.npz")
     u0, controls, it = oracle.solve_general(I, H, g["A"], g["B"], g["C"], g["Q"], g["R"], g["lo"],
@@ -104,6 +104,31 @@ def test_rollout_i2(oracle):
     c, s, it = oracle.rollout(2, 10, int(g["steps"]), g["A"], g["B"], g["C"], g["Q"], g["R"],
                               g["lo"], g["hi"], g["x0"], g["targets0"], g["new_last_targets"])
     assert bits_equal(c, g["controls"]) and bits_equal(s, g["states"])
+
+
+@pytest.mark.parametrize("I", [1, 2])
+@pytest.mark.parametrize("H", [4, 5, 10, 20, 30, 40])
+def test_rollout8_bit_exact(oracle, I, H):
+    """8 controllers x 5 warm-started steps per horizon, from real dlib (make_golden_r02.py)."""
+    g = load_golden(f"rollout8_I{I}_H{H}.npz")
+    steps = int(g["steps"])
+    for k in range(g["A"].shape[0]):
+        c, s, _ = oracle.rollout(I, H, steps, g["A"][k], g["B"][k], g["C"][k], g["Q"][k], g["R"][k],
+                                 g["lo"][k], g["hi"][k], g["x0"][k], g["targets"][k], g["new_last_targets"][k])
+        assert bits_equal(c, g["controls"][k]) and bits_equal(s, g["states"][k]), k
+
+
+def test_float_oracle_tracks_the_pinned_one(oracle, oracle32):
+    """The float-typed build of the same source is deterministic and stays close to the fp64 result
+    (it is the checker of the fp32 kernels; dlib has no fp32 form to pin it to)."""
+    from trajectory_controller_amd.synth import compact_inputs
+    v, dy, dphi = compact_inputs(10, 512, first=31337)
+    f64, r64, _ = oracle.solve_compact(10, v, dy, dphi)
+    f32, r32, it32 = oracle32.solve_compact(10, v, dy, dphi)
+    f32b, r32b, it32b = oracle32.solve_compact(10, v, dy, dphi, nthreads=4)
+    assert f32.dtype == np.float32 and np.array_equal(f32, f32b) and np.array_equal(it32, it32b)
+    err = np.maximum(np.abs(f32 - f64), np.abs(r32 - r64))
+    assert np.median(err) < 1e-4 and err.max() < 0.1
 
 
 def test_oracle_vs_live_dlib(oracle, dlibref):

@@ -8,13 +8,16 @@ Tolerances (stated once, used below):
                        dlib's own operation sequence.
   WAVE kernel,  fp64 : |du| <= 1e-9 absolute (=> <= 1e-6 relative for every |u| >= 1e-3; bounds are
                        +-0.384) and identical iteration counts; observed ~1e-11.
-  fp32 (either)      : a throughput / tolerance-sweep mode, not a parity mode (SURVEY.md section 0
+  LANE kernels, fp32 : bit-exact against the SAME restatement compiled with every value typed
+                       float (oracle/liboracle_mpc_f32.so) and identical iteration counts.  dlib has
+                       no fp32 form, so this checks "dlib's operation sequence in fp32", nothing more.
+  fp32 vs fp64       : a throughput / tolerance-sweep mode, not a parity mode (SURVEY.md section 0
                        fact 3): only loose sanity bounds are asserted, the histogram is reported.
 """
 import numpy as np
 import pytest
 
-from conftest import bits_equal, load_golden
+from conftest import bits_equal, bits_equal32, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -186,9 +189,13 @@ def test_bad_arguments(torch_cuda):
 # general dlib::mpc<2,I,H> surface
 
 @pytest.mark.parametrize("I", [1, 2])
-@pytest.mark.parametrize("H", [5, 10, 20])
+@pytest.mark.parametrize("H", [4, 5, 10, 20, 30, 40])
 @pytest.mark.parametrize("algo", ["lane", "wave"])
 def test_general_golden(torch_cuda, I, H, algo):
+    """Real-dlib fixtures for every horizon the library ships (cold start: the fused LANE kernels,
+    and every WAVE shape up to the 60-lane I = 2, H = 30 one)."""
+    if algo == "wave" and I * H > 64:
+        pytest.skip("WAVE kernel covers inputs*horizon <= 64")
     torch = torch_cuda
     g = load_golden(f"general_I{I}_H{H}.npz")
     names = ["A", "B", "C", "Q", "R", "lo", "hi", "x0", "targets"]
@@ -566,3 +573,109 @@ def test_general_invalid_models_are_flagged(torch_cuda, oracle, algo):
         assert bits_equal(gu0.T[good], u0[good])
     else:
         assert np.abs(gu0.T[good] - u0[good]).max() <= WAVE_ATOL
+
+
+# ---------------------------------------------------------------------------------------------
+# every shipped kernel instantiation under an oracle / real-dlib check (round 2)
+
+ALL_H = [4, 5, 10, 20, 30, 40]
+GEN_NAMES = ["A", "B", "C", "Q", "R", "lo", "hi", "x0", "targets"]
+
+
+@pytest.mark.parametrize("I", [1, 2])
+@pytest.mark.parametrize("H", ALL_H)
+@pytest.mark.parametrize("algo", ["lane", "wave"])
+def test_rollout8_golden(torch_cuda, I, H, algo):
+    """8 controllers x 5 warm-started closed-loop steps per horizon, expected values from real dlib
+    (tests/golden/make_golden_r02.py).  tpc_mpc_rollout keeps controls and dlib's v on the device
+    between steps, i.e. this is the state-returning lane_pg_kernel at every horizon."""
+    if algo == "wave" and I * H > 64:
+        pytest.skip("WAVE kernel covers inputs*horizon <= 64")
+    g = load_golden(f"rollout8_I{I}_H{H}.npz")
+    steps, n = int(g["steps"]), g["A"].shape[0]
+    with _solver(H, algo) as s:
+        c, st, _ = s.rollout(steps, *[_soa(g[k]) for k in GEN_NAMES],
+                             new_last_targets=_soa(g["new_last_targets"]), inputs=I)
+    c = c.T.reshape(n, steps, I)
+    st = st.T.reshape(n, steps, 2)
+    if algo == "lane":
+        assert bits_equal(c, g["controls"]) and bits_equal(st, g["states"])
+    else:
+        assert np.abs(c - g["controls"]).max() <= 1e-7
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("I", [1, 2])
+@pytest.mark.parametrize("H", ALL_H)
+def test_lane_state_returning_vs_oracle(torch_cuda, oracle, oracle32, H, I, dtype):
+    """controls_inout + v_inout: the caller gets the whole controller state back, which takes the
+    unfused lane_pg_kernel (every horizon, both input counts, both dtypes).  Warm start from random
+    controls and a random v; outputs, solved sequence, v and iteration counts against the oracle of
+    the same arithmetic type, bit for bit."""
+    from trajectory_controller_amd.synth import general_inputs
+    orc, npdt, eq = (oracle, np.float64, bits_equal) if dtype == "f64" else (oracle32, np.float32, bits_equal32)
+    n = 320 if H <= 20 else 130   # not multiples of 64
+    g = {k: a.astype(npdt) for k, a in general_inputs(H, n, I=I, first=1234 + H).items()}
+    rng = np.random.default_rng(100 + H + I)
+    cin = rng.uniform(-0.3, 0.3, size=(n, H, I)).astype(npdt)
+    vin = rng.uniform(-0.3, 0.3, size=(n, H, I)).astype(npdt)
+    u0, cout, it, vout = orc.solve_general(I, H, *[g[k] for k in GEN_NAMES], controls_in=cin, v_in=vin,
+                                           want_v=True, nthreads=8)
+    controls, vstate = _soa(cin), _soa(vin)
+    with _solver(H, "lane", dtype=dtype) as s:
+        gu0, git = s.solve_batch_general(*[_soa(g[k]) for k in GEN_NAMES], controls=controls, v_state=vstate,
+                                         inputs=I, want_iters=True)
+    assert np.array_equal(git, it)
+    assert eq(gu0.T, u0)
+    assert eq(controls.T.reshape(n, H, I), cout)
+    assert eq(vstate.T.reshape(n, H, I), vout)
+
+
+@pytest.mark.parametrize("H", ALL_H)
+def test_fp32_lane_compact_bit_exact(torch_cuda, oracle32, H):
+    """The fp32 fused LANE kernels (compact form, both stop-test builds) against the float-typed
+    restatement: same bits, same iteration counts."""
+    from trajectory_controller_amd.synth import compact_inputs
+    n = 3000 if H <= 20 else 700
+    v, dy, dphi = (a.astype(np.float32) for a in compact_inputs(H, n, first=250000))
+    cases = [dict(), dict(lo=(0.0, -0.3), hi=(0.3, 0.0))]      # second: bounds touch zero -> exact stop test
+    for c in cases:
+        kw = dict(lo=c["lo"], hi=c["hi"]) if c else {}
+        of, orr, oit = oracle32.solve_compact(H, v, dy, dphi, nthreads=8, **kw)
+        over = dict(lower=c["lo"], upper=c["hi"]) if c else {}
+        with _solver(H, "lane", dtype="f32", **over) as s:
+            f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+        assert f.dtype == np.float32
+        assert np.array_equal(it, oit), c
+        assert bits_equal32(f, of) and bits_equal32(r, orr), c
+
+
+@pytest.mark.parametrize("I", [1, 2])
+@pytest.mark.parametrize("H", ALL_H)
+def test_fp32_lane_general_bit_exact(torch_cuda, oracle32, H, I):
+    """The fp32 fused LANE kernels, general form (cold start), against the float-typed restatement."""
+    from trajectory_controller_amd.synth import general_inputs
+    n = 700 if H <= 20 else 200
+    g = {k: a.astype(np.float32) for k, a in general_inputs(H, n, I=I, first=55 + H).items()}
+    u0, _, it = oracle32.solve_general(I, H, *[g[k] for k in GEN_NAMES], nthreads=8)
+    with _solver(H, "lane", dtype="f32") as s:
+        gu0, git = s.solve_batch_general(*[_soa(g[k]) for k in GEN_NAMES], inputs=I, want_iters=True)
+    assert np.array_equal(git, it)
+    assert bits_equal32(gu0.T, u0)
+
+
+def test_signed_zero_outputs(torch_cuda, oracle):
+    """bits_equal distinguishes +0 from -0.  The compact model drops products with the literal 0
+    entries of A and B (mpc_model.h), which is value-exact but could flip the sign of a zero
+    intermediate; this batch is built to produce exact zeros (zero targets, targets that cancel,
+    one variable pinned at a bound that is 0) and must still match the oracle bit for bit."""
+    H = 10
+    v = np.array([1.0, 2.0, 0.5, 1.0, 3.0, 1.0, 1.0, 2.5])
+    dy = np.array([0.0, -0.0, 0.0, 0.1, -0.1, 0.0, -0.0, 0.3])
+    dphi = np.array([0.0, 0.0, -0.0, 0.0, -0.0, 0.2, -0.2, 0.0])
+    for lo, hi in (((-0.384, -0.384), (0.384, 0.384)), ((0.0, -0.384), (0.384, 0.0)), ((-0.384, 0.0), (0.0, 0.384))):
+        of, orr, oit = oracle.solve_compact(H, v, dy, dphi, lo=lo, hi=hi)
+        with _solver(H, "lane", lower=lo, upper=hi) as s:
+            f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+        assert np.array_equal(it, oit), (lo, hi)
+        assert bits_equal(f, of) and bits_equal(r, orr), (lo, hi, f, of, r, orr)

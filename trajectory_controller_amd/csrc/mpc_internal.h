@@ -63,5 +63,52 @@ const uint32_t* order_queue_len(const void* temp);   // device word: queue entri
 hipError_t order_finish(const uint32_t* keys, const uint32_t* rank, uint32_t* order, int64_t n, void* temp,
                         hipStream_t s);
 
+// mpc_rollout.hip: what the caller of dlib::mpc does between two operator() calls of a closed loop.
+// Three leading dimensions: the handle's working set (model copy, state, targets, controls), the
+// caller's output arrays, and the caller's new_last_targets.
+struct RolloutStepArgs {
+    int64_t n, ld, ld_out, ld_nlt;
+    int I, H, step, steps;
+    const void *A, *B, *C;        // model (SoA, ld)
+    void* x;                      // [2] current state, updated in place (ld)
+    void* targets;                // [2H] shifted in place (ld)
+    const void* controls;         // [H*I] solved sequence of this step (ld)
+    const void* new_last_targets; // [steps*2] or null (ld_nlt)
+    void* controls_out;           // [steps*I] (ld_out)
+    void* states_out;             // [steps*2] or null (ld_out)
+    const int32_t* iters_step;    // [n] or null
+    int32_t* iters_out;           // [steps] or null (ld_out)
+};
+hipError_t launch_rollout_step(int dtype, const RolloutStepArgs& a, hipStream_t s);
+
+// mpc_follow.hip: batched front and back ends of the tobiMPC branch of cycle().
+struct FollowArgs {
+    int64_t n, ld;
+    int max_points;
+    const float *px, *py, *dx, *dy, *vel;   // [max_points][ld]
+    const int32_t* count;                   // [n]
+    const float* car_velocity;              // [n]
+    const float* look_ahead;                // [n]
+    const float *lut_x, *lut_y;             // velocity lookup (ascending x), may be null
+    int lut_n;
+    double *v_out, *ysoll_out, *phisoll_out;   // [n] -> inputs of the compact solve
+    float *target_speed, *target_distance;     // [n]
+};
+hipError_t launch_traj_point(const FollowArgs& a, hipStream_t s);
+// ... one trajectory point per horizon step (tpc_mpc_follow_batch_horizon): the kernel writes a whole
+// general-form batch -- the compact model spelled out as A, B, C, Q, R, bounds, x0 = 0 -- plus
+// targets[2H], all SoA with leading dimension ldw, for the general-form solver to consume.
+struct FollowHorizonArgs {
+    int H;
+    int64_t ldw;
+    const float* step_spacing;     // [n] arc length between consecutive horizon targets, or null: |v|*T
+    double step, wheelbase;        // T, l
+    double q[2], r[2], lo[2], hi[2];
+    double *A, *B, *C, *Q, *R, *lo_out, *hi_out, *x0, *targets;
+    double* targets_copy;          // optional [2H][ld_copy] copy of the targets for the caller
+    int64_t ld_copy;
+};
+hipError_t launch_traj_horizon(const FollowArgs& a, const FollowHorizonArgs& f, hipStream_t s);
+hipError_t launch_follow_post(int64_t n, const float* target_speed, double* front, double* rear, hipStream_t s);
 
 }  // namespace tpc

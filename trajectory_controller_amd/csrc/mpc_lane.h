@@ -162,8 +162,12 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args 
     const T eps = (T)kn.eps;
     // one instance outside the screen sends the whole batch to the exact-stop-test build of the
     // fused PG kernel (stats[2], read by both builds at launch; see lane_pg_fused_kernel)
-    if constexpr (Model::kFastStop)
-        if (!m.fast_stop_ok(mm_max, eps)) atomicOr(&stats[2], 1ull);
+    // (one atomic per wavefront at most: when the failing condition is batch-wide -- bounds that do
+    // not straddle zero, a huge eps -- every lane fails, and n atomics on one word would serialise)
+    if constexpr (Model::kFastStop) {
+        const unsigned long long failing = __ballot(!m.fast_stop_ok(mm_max, eps));
+        if (failing != 0ull && lane == __ffsll((long long)failing) - 1) atomicOr(&stats[2], 1ull);
+    }
     const uint32_t cd_iters = kn.smo_iters < kn.max_iter ? kn.smo_iters : kn.max_iter;
     uint32_t iter = 0;
     bool stopped = (Model::kScreen && nonfinite) || badmodel;   // see CompactModel::kScreen, GeneralModel::invalid

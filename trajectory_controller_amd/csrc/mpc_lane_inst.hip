@@ -17,17 +17,25 @@ constexpr int kH = TPC_LANE_H;
 // Persistent-wave count of a PG kernel: every wave must be resident at once (the queue is pulled,
 // not pushed), so the grid is what the occupancy query says the chip holds, capped by the work.
 // `block` threads per workgroup; at most 4 workgroups per CU are used (one per SIMD or SIMD pair).
-template <class Kernel>
+// The answer depends on the device (CU count), so it is cached per device ordinal, once per kernel
+// instantiation (`Tag` makes the cache unique to the call site).
+template <class Tag, class Kernel>
 inline int pg_grid(Kernel kernel, int block) {
-    int dev = 0, cus = 256, per_cu = 4;
+    constexpr int kMaxDev = 64;
+    static int cache[kMaxDev] = {0};   // 0 = not asked yet; racing first calls store the same value
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev >= 0 && dev < kMaxDev && cache[dev] > 0) return cache[dev];
+    int cus = 256, per_cu = 4;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-        cus = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess || per_cu < 1)
         per_cu = 1;
     if (per_cu > 4) per_cu = 4;
+    if (dev >= 0 && dev < kMaxDev) cache[dev] = cus * per_cu;
     return cus * per_cu;
 }
+struct TagState {}; struct TagFast {}; struct TagExact {};
 
 // The fused PG kernel publishes controls[0] only; a caller that wants the controller state back
 // (warm-start chains, tpc_mpc_rollout) gets the kernel that keeps it.
@@ -52,7 +60,7 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
     if (e != hipSuccess) return e;
     if (ws.ev) (void)hipEventRecord(ws.ev[1], s);
     if (wants_state(a)) {
-        static const int grid_cap = pg_grid(lane_pg_kernel<T, I, kH, Model, Args>, kWave);
+        const int grid_cap = pg_grid<TagState>(lane_pg_kernel<T, I, kH, Model, Args>, kWave);
         const int64_t need = (a.n + kWave - 1) / kWave;
         hipLaunchKernelGGL((lane_pg_kernel<T, I, kH, Model, Args>), dim3((unsigned)(need < grid_cap ? need : grid_cap)),
                            dim3(kWave), 0, s, a, k, (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats);
@@ -63,12 +71,12 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
         const uint32_t* queue_len = order_queue_len(ws.sort_temp);
         if constexpr (Model::kFastStop) {
             // both builds go out; the one the CD kernel's screen did not pick returns at once
-            static const int fast_cap = pg_grid(lane_pg_fused_kernel<T, I, kH, Model, Args, true>, bt);
+            const int fast_cap = pg_grid<TagFast>(lane_pg_fused_kernel<T, I, kH, Model, Args, true>, bt);
             hipLaunchKernelGGL((lane_pg_fused_kernel<T, I, kH, Model, Args, true>),
                                dim3((unsigned)(need < fast_cap ? need : fast_cap)), dim3(bt), 0, s, a, k,
                                (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats, queue_len);
         }
-        static const int grid_cap = pg_grid(lane_pg_fused_kernel<T, I, kH, Model, Args, false>, bt);
+        const int grid_cap = pg_grid<TagExact>(lane_pg_fused_kernel<T, I, kH, Model, Args, false>, bt);
         hipLaunchKernelGGL((lane_pg_fused_kernel<T, I, kH, Model, Args, false>),
                            dim3((unsigned)(need < grid_cap ? need : grid_cap)), dim3(bt), 0, s, a, k,
                            (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats, queue_len);
@@ -82,6 +90,13 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
 
 #define TPC_CAT2(a, b) a##b
 #define TPC_CAT(a, b) TPC_CAT2(a, b)
+
+// Which LLVM machine scheduler built this translation unit (csrc/Makefile passes it): readable
+// through tpc_mpc_build_info(), so a shipped object says how it was made.
+#ifndef TPC_SCHED_NAME
+#define TPC_SCHED_NAME "default"
+#endif
+const char* TPC_CAT(lane_build_h, TPC_LANE_H)() { return "sched=" TPC_SCHED_NAME; }
 
 int64_t TPC_CAT(lane_rec_len_h, TPC_LANE_H)(int dtype) {
     return dtype == 0 ? LaneRec<double, kH>::kLen : LaneRec<float, kH>::kLen;

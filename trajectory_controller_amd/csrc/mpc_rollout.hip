@@ -6,20 +6,6 @@
 
 namespace tpc {
 
-struct RolloutStepArgs {
-    int64_t n, ld;
-    int I, H, step, steps;
-    const void *A, *B, *C;        // model (SoA, ld)
-    void* x;                      // [2] current state, updated in place
-    void* targets;                // [2H] shifted in place
-    const void* controls;         // [H*I] solved sequence of this step
-    const void* new_last_targets; // [steps*2] or null
-    void* controls_out;           // [steps*I]
-    void* states_out;             // [steps*2] or null
-    const int32_t* iters_step;    // [n] or null
-    int32_t* iters_out;           // [steps] or null
-};
-
 template <typename T>
 __global__ void rollout_step_kernel(RolloutStepArgs a) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -37,12 +23,13 @@ __global__ void rollout_step_kernel(RolloutStepArgs a) {
     const T n0 = ((A[0] * x0 + A[ld] * x1) + bu0) + Cc[0];
     const T n1 = ((A[2 * ld] * x0 + A[3 * ld] * x1) + bu1) + Cc[ld];
     x[0] = n0; x[ld] = n1;
-    for (int j = 0; j < a.I; ++j) ((T*)a.controls_out)[(int64_t)(a.step * a.I + j) * ld + k] = u[(int64_t)j * ld];
+    const int64_t lo = a.ld_out;
+    for (int j = 0; j < a.I; ++j) ((T*)a.controls_out)[((int64_t)a.step * a.I + j) * lo + k] = u[(int64_t)j * ld];
     if (a.states_out) {
-        ((T*)a.states_out)[(int64_t)(a.step * 2) * ld + k] = n0;
-        ((T*)a.states_out)[(int64_t)(a.step * 2 + 1) * ld + k] = n1;
+        ((T*)a.states_out)[((int64_t)a.step * 2) * lo + k] = n0;
+        ((T*)a.states_out)[((int64_t)a.step * 2 + 1) * lo + k] = n1;
     }
-    if (a.iters_out && a.iters_step) a.iters_out[(int64_t)a.step * ld + k] = a.iters_step[k];
+    if (a.iters_out && a.iters_step) a.iters_out[(int64_t)a.step * lo + k] = a.iters_step[k];
     // operator()'s target shift (mpc.h:236-237), then the caller's set_last_target for the next call
     T* t = (T*)a.targets + k;
     for (int i = 1; i < a.H; ++i) {
@@ -51,8 +38,8 @@ __global__ void rollout_step_kernel(RolloutStepArgs a) {
     }
     if (a.new_last_targets && a.step + 1 < a.steps) {
         const T* nl = (const T*)a.new_last_targets + k;
-        t[(int64_t)(2 * (a.H - 1)) * ld] = nl[(int64_t)(2 * (a.step + 1)) * ld];
-        t[(int64_t)(2 * (a.H - 1) + 1) * ld] = nl[(int64_t)(2 * (a.step + 1) + 1) * ld];
+        t[(int64_t)(2 * (a.H - 1)) * ld] = nl[(2 * ((int64_t)a.step + 1)) * a.ld_nlt];
+        t[(int64_t)(2 * (a.H - 1) + 1) * ld] = nl[(2 * ((int64_t)a.step + 1) + 1) * a.ld_nlt];
     }
 }
 

@@ -112,14 +112,14 @@ TPC_DEV void hessian_row(const Model& m, bool active, int qi, int qj, T* row) {
     }
 }
 
+// One instance solved by the calling wavefront (all 64 lanes must call it together; the workgroup
+// must be that one wavefront, because the control exchange uses __syncthreads as its wait).
+// s_u: I*H + 2 values, s_w: 2*H values of LDS, both 16-byte aligned.
 template <typename T, int I, int H, class Model, class Args>
-__global__ __launch_bounds__(64) void wave_kernel(Args g, Knobs kn) {
+TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_u, T* s_w) {
     constexpr int N = I * H;
     static_assert(N <= kWave, "WAVE kernel: one variable per lane");
-    __shared__ __attribute__((aligned(16))) T s_u[N + 2];
-    __shared__ __attribute__((aligned(16))) T s_w[2 * H];
     const int lane = threadIdx.x;
-    const int64_t k = blockIdx.x;
     const bool active = lane < N;
     const int qi = active ? lane / I : 0, qj = active ? lane % I : 0;
     const int slot = 2 * qi + qj;
@@ -202,6 +202,13 @@ __global__ __launch_bounds__(64) void wave_kernel(Args g, Knobs kn) {
         if (capped) f |= 0x2u;
         if (f) atomicOr(g.flags, f);
     }
+}
+
+template <typename T, int I, int H, class Model, class Args>
+__global__ __launch_bounds__(64) void wave_kernel(Args g, Knobs kn) {
+    __shared__ __attribute__((aligned(16))) T s_u[I * H + 2];
+    __shared__ __attribute__((aligned(16))) T s_w[2 * H];
+    wave_solve<T, I, H, Model, Args>(g, kn, (int64_t)blockIdx.x, s_u, s_w);
 }
 
 }  // namespace tpc

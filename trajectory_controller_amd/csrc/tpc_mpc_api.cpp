@@ -1,20 +1,11 @@
 // C ABI of libtpc_mpc.so (include/tpc_mpc.h): argument validation, host<->device staging, kernel
 // family selection.  No solver arithmetic lives here and there is no CPU solve path: every entry
-// point ends in a gfx950 kernel launch or fails.
-#include "../../include/tpc_mpc.h"
-
-#include <hip/hip_runtime.h>
+// point ends in a gfx950 kernel launch or fails.  (Mixed-horizon batches: tpc_mpc_mixed.hip; sharded
+// solves over RCCL: tpc_mpc_comm.cpp; the resident single-solve kernel: tpc_mpc_one.hip.)
+#include "tpc_mpc_context.h"
 
 #include <cmath>
-#include <cstdio>
-#include <chrono>
 #include <cstdlib>
-#include <cstring>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "mpc_internal.h"
 
 namespace tpc {
 // per-horizon launchers, one translation unit each (mpc_lane_inst.hip / mpc_wave_inst.hip)
@@ -23,138 +14,23 @@ namespace tpc {
     hipError_t lane_general_h##h(int, int, const GeneralArgs&, const Knobs&, const Workspace&, hipStream_t); \
     hipError_t wave_compact_h##h(int, const CompactArgs&, const Knobs&, const Workspace&, hipStream_t); \
     hipError_t wave_general_h##h(int, int, const GeneralArgs&, const Knobs&, const Workspace&, hipStream_t); \
-    int64_t lane_rec_len_h##h(int dtype);
+    int64_t lane_rec_len_h##h(int dtype);                                                          \
+    const char* lane_build_h##h();
 TPC_DECL_H(4) TPC_DECL_H(5) TPC_DECL_H(10) TPC_DECL_H(20) TPC_DECL_H(30) TPC_DECL_H(40)
 #undef TPC_DECL_H
-}  // namespace tpc
 
-namespace tpc {
-struct RolloutStepArgs {
-    int64_t n, ld;
-    int I, H, step, steps;
-    const void *A, *B, *C;
-    void* x;
-    void* targets;
-    const void* controls;
-    const void* new_last_targets;
-    void* controls_out;
-    void* states_out;
-    const int32_t* iters_step;
-    int32_t* iters_out;
-};
-hipError_t launch_rollout_step(int dtype, const RolloutStepArgs& a, hipStream_t s);
-
-struct FollowArgs {
-    int64_t n, ld;
-    int max_points;
-    const float *px, *py, *dx, *dy, *vel;
-    const int32_t* count;
-    const float* car_velocity;
-    const float* look_ahead;
-    const float *lut_x, *lut_y;
-    int lut_n;
-    double *v_out, *ysoll_out, *phisoll_out;
-    float *target_speed, *target_distance;
-};
-hipError_t launch_traj_point(const FollowArgs& a, hipStream_t s);
-hipError_t launch_follow_post(int64_t n, const float* target_speed, double* front, double* rear, hipStream_t s);
+thread_local char g_create_error[kTpcErrLen] = "";
 }  // namespace tpc
 
 using namespace tpc;
 
 static const int kHorizons[] = {4, 5, 10, 20, 30, 40};
-static std::string g_create_error;
-
-struct tpc_mpc_context {
-    int device = 0;
-    int cu_count = 0;
-    std::string err;
-    // device scratch (grown on demand, never shrunk)
-    void* ws_state = nullptr;
-    int64_t ws_bytes = 0;
-    uint32_t* ws_words = nullptr;   // [0] ticket, [1] flags
-    // staging for TPC_MPC_HOST batches
-    void* stage = nullptr;
-    int64_t stage_bytes = 0;
-    // rollout working set (state, targets, controller memory, per-step iteration counts)
-    void* roll = nullptr;
-    int64_t roll_bytes = 0;
-    // 64 B of pinned host memory mapped into the device: solve_one's three inputs and two outputs
-    // travel through it, so a single solve costs one kernel launch and one sync, no memcpy calls
-    void* pin_host = nullptr;
-    void* pin_dev = nullptr;
-    // queue-order hint for the next batch solve (tpc_mpc_set_work_hint): the caller's device array,
-    // or our device copy of a host array
-    const int32_t* hint = nullptr;
-    int64_t hint_n = 0;
-    void* hint_own = nullptr;
-    int64_t hint_own_bytes = 0;
-    // solve_one has no flags output: it skips the flag word's memset and the kernels' atomicOr
-    bool collect_flags = true;
-    // optional kernel timing (tpc_mpc_set_profiling)
-    bool profiling = false;
-    bool ev_valid = false;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    int last_algo = 0;
-};
 
 namespace {
-
-int fail(tpc_mpc_context* h, int code, const std::string& msg) {
-    if (h) h->err = msg; else g_create_error = msg;
-    return code;
-}
-int hip_fail(tpc_mpc_context* h, hipError_t e, const char* what) {
-    return fail(h, TPC_MPC_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
-}
-#define HIP_TRY(h, call)                                         \
-    do {                                                         \
-        hipError_t e__ = (call);                                 \
-        if (e__ != hipSuccess) return hip_fail(h, e__, #call);   \
-    } while (0)
 
 bool horizon_ok(int H) {
     for (int h : kHorizons) if (h == H) return true;
     return false;
-}
-size_t esize(int dtype) { return dtype == TPC_MPC_F64 ? 8 : 4; }
-
-int check_common(tpc_mpc_context* h, const tpc_mpc_params* p) {
-    if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
-    if (!p) return fail(h, TPC_MPC_ERR_BAD_ARG, "null params");
-    if (!horizon_ok(p->horizon))
-        return fail(h, TPC_MPC_ERR_BAD_HORIZON, "unsupported horizon " + std::to_string(p->horizon) +
-                                                    " (supported: 4 5 10 20 30 40)");
-    if (p->dtype != TPC_MPC_F64 && p->dtype != TPC_MPC_F32) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad dtype");
-    if (p->algo < TPC_MPC_ALGO_AUTO || p->algo > TPC_MPC_ALGO_LANE) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad algo");
-    if (!(p->eps > 0)) return fail(h, TPC_MPC_ERR_BAD_EPS, "eps must be > 0 (mpc.h:202)");
-    if (p->max_iter > 0x7fffffffull || p->smo_iters > 0x7fffffffull)
-        return fail(h, TPC_MPC_ERR_BAD_ARG, "max_iter / smo_iters must fit in 31 bits");
-    return TPC_MPC_OK;
-}
-
-// mpc_abstract.h:90-97: min(Q) >= 0, min(R) > 0, min(upper-lower) >= 0
-int check_compact_model(tpc_mpc_context* h, const tpc_mpc_params* p) {
-    if (!(p->weight_y >= 0) || !(p->weight_phi >= 0))
-        return fail(h, TPC_MPC_ERR_BAD_WEIGHTS, "min(Q) >= 0 violated (mpc_abstract.h:90-97)");
-    if (!(p->weight_steering_front > 0) || !(p->weight_steering_rear > 0))
-        return fail(h, TPC_MPC_ERR_BAD_WEIGHTS, "min(R) > 0 violated (mpc_abstract.h:90-97)");
-    for (int j = 0; j < 2; ++j)
-        if (!(p->upper[j] >= p->lower[j]))
-            return fail(h, TPC_MPC_ERR_BAD_BOUNDS, "upper >= lower violated (mpc_abstract.h:90-97)");
-    if (!std::isfinite(p->step_size) || !std::isfinite(p->wheelbase) || p->wheelbase == 0)
-        return fail(h, TPC_MPC_ERR_BAD_ARG, "step_size / wheelbase must be finite, wheelbase != 0");
-    return TPC_MPC_OK;
-}
-
-int ensure(tpc_mpc_context* h, void** buf, int64_t* have, int64_t need) {
-    if (need <= *have) return TPC_MPC_OK;
-    if (*buf) { hipError_t e = hipFree(*buf); *buf = nullptr; *have = 0; if (e != hipSuccess) return hip_fail(h, e, "hipFree"); }
-    const int64_t grow = need + need / 4 + 4096;
-    hipError_t e = hipMalloc(buf, (size_t)grow);
-    if (e != hipSuccess) return fail(h, TPC_MPC_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
-    *have = grow;
-    return TPC_MPC_OK;
 }
 
 Knobs knobs_of(const tpc_mpc_params* p) {
@@ -231,11 +107,10 @@ int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n,
     ws->sort_temp_bytes = 0;
     if (algo == TPC_MPC_ALGO_LANE) {
         // records | keys | rank | order | counting-sort bins
-        auto pad = [](int64_t b) { return (b + 255) / 256 * 256; };
-        const int64_t rec_b = pad(lane_rec_len(H, dtype) * (int64_t)esize(dtype) * n);
-        const int64_t col_b = pad(n * 4);
+        const int64_t rec_b = pad256(lane_rec_len(H, dtype) * (int64_t)esize(dtype) * n);
+        const int64_t col_b = pad256(n * 4);
         const size_t tmp_b = sort_temp_bytes(n);
-        int rc = ensure(h, &h->ws_state, &h->ws_bytes, rec_b + 3 * col_b + pad((int64_t)tmp_b));
+        int rc = ensure(h, &h->ws_state, &h->ws_bytes, rec_b + 3 * col_b + pad256((int64_t)tmp_b));
         if (rc) return rc;
         char* b = (char*)h->ws_state;
         ws->state = b;
@@ -249,6 +124,69 @@ int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n,
     return TPC_MPC_OK;
 }
 
+// Copy `rows` rows of `width` bytes between arrays of different leading dimensions (pitches in bytes).
+hipError_t copy_rows(void* dst, int64_t dpitch, const void* src, int64_t spitch, int64_t width, int64_t rows,
+                     hipMemcpyKind kind, hipStream_t s) {
+    if (rows <= 0 || width <= 0) return hipSuccess;
+    if (dpitch == width && spitch == width) return hipMemcpyAsync(dst, src, (size_t)(width * rows), kind, s);
+    return hipMemcpy2DAsync(dst, (size_t)dpitch, src, (size_t)spitch, (size_t)width, (size_t)rows, kind, s);
+}
+
+int check_general_io(tpc_mpc_context* h, const tpc_mpc_general_io* io, int mem) {
+    if (!io) return fail(h, TPC_MPC_ERR_BAD_ARG, "null io");
+    if (io->inputs != 1 && io->inputs != 2) return fail(h, TPC_MPC_ERR_BAD_ARG, "inputs must be 1 or 2");
+    if (io->n < 0 || io->ld < io->n || io->n > 0x7fffffffll)
+        return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= n <= ld, n < 2^31");
+    if (mem != TPC_MPC_HOST && mem != TPC_MPC_DEVICE) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad memory kind");
+    return TPC_MPC_OK;
+}
+
+}  // namespace
+
+namespace tpc {
+
+int check_common(tpc_mpc_context* h, const tpc_mpc_params* p) {
+    if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+    if (!p) return fail(h, TPC_MPC_ERR_BAD_ARG, "null params");
+    if (!horizon_ok(p->horizon))
+        return fail(h, TPC_MPC_ERR_BAD_HORIZON, "unsupported horizon %d (supported: 4 5 10 20 30 40)", p->horizon);
+    if (p->dtype != TPC_MPC_F64 && p->dtype != TPC_MPC_F32) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad dtype");
+    if (p->algo < TPC_MPC_ALGO_AUTO || p->algo > TPC_MPC_ALGO_LANE) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad algo");
+    if (!(p->eps > 0)) return fail(h, TPC_MPC_ERR_BAD_EPS, "eps must be > 0 (mpc.h:202)");
+    if (p->max_iter > 0x7fffffffull || p->smo_iters > 0x7fffffffull)
+        return fail(h, TPC_MPC_ERR_BAD_ARG, "max_iter / smo_iters must fit in 31 bits");
+    return TPC_MPC_OK;
+}
+
+// mpc_abstract.h:90-97: min(Q) >= 0, min(R) > 0, min(upper-lower) >= 0
+int check_compact_model(tpc_mpc_context* h, const tpc_mpc_params* p) {
+    if (!(p->weight_y >= 0) || !(p->weight_phi >= 0))
+        return fail(h, TPC_MPC_ERR_BAD_WEIGHTS, "min(Q) >= 0 violated (mpc_abstract.h:90-97)");
+    if (!(p->weight_steering_front > 0) || !(p->weight_steering_rear > 0))
+        return fail(h, TPC_MPC_ERR_BAD_WEIGHTS, "min(R) > 0 violated (mpc_abstract.h:90-97)");
+    for (int j = 0; j < 2; ++j)
+        if (!(p->upper[j] >= p->lower[j]))
+            return fail(h, TPC_MPC_ERR_BAD_BOUNDS, "upper >= lower violated (mpc_abstract.h:90-97)");
+    if (!std::isfinite(p->step_size) || !std::isfinite(p->wheelbase) || p->wheelbase == 0)
+        return fail(h, TPC_MPC_ERR_BAD_ARG, "step_size / wheelbase must be finite, wheelbase != 0");
+    return TPC_MPC_OK;
+}
+
+// StreamOrder.  Solves of one handle share its scratch (ticket, flag word, statistics, records,
+// queue, staging), so two of them must never overlap.  On one stream they cannot; a solve that
+// arrives on a different stream than the previous one first makes its stream wait for the event
+// recorded behind that previous solve.
+int stream_order_begin(tpc_mpc_context* h, hipStream_t s) {
+    if (h->have_last && h->last_stream != s) HIP_TRY(h, hipStreamWaitEvent(s, h->done_ev, 0));
+    return TPC_MPC_OK;
+}
+int stream_order_end(tpc_mpc_context* h, hipStream_t s) {
+    HIP_TRY(h, hipEventRecord(h->done_ev, s));
+    h->last_stream = s;
+    h->have_last = true;
+    return TPC_MPC_OK;
+}
+
 int finish_flags(tpc_mpc_context* h, uint32_t* flags_out, hipStream_t s) {
     if (!flags_out) return TPC_MPC_OK;
     uint32_t f = 0;
@@ -258,7 +196,40 @@ int finish_flags(tpc_mpc_context* h, uint32_t* flags_out, hipStream_t s) {
     return TPC_MPC_OK;
 }
 
-}  // namespace
+int reserve_lane_workspace(tpc_mpc_context* h, int H, int dtype, int64_t n) {
+    const bool ev_valid = h->ev_valid;
+    const int last_algo = h->last_algo;
+    Workspace ws;
+    const int rc = prepare_workspace(h, TPC_MPC_ALGO_LANE, H, dtype, n, &ws);
+    h->ev_valid = ev_valid;
+    h->last_algo = last_algo;
+    return rc;
+}
+
+int compact_launch(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy,
+                   const void* dphi, void* front, void* rear, int32_t* iters, hipStream_t s) {
+    const int algo = pick_algo(h, p->algo, 2, p->horizon, n);
+    if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel needs inputs*horizon <= 64; use LANE or AUTO");
+    CompactArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.n = n;
+    a.v = v; a.dy = dy; a.dphi = dphi;
+    a.front = front; a.rear = rear; a.iters = iters;
+    a.flags = h->collect_flags ? h->ws_words + 1 : nullptr;
+    a.work_hint = take_hint(h, n);
+    a.step = p->step_size; a.wheelbase = p->wheelbase;
+    a.q[0] = p->weight_y; a.q[1] = p->weight_phi;
+    a.r[0] = p->weight_steering_front; a.r[1] = p->weight_steering_rear;
+    a.lo[0] = p->lower[0]; a.lo[1] = p->lower[1]; a.hi[0] = p->upper[0]; a.hi[1] = p->upper[1];
+    Workspace ws;
+    int rc = prepare_workspace(h, algo, p->horizon, p->dtype, n, &ws);
+    if (rc) return rc;
+    hipError_t e = dispatch_compact(algo, p->horizon, p->dtype, a, knobs_of(p), ws, s);
+    if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
+    return TPC_MPC_OK;
+}
+
+}  // namespace tpc
 
 extern "C" {
 
@@ -268,6 +239,16 @@ int tpc_mpc_supported_horizons(int* out, int cap) {
     const int n = (int)(sizeof(kHorizons) / sizeof(kHorizons[0]));
     for (int i = 0; i < n && i < cap && out; ++i) out[i] = kHorizons[i];
     return n;
+}
+
+const char* tpc_mpc_build_info(void) {
+    // assembled from what each LANE translation unit recorded about its own build (csrc/Makefile)
+    static thread_local char info[512];
+    std::snprintf(info, sizeof(info),
+                  "libtpc_mpc abi %d gfx950; lane units: h4[%s] h5[%s] h10[%s] h20[%s] h30[%s] h40[%s]",
+                  TPC_MPC_ABI_VERSION, lane_build_h4(), lane_build_h5(), lane_build_h10(), lane_build_h20(),
+                  lane_build_h30(), lane_build_h40());
+    return info;
 }
 
 int tpc_mpc_default_params(tpc_mpc_params* p, int horizon) {
@@ -292,475 +273,540 @@ int tpc_mpc_default_params(tpc_mpc_params* p, int horizon) {
 }
 
 int tpc_mpc_create(int device, tpc_mpc_handle* out) {
-    if (!out) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null out pointer");
-    *out = nullptr;
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count <= 0)
-        return fail(nullptr, TPC_MPC_ERR_NO_DEVICE,
-                    std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count == 0"));
-    if (device < 0 || device >= count)
-        return fail(nullptr, TPC_MPC_ERR_NO_DEVICE, "device index out of range");
-    hipDeviceProp_t prop;
-    e = hipGetDeviceProperties(&prop, device);
-    if (e != hipSuccess) return fail(nullptr, TPC_MPC_ERR_NO_DEVICE, hipGetErrorString(e));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(nullptr, TPC_MPC_ERR_NO_DEVICE,
-                    std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
-    tpc_mpc_context* h = new (std::nothrow) tpc_mpc_context;
-    if (!h) return fail(nullptr, TPC_MPC_ERR_ALLOC, "out of host memory");
-    h->device = device;
-    h->cu_count = prop.multiProcessorCount;
-    e = hipSetDevice(device);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->ws_words, 64);
-    if (e == hipSuccess) e = hipMemset(h->ws_words, 0, 64);
-    if (e == hipSuccess) e = hipHostMalloc(&h->pin_host, 64, hipHostMallocMapped);
-    if (e == hipSuccess) e = hipHostGetDevicePointer(&h->pin_dev, h->pin_host, 0);
-    if (e != hipSuccess) {
-        delete h;
-        return fail(nullptr, TPC_MPC_ERR_HIP, std::string("create: ") + hipGetErrorString(e));
-    }
-    *out = h;
-    return TPC_MPC_OK;
+    return guarded(nullptr, [&]() -> int {
+        if (!out) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null out pointer");
+        *out = nullptr;
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count <= 0)
+            return fail(nullptr, TPC_MPC_ERR_NO_DEVICE, "no HIP device: %s",
+                        e != hipSuccess ? hipGetErrorString(e) : "count == 0");
+        if (device < 0 || device >= count) return fail(nullptr, TPC_MPC_ERR_NO_DEVICE, "device index out of range");
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, device);
+        if (e != hipSuccess) return fail(nullptr, TPC_MPC_ERR_NO_DEVICE, "%s", hipGetErrorString(e));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(nullptr, TPC_MPC_ERR_NO_DEVICE, "device is %s, this library carries gfx950 code only",
+                        prop.gcnArchName);
+        tpc_mpc_context* h = new (std::nothrow) tpc_mpc_context;
+        if (!h) return fail(nullptr, TPC_MPC_ERR_ALLOC, "out of host memory");
+        h->device = device;
+        h->cu_count = prop.multiProcessorCount;
+        e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->ws_words, 64);
+        if (e == hipSuccess) e = hipMemset(h->ws_words, 0, 64);
+        if (e == hipSuccess) e = hipHostMalloc(&h->pin_host, 512, hipHostMallocMapped | hipHostMallocCoherent);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&h->pin_dev, h->pin_host, 0);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->done_ev, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            (void)tpc_mpc_destroy(h);
+            return fail(nullptr, TPC_MPC_ERR_HIP, "create: %s", hipGetErrorString(e));
+        }
+        std::memset(h->pin_host, 0, 512);
+        *out = h;
+        return TPC_MPC_OK;
+    });
 }
 
 int tpc_mpc_destroy(tpc_mpc_handle h) {
     if (!h) return TPC_MPC_OK;
-    (void)hipSetDevice(h->device);
-    if (h->ws_state) (void)hipFree(h->ws_state);
-    if (h->ws_words) (void)hipFree(h->ws_words);
-    if (h->stage) (void)hipFree(h->stage);
-    if (h->roll) (void)hipFree(h->roll);
-    if (h->hint_own) (void)hipFree(h->hint_own);
-    if (h->pin_host) (void)hipHostFree(h->pin_host);
-    for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
-    delete h;
-    return TPC_MPC_OK;
+    return guarded(nullptr, [&]() -> int {
+        (void)hipSetDevice(h->device);
+        one_shot_destroy(h);   // stops the resident kernel before its mailbox goes away
+        comm_destroy(h);
+        if (h->ws_state) (void)hipFree(h->ws_state);
+        if (h->ws_words) (void)hipFree(h->ws_words);
+        if (h->stage) (void)hipFree(h->stage);
+        if (h->roll) (void)hipFree(h->roll);
+        if (h->mix) (void)hipFree(h->mix);
+        if (h->hint_own) (void)hipFree(h->hint_own);
+        if (h->pin_host) (void)hipHostFree(h->pin_host);
+        if (h->done_ev) (void)hipEventDestroy(h->done_ev);
+        for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+        delete h;
+        return TPC_MPC_OK;
+    });
 }
 
-const char* tpc_mpc_last_error(tpc_mpc_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+const char* tpc_mpc_last_error(tpc_mpc_handle h) { return h ? h->err : g_create_error; }
 
 int tpc_mpc_solve_batch_compact(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n, const void* v,
                                 const void* delta_y, const void* delta_phi, void* steering_front,
                                 void* steering_rear, int32_t* iters, uint32_t* flags_out, int mem,
                                 void* stream) {
-    int rc = check_common(h, p);
-    if (rc) return rc;
-    rc = check_compact_model(h, p);
-    if (rc) return rc;
-    if (n < 0 || n > 0x7fffffffll) return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= n < 2^31");
-    if (mem != TPC_MPC_HOST && mem != TPC_MPC_DEVICE) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad memory kind");
-    if (n == 0) { if (flags_out) *flags_out = 0; return TPC_MPC_OK; }
-    if (!v || !delta_y || !delta_phi || !steering_front || !steering_rear)
-        return fail(h, TPC_MPC_ERR_BAD_ARG, "null batch pointer");
-    HIP_TRY(h, hipSetDevice(h->device));
-    hipStream_t s = (hipStream_t)stream;
-    const size_t es = esize(p->dtype);
-    const int algo = pick_algo(h, p->algo, 2, p->horizon, n);
-    if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel needs inputs*horizon <= 64; use LANE or AUTO");
-
-    CompactArgs a;
-    std::memset(&a, 0, sizeof(a));
-    a.n = n;
-    if (mem == TPC_MPC_DEVICE) {
-        a.v = v; a.dy = delta_y; a.dphi = delta_phi;
-        a.front = steering_front; a.rear = steering_rear; a.iters = iters;
-    } else {
-        // staging layout: v | dy | dphi | front | rear | iters
-        const int64_t col = (int64_t)((n * es + 255) / 256 * 256);
-        const int64_t icol = (int64_t)((n * 4 + 255) / 256 * 256);
-        rc = ensure(h, &h->stage, &h->stage_bytes, 5 * col + icol);
+    return guarded(h, [&]() -> int {
+        int rc = check_common(h, p);
         if (rc) return rc;
-        char* b = (char*)h->stage;
-        HIP_TRY(h, hipMemcpyAsync(b, v, n * es, hipMemcpyHostToDevice, s));
-        HIP_TRY(h, hipMemcpyAsync(b + col, delta_y, n * es, hipMemcpyHostToDevice, s));
-        HIP_TRY(h, hipMemcpyAsync(b + 2 * col, delta_phi, n * es, hipMemcpyHostToDevice, s));
-        a.v = b; a.dy = b + col; a.dphi = b + 2 * col;
-        a.front = b + 3 * col; a.rear = b + 4 * col;
-        a.iters = iters ? (int32_t*)(b + 5 * col) : nullptr;
-    }
-    a.flags = h->collect_flags ? h->ws_words + 1 : nullptr;
-    a.work_hint = take_hint(h, n);
-    a.step = p->step_size; a.wheelbase = p->wheelbase;
-    a.q[0] = p->weight_y; a.q[1] = p->weight_phi;
-    a.r[0] = p->weight_steering_front; a.r[1] = p->weight_steering_rear;
-    a.lo[0] = p->lower[0]; a.lo[1] = p->lower[1]; a.hi[0] = p->upper[0]; a.hi[1] = p->upper[1];
-
-    Workspace ws;
-    rc = prepare_workspace(h, algo, p->horizon, p->dtype, n, &ws);
-    if (rc) return rc;
-    if (a.flags) HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
-    hipError_t e = dispatch_compact(algo, p->horizon, p->dtype, a, knobs_of(p), ws, s);
-    if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
-
-    if (mem == TPC_MPC_HOST) {
-        HIP_TRY(h, hipMemcpyAsync(steering_front, a.front, n * es, hipMemcpyDeviceToHost, s));
-        HIP_TRY(h, hipMemcpyAsync(steering_rear, a.rear, n * es, hipMemcpyDeviceToHost, s));
-        if (iters) HIP_TRY(h, hipMemcpyAsync(iters, a.iters, n * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(h, hipStreamSynchronize(s));
-    }
-    return finish_flags(h, flags_out, s);
+        rc = check_compact_model(h, p);
+        if (rc) return rc;
+        if (n < 0 || n > 0x7fffffffll) return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= n < 2^31");
+        if (mem != TPC_MPC_HOST && mem != TPC_MPC_DEVICE) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad memory kind");
+        if (n == 0) { if (flags_out) *flags_out = 0; return TPC_MPC_OK; }
+        if (!v || !delta_y || !delta_phi || !steering_front || !steering_rear)
+            return fail(h, TPC_MPC_ERR_BAD_ARG, "null batch pointer");
+        HIP_TRY(h, hipSetDevice(h->device));
+        hipStream_t s = (hipStream_t)stream;
+        const int64_t es = (int64_t)esize(p->dtype);
+        rc = stream_order_begin(h, s);
+        if (rc) return rc;
+        HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
+        if (mem == TPC_MPC_DEVICE) {
+            rc = compact_launch(h, p, n, v, delta_y, delta_phi, steering_front, steering_rear, iters, s);
+            if (rc) return rc;
+        } else {
+            // staging layout: v | dy | dphi | front | rear | iters
+            const int64_t col = pad256(n * es), icol = pad256(n * 4);
+            rc = ensure(h, &h->stage, &h->stage_bytes, 5 * col + icol);
+            if (rc) return rc;
+            char* b = (char*)h->stage;
+            HIP_TRY(h, hipMemcpyAsync(b, v, n * es, hipMemcpyHostToDevice, s));
+            HIP_TRY(h, hipMemcpyAsync(b + col, delta_y, n * es, hipMemcpyHostToDevice, s));
+            HIP_TRY(h, hipMemcpyAsync(b + 2 * col, delta_phi, n * es, hipMemcpyHostToDevice, s));
+            int32_t* d_it = iters ? (int32_t*)(b + 5 * col) : nullptr;
+            rc = compact_launch(h, p, n, b, b + col, b + 2 * col, b + 3 * col, b + 4 * col, d_it, s);
+            if (rc) return rc;
+            HIP_TRY(h, hipMemcpyAsync(steering_front, b + 3 * col, n * es, hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipMemcpyAsync(steering_rear, b + 4 * col, n * es, hipMemcpyDeviceToHost, s));
+            if (iters) HIP_TRY(h, hipMemcpyAsync(iters, d_it, n * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipStreamSynchronize(s));
+        }
+        rc = stream_order_end(h, s);
+        if (rc) return rc;
+        return finish_flags(h, flags_out, s);
+    });
 }
 
 int tpc_mpc_solve_one(tpc_mpc_handle h, const tpc_mpc_params* p, double v, double delta_y,
                       double delta_phi, double* steering_front, double* steering_rear) {
-    if (!steering_front || !steering_rear) return fail(h, TPC_MPC_ERR_BAD_ARG, "null output pointer");
-    if (!p) return fail(h, TPC_MPC_ERR_BAD_ARG, "null params");
-    if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
-    tpc_mpc_params q = *p;
-    if (q.algo == TPC_MPC_ALGO_AUTO && 2 * q.horizon <= kWave) q.algo = TPC_MPC_ALGO_WAVE;   // one instance: one wavefront
-    // inputs and outputs go through the handle's mapped pinned block: [v, dy, dphi, front, rear]
-    const size_t es = q.dtype == TPC_MPC_F64 ? 8 : 4;
-    char* hp = (char*)h->pin_host;
-    char* dp = (char*)h->pin_dev;
-    if (q.dtype == TPC_MPC_F64) {
-        double* x = (double*)hp;
-        x[0] = v; x[1] = delta_y; x[2] = delta_phi;
-    } else {
-        float* x = (float*)hp;
-        x[0] = (float)v; x[1] = (float)delta_y; x[2] = (float)delta_phi;
-    }
-    // The outputs are pre-set to a NaN with a payload no solve produces; the kernel's two stores
-    // into the mapped block are the completion signal the host polls for (a stream synchronise
-    // costs 10-20 us more than the solve itself at N = 4).  Bounded: after 2 ms of polling, or if
-    // the pattern is still there when the stream has drained, fall back to the stream's verdict.
-    const uint64_t sentinel64 = 0x7ff8dead5eedc0deull;
-    const uint32_t sentinel32 = 0x7fc5eed1u;
-    if (q.dtype == TPC_MPC_F64) { std::memcpy(hp + 3 * es, &sentinel64, 8); std::memcpy(hp + 4 * es, &sentinel64, 8); }
-    else { std::memcpy(hp + 3 * es, &sentinel32, 4); std::memcpy(hp + 4 * es, &sentinel32, 4); }
-    h->collect_flags = false;
-    int rc = tpc_mpc_solve_batch_compact(h, &q, 1, dp, dp + es, dp + 2 * es, dp + 3 * es, dp + 4 * es, nullptr,
-                                         nullptr, TPC_MPC_DEVICE, nullptr);
-    h->collect_flags = true;
-    if (rc) return rc;
-    bool done = false;
-    {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int it = 0; !done; ++it) {
-            if (q.dtype == TPC_MPC_F64) {
-                const volatile uint64_t* o = (const volatile uint64_t*)(hp + 3 * es);
-                done = o[0] != sentinel64 && o[1] != sentinel64;
-            } else {
-                const volatile uint32_t* o = (const volatile uint32_t*)(hp + 3 * es);
-                done = o[0] != sentinel32 && o[1] != sentinel32;
-            }
-            if (!done && (it & 255) == 255 &&
-                std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
-        }
-    }
-    if (!done) HIP_TRY(h, hipStreamSynchronize(nullptr));
-    if (q.dtype == TPC_MPC_F64) {
-        *steering_front = ((double*)hp)[3];
-        *steering_rear = ((double*)hp)[4];
-    } else {
-        *steering_front = ((float*)hp)[3];
-        *steering_rear = ((float*)hp)[4];
-    }
-    return TPC_MPC_OK;
+    return guarded(h, [&]() -> int {
+        if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+        if (!steering_front || !steering_rear) return fail(h, TPC_MPC_ERR_BAD_ARG, "null output pointer");
+        int rc = check_common(h, p);
+        if (rc) return rc;
+        rc = check_compact_model(h, p);
+        if (rc) return rc;
+        HIP_TRY(h, hipSetDevice(h->device));
+        return one_shot_solve(h, p, v, delta_y, delta_phi, steering_front, steering_rear);
+    });
 }
 
 int tpc_mpc_solve_batch_general(tpc_mpc_handle h, const tpc_mpc_params* p,
                                 const tpc_mpc_general_io* io, uint32_t* flags_out, int mem,
                                 void* stream) {
-    int rc = check_common(h, p);
-    if (rc) return rc;
-    if (!io) return fail(h, TPC_MPC_ERR_BAD_ARG, "null io");
-    if (io->inputs != 1 && io->inputs != 2) return fail(h, TPC_MPC_ERR_BAD_ARG, "inputs must be 1 or 2");
-    if (io->n < 0 || io->ld < io->n || io->n > 0x7fffffffll) return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= n <= ld, n < 2^31");
-    if (mem != TPC_MPC_HOST && mem != TPC_MPC_DEVICE) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad memory kind");
-    if (io->n == 0) { if (flags_out) *flags_out = 0; return TPC_MPC_OK; }
-    if (!io->A || !io->B || !io->C || !io->Q || !io->R || !io->lower || !io->upper || !io->x0 ||
-        !io->targets || !io->u0)
-        return fail(h, TPC_MPC_ERR_BAD_ARG, "null batch pointer");
-    HIP_TRY(h, hipSetDevice(h->device));
-    hipStream_t s = (hipStream_t)stream;
-    const size_t es = esize(p->dtype);
-    const int I = io->inputs, H = p->horizon;
-    const int64_t n = io->n;
-    const int algo = pick_algo(h, p->algo, I, H, n);
-    if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel needs inputs*horizon <= 64; use LANE or AUTO");
-
-    GeneralArgs a;
-    std::memset(&a, 0, sizeof(a));
-    a.n = n;
-    a.shift_controls = 1;
-    std::vector<std::pair<void*, const void*>> back;   // (host dst, device src) copies after the solve
-    std::vector<int64_t> back_bytes;
-    if (mem == TPC_MPC_DEVICE) {
-        a.ld = io->ld;
-        a.A = io->A; a.B = io->B; a.C = io->C; a.Q = io->Q; a.R = io->R; a.lo = io->lower; a.hi = io->upper;
-        a.x0 = io->x0; a.targets = io->targets; a.controls = io->controls_inout; a.v = io->v_inout;
-        a.u0 = io->u0; a.iters = io->iters;
-    } else {
-        // Host arrays use leading dimension io->ld; they are staged as they are (ld kept).
-        const int64_t ld = io->ld;
-        a.ld = ld;
-        const int comps[] = {4, 2 * I, 2, 2, I, I, I, 2, 2 * H, H * I, H * I, I};
-        const void* src[] = {io->A, io->B, io->C, io->Q, io->R, io->lower, io->upper, io->x0, io->targets,
-                             io->controls_inout, io->v_inout, nullptr};
-        int64_t off[13];
-        int64_t total = 0;
-        for (int c = 0; c < 12; ++c) { off[c] = total; total += ((int64_t)comps[c] * ld * es + 255) / 256 * 256; }
-        off[12] = total;
-        total += (n * 4 + 255) / 256 * 256;
-        rc = ensure(h, &h->stage, &h->stage_bytes, total);
+    return guarded(h, [&]() -> int {
+        int rc = check_common(h, p);
         if (rc) return rc;
-        char* b = (char*)h->stage;
-        for (int c = 0; c < 11; ++c)
-            if (src[c]) HIP_TRY(h, hipMemcpyAsync(b + off[c], src[c], (size_t)comps[c] * ld * es, hipMemcpyHostToDevice, s));
-        a.A = b + off[0]; a.B = b + off[1]; a.C = b + off[2]; a.Q = b + off[3]; a.R = b + off[4];
-        a.lo = b + off[5]; a.hi = b + off[6]; a.x0 = b + off[7]; a.targets = b + off[8];
-        a.controls = io->controls_inout ? b + off[9] : nullptr;
-        a.v = io->v_inout ? b + off[10] : nullptr;
-        a.u0 = b + off[11];
-        a.iters = io->iters ? (int32_t*)(b + off[12]) : nullptr;
-        back.push_back({io->u0, a.u0}); back_bytes.push_back((int64_t)I * ld * es);
-        if (io->controls_inout) { back.push_back({io->controls_inout, a.controls}); back_bytes.push_back((int64_t)H * I * ld * es); }
-        if (io->v_inout) { back.push_back({io->v_inout, a.v}); back_bytes.push_back((int64_t)H * I * ld * es); }
-        if (io->iters) { back.push_back({io->iters, a.iters}); back_bytes.push_back(n * 4); }
-    }
-    a.flags = h->ws_words + 1;
-    a.work_hint = take_hint(h, n);
+        rc = check_general_io(h, io, mem);
+        if (rc) return rc;
+        if (io->n == 0) { if (flags_out) *flags_out = 0; return TPC_MPC_OK; }
+        if (!io->A || !io->B || !io->C || !io->Q || !io->R || !io->lower || !io->upper || !io->x0 ||
+            !io->targets || !io->u0)
+            return fail(h, TPC_MPC_ERR_BAD_ARG, "null batch pointer");
+        HIP_TRY(h, hipSetDevice(h->device));
+        hipStream_t s = (hipStream_t)stream;
+        const int64_t es = (int64_t)esize(p->dtype);
+        const int I = io->inputs, H = p->horizon;
+        const int64_t n = io->n;
+        const int algo = pick_algo(h, p->algo, I, H, n);
+        if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel needs inputs*horizon <= 64; use LANE or AUTO");
+        rc = stream_order_begin(h, s);
+        if (rc) return rc;
 
-    Workspace ws;
-    rc = prepare_workspace(h, algo, H, p->dtype, n, &ws);
-    if (rc) return rc;
-    HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
-    hipError_t e = dispatch_general(algo, I, H, p->dtype, a, knobs_of(p), ws, s);
-    if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
-    if (mem == TPC_MPC_HOST) {
-        for (size_t i = 0; i < back.size(); ++i)
-            HIP_TRY(h, hipMemcpyAsync(back[i].first, back[i].second, (size_t)back_bytes[i], hipMemcpyDeviceToHost, s));
-        HIP_TRY(h, hipStreamSynchronize(s));
-    }
-    return finish_flags(h, flags_out, s);
+        GeneralArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.n = n;
+        a.shift_controls = 1;
+        // HOST arrays: component c of the caller's array starts at base + c*ld and only its first n
+        // elements belong to this call (a shard passes base + k0 and the full batch's ld), so every
+        // component row is copied on its own -- n elements, never ld -- into a staging array whose
+        // leading dimension is n rounded up to a wavefront.
+        const int64_t lds = (n + 63) / 64 * 64;
+        const int comps[12] = {4, 2 * I, 2, 2, I, I, I, 2, 2 * H, H * I, H * I, I};
+        int64_t off[13] = {0};
+        char* b = nullptr;
+        if (mem == TPC_MPC_DEVICE) {
+            a.ld = io->ld;
+            a.A = io->A; a.B = io->B; a.C = io->C; a.Q = io->Q; a.R = io->R; a.lo = io->lower; a.hi = io->upper;
+            a.x0 = io->x0; a.targets = io->targets; a.controls = io->controls_inout; a.v = io->v_inout;
+            a.u0 = io->u0; a.iters = io->iters;
+        } else {
+            const void* src[12] = {io->A, io->B, io->C, io->Q, io->R, io->lower, io->upper, io->x0, io->targets,
+                                   io->controls_inout, io->v_inout, nullptr};
+            int64_t total = 0;
+            for (int c = 0; c < 12; ++c) { off[c] = total; total += pad256((int64_t)comps[c] * lds * es); }
+            off[12] = total;
+            total += pad256(n * 4);
+            rc = ensure(h, &h->stage, &h->stage_bytes, total);
+            if (rc) return rc;
+            b = (char*)h->stage;
+            for (int c = 0; c < 11; ++c)
+                if (src[c])
+                    HIP_TRY(h, copy_rows(b + off[c], lds * es, src[c], io->ld * es, n * es, comps[c],
+                                         hipMemcpyHostToDevice, s));
+            a.ld = lds;
+            a.A = b + off[0]; a.B = b + off[1]; a.C = b + off[2]; a.Q = b + off[3]; a.R = b + off[4];
+            a.lo = b + off[5]; a.hi = b + off[6]; a.x0 = b + off[7]; a.targets = b + off[8];
+            a.controls = io->controls_inout ? b + off[9] : nullptr;
+            a.v = io->v_inout ? b + off[10] : nullptr;
+            a.u0 = b + off[11];
+            a.iters = io->iters ? (int32_t*)(b + off[12]) : nullptr;
+        }
+        a.flags = h->ws_words + 1;
+        a.work_hint = take_hint(h, n);
+
+        Workspace ws;
+        rc = prepare_workspace(h, algo, H, p->dtype, n, &ws);
+        if (rc) return rc;
+        HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
+        hipError_t e = dispatch_general(algo, I, H, p->dtype, a, knobs_of(p), ws, s);
+        if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
+        if (mem == TPC_MPC_HOST) {
+            const int64_t hp = io->ld * es, dp = lds * es, w = n * es;
+            HIP_TRY(h, copy_rows(io->u0, hp, a.u0, dp, w, I, hipMemcpyDeviceToHost, s));
+            if (io->controls_inout)
+                HIP_TRY(h, copy_rows(io->controls_inout, hp, a.controls, dp, w, H * I, hipMemcpyDeviceToHost, s));
+            if (io->v_inout) HIP_TRY(h, copy_rows(io->v_inout, hp, a.v, dp, w, H * I, hipMemcpyDeviceToHost, s));
+            if (io->iters) HIP_TRY(h, hipMemcpyAsync(io->iters, a.iters, n * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipStreamSynchronize(s));
+        }
+        rc = stream_order_end(h, s);
+        if (rc) return rc;
+        return finish_flags(h, flags_out, s);
+    });
 }
 
 int tpc_mpc_rollout(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mpc_general_io* io,
                     int32_t steps, const void* new_last_targets, void* controls_out,
                     void* states_out, int32_t* iters_out, uint32_t* flags_out, int mem,
                     void* stream) {
-    int rc = check_common(h, p);
-    if (rc) return rc;
-    if (!io) return fail(h, TPC_MPC_ERR_BAD_ARG, "null io");
-    if (io->inputs != 1 && io->inputs != 2) return fail(h, TPC_MPC_ERR_BAD_ARG, "inputs must be 1 or 2");
-    if (io->n < 0 || io->ld < io->n || steps < 0) return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= n <= ld, steps >= 0");
-    if (mem != TPC_MPC_HOST && mem != TPC_MPC_DEVICE) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad memory kind");
-    if (io->n == 0 || steps == 0) { if (flags_out) *flags_out = 0; return TPC_MPC_OK; }
-    if (!io->A || !io->B || !io->C || !io->Q || !io->R || !io->lower || !io->upper || !io->x0 ||
-        !io->targets || !controls_out)
-        return fail(h, TPC_MPC_ERR_BAD_ARG, "null batch pointer");
-    HIP_TRY(h, hipSetDevice(h->device));
-    hipStream_t s = (hipStream_t)stream;
-    const size_t es = esize(p->dtype);
-    const int I = io->inputs, H = p->horizon;
-    const int64_t n = io->n, ld = io->ld;
-    const int algo = pick_algo(h, p->algo, I, H, n);
-    if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel needs inputs*horizon <= 64; use LANE or AUTO");
-    auto pad = [](int64_t b) { return (b + 255) / 256 * 256; };
-
-    // device views of the caller's arrays (staged when they live on the host)
-    const int in_comps[] = {4, 2 * I, 2, 2, I, I, I, 2, 2 * H, H * I, H * I, steps * 2};
-    const void* in_src[] = {io->A, io->B, io->C, io->Q, io->R, io->lower, io->upper, io->x0, io->targets,
-                            io->controls_inout, io->v_inout, new_last_targets};
-    const void* dv[12];
-    char* out_base = nullptr;
-    int64_t o_ctrl = 0, o_states = 0, o_iters = 0;
-    if (mem == TPC_MPC_DEVICE) {
-        for (int c = 0; c < 12; ++c) dv[c] = in_src[c];
-    } else {
-        int64_t off[12], total = 0;
-        for (int c = 0; c < 12; ++c) { off[c] = total; total += pad((int64_t)in_comps[c] * ld * es); }
-        o_ctrl = total; total += pad((int64_t)steps * I * ld * es);
-        o_states = total; total += pad((int64_t)steps * 2 * ld * es);
-        o_iters = total; total += pad((int64_t)steps * ld * 4);
-        rc = ensure(h, &h->stage, &h->stage_bytes, total);
+    return guarded(h, [&]() -> int {
+        int rc = check_common(h, p);
         if (rc) return rc;
-        char* b = (char*)h->stage;
-        for (int c = 0; c < 12; ++c) {
-            dv[c] = in_src[c] ? b + off[c] : nullptr;
-            if (in_src[c]) HIP_TRY(h, hipMemcpyAsync(b + off[c], in_src[c], (size_t)in_comps[c] * ld * es, hipMemcpyHostToDevice, s));
+        rc = check_general_io(h, io, mem);
+        if (rc) return rc;
+        if (steps < 0 || steps > (1 << 24)) return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= steps <= 2^24");
+        if (io->n == 0 || steps == 0) { if (flags_out) *flags_out = 0; return TPC_MPC_OK; }
+        if (!io->A || !io->B || !io->C || !io->Q || !io->R || !io->lower || !io->upper || !io->x0 ||
+            !io->targets || !controls_out)
+            return fail(h, TPC_MPC_ERR_BAD_ARG, "null batch pointer");
+        HIP_TRY(h, hipSetDevice(h->device));
+        hipStream_t s = (hipStream_t)stream;
+        const int64_t es = (int64_t)esize(p->dtype);
+        const int I = io->inputs, H = p->horizon;
+        const int64_t n = io->n, ld = io->ld;
+        const int algo = pick_algo(h, p->algo, I, H, n);
+        if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel needs inputs*horizon <= 64; use LANE or AUTO");
+        rc = stream_order_begin(h, s);
+        if (rc) return rc;
+        const bool host = mem == TPC_MPC_HOST;
+        const hipMemcpyKind in_kind = host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+        const hipMemcpyKind out_kind = host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+
+        // The handle's working set, leading dimension ldw (n rounded up to a wavefront): a copy of the
+        // model, then the state the loop carries -- x, targets, controls, v -- and the per-step u0 and
+        // iteration counts.  Copies are row-wise with n elements per component, so a caller's ld > n
+        // (a shard of a larger batch) is neither over-read nor over-written.
+        //   0 A[4] 1 B[2I] 2 C[2] 3 Q[2] 4 R[I] 5 lo[I] 6 hi[I] 7 x[2] 8 targets[2H] 9 controls[HI] 10 v[HI] 11 u0[I]
+        const int64_t ldw = (n + 63) / 64 * 64;
+        const int comps[12] = {4, 2 * I, 2, 2, I, I, I, 2, 2 * H, H * I, H * I, I};
+        const void* src[12] = {io->A, io->B, io->C, io->Q, io->R, io->lower, io->upper, io->x0, io->targets,
+                               io->controls_inout, io->v_inout, nullptr};
+        int64_t off[12], total = 0;
+        for (int c = 0; c < 12; ++c) { off[c] = total; total += pad256((int64_t)comps[c] * ldw * es); }
+        const int64_t o_iters = total; total += pad256(ldw * 4);
+        rc = ensure(h, &h->roll, &h->roll_bytes, total);
+        if (rc) return rc;
+        char* w = (char*)h->roll;
+        for (int c = 0; c < 11; ++c) {
+            if (src[c]) HIP_TRY(h, copy_rows(w + off[c], ldw * es, src[c], ld * es, n * es, comps[c], in_kind, s));
+            else HIP_TRY(h, hipMemsetAsync(w + off[c], 0, (size_t)((int64_t)comps[c] * ldw * es), s));
         }
-        out_base = b;
-    }
-    // working set: x[2] | targets[2H] | controls[H*I] | v[H*I] | u0[I] | iters[n]
-    const int64_t w_x = 0, w_t = w_x + pad(2 * ld * es), w_c = w_t + pad((int64_t)2 * H * ld * es);
-    const int64_t w_v = w_c + pad((int64_t)H * I * ld * es), w_u = w_v + pad((int64_t)H * I * ld * es);
-    const int64_t w_i = w_u + pad((int64_t)I * ld * es), w_end = w_i + pad(ld * 4);
-    rc = ensure(h, &h->roll, &h->roll_bytes, w_end);
-    if (rc) return rc;
-    char* w = (char*)h->roll;
-    HIP_TRY(h, hipMemcpyAsync(w + w_x, dv[7], 2 * ld * es, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(h, hipMemcpyAsync(w + w_t, dv[8], (size_t)2 * H * ld * es, hipMemcpyDeviceToDevice, s));
-    if (dv[9]) HIP_TRY(h, hipMemcpyAsync(w + w_c, dv[9], (size_t)H * I * ld * es, hipMemcpyDeviceToDevice, s));
-    else HIP_TRY(h, hipMemsetAsync(w + w_c, 0, (size_t)H * I * ld * es, s));
-    if (dv[10]) HIP_TRY(h, hipMemcpyAsync(w + w_v, dv[10], (size_t)H * I * ld * es, hipMemcpyDeviceToDevice, s));
-    else HIP_TRY(h, hipMemsetAsync(w + w_v, 0, (size_t)H * I * ld * es, s));
+        // HOST mode: new_last_targets in, and the three per-step outputs, go through the staging buffer
+        const void* d_nlt = new_last_targets;
+        int64_t ld_nlt = ld, ld_out = ld;
+        char *d_ctrl = (char*)controls_out, *d_states = (char*)states_out;
+        int32_t* d_iters = iters_out;
+        if (host) {
+            const int64_t s_nlt = 0, s_ctrl = s_nlt + pad256((int64_t)steps * 2 * ldw * es);
+            const int64_t s_states = s_ctrl + pad256((int64_t)steps * I * ldw * es);
+            const int64_t s_iters = s_states + pad256((int64_t)steps * 2 * ldw * es);
+            rc = ensure(h, &h->stage, &h->stage_bytes, s_iters + pad256((int64_t)steps * ldw * 4));
+            if (rc) return rc;
+            char* b = (char*)h->stage;
+            if (new_last_targets) {
+                HIP_TRY(h, copy_rows(b + s_nlt, ldw * es, new_last_targets, ld * es, n * es, (int64_t)steps * 2,
+                                     hipMemcpyHostToDevice, s));
+                d_nlt = b + s_nlt;
+            }
+            ld_nlt = ld_out = ldw;
+            d_ctrl = b + s_ctrl;
+            d_states = states_out ? b + s_states : nullptr;
+            d_iters = iters_out ? (int32_t*)(b + s_iters) : nullptr;
+        }
 
-    GeneralArgs a;
-    std::memset(&a, 0, sizeof(a));
-    a.n = n; a.ld = ld; a.shift_controls = 1;
-    a.A = dv[0]; a.B = dv[1]; a.C = dv[2]; a.Q = dv[3]; a.R = dv[4]; a.lo = dv[5]; a.hi = dv[6];
-    a.x0 = w + w_x; a.targets = w + w_t; a.controls = w + w_c; a.v = w + w_v; a.u0 = w + w_u;
-    a.iters = (int32_t*)(w + w_i);
-    a.flags = h->ws_words + 1;
+        GeneralArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.n = n; a.ld = ldw; a.shift_controls = 1;
+        a.A = w + off[0]; a.B = w + off[1]; a.C = w + off[2]; a.Q = w + off[3]; a.R = w + off[4];
+        a.lo = w + off[5]; a.hi = w + off[6];
+        a.x0 = w + off[7]; a.targets = w + off[8]; a.controls = w + off[9]; a.v = w + off[10]; a.u0 = w + off[11];
+        a.iters = (int32_t*)(w + o_iters);
+        a.flags = h->ws_words + 1;
 
-    RolloutStepArgs r;
-    std::memset(&r, 0, sizeof(r));
-    r.n = n; r.ld = ld; r.I = I; r.H = H; r.steps = steps;
-    r.A = dv[0]; r.B = dv[1]; r.C = dv[2];
-    r.x = w + w_x; r.targets = w + w_t; r.controls = w + w_c; r.new_last_targets = dv[11];
-    r.controls_out = mem == TPC_MPC_DEVICE ? controls_out : (void*)(out_base + o_ctrl);
-    r.states_out = states_out ? (mem == TPC_MPC_DEVICE ? states_out : (void*)(out_base + o_states)) : nullptr;
-    r.iters_step = a.iters;
-    r.iters_out = iters_out ? (mem == TPC_MPC_DEVICE ? iters_out : (int32_t*)(out_base + o_iters)) : nullptr;
+        RolloutStepArgs r;
+        std::memset(&r, 0, sizeof(r));
+        r.n = n; r.ld = ldw; r.ld_out = ld_out; r.ld_nlt = ld_nlt; r.I = I; r.H = H; r.steps = steps;
+        r.A = a.A; r.B = a.B; r.C = a.C;
+        r.x = w + off[7]; r.targets = w + off[8]; r.controls = w + off[9]; r.new_last_targets = d_nlt;
+        r.controls_out = d_ctrl; r.states_out = d_states;
+        r.iters_step = a.iters; r.iters_out = d_iters;
 
-    Workspace ws;
-    rc = prepare_workspace(h, algo, H, p->dtype, n, &ws);
-    if (rc) return rc;
-    HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
-    const Knobs kn = knobs_of(p);
-    for (int st = 0; st < steps; ++st) {
-        hipError_t e = dispatch_general(algo, I, H, p->dtype, a, kn, ws, s);
-        if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
-        r.step = st;
-        e = launch_rollout_step(p->dtype, r, s);
-        if (e != hipSuccess) return hip_fail(h, e, "rollout step launch");
-    }
-    // controller state back to the caller
-    if (io->controls_inout)
-        HIP_TRY(h, hipMemcpyAsync(io->controls_inout, w + w_c, (size_t)H * I * ld * es,
-                                  mem == TPC_MPC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
-    if (io->v_inout)
-        HIP_TRY(h, hipMemcpyAsync(io->v_inout, w + w_v, (size_t)H * I * ld * es,
-                                  mem == TPC_MPC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
-    if (mem == TPC_MPC_HOST) {
-        HIP_TRY(h, hipMemcpyAsync(controls_out, out_base + o_ctrl, (size_t)steps * I * ld * es, hipMemcpyDeviceToHost, s));
-        if (states_out) HIP_TRY(h, hipMemcpyAsync(states_out, out_base + o_states, (size_t)steps * 2 * ld * es, hipMemcpyDeviceToHost, s));
-        if (iters_out) HIP_TRY(h, hipMemcpyAsync(iters_out, out_base + o_iters, (size_t)steps * ld * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(h, hipStreamSynchronize(s));
-    }
-    return finish_flags(h, flags_out, s);
+        Workspace ws;
+        rc = prepare_workspace(h, algo, H, p->dtype, n, &ws);
+        if (rc) return rc;
+        HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
+        const Knobs kn = knobs_of(p);
+        for (int st = 0; st < steps; ++st) {
+            hipError_t e = dispatch_general(algo, I, H, p->dtype, a, kn, ws, s);
+            if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
+            r.step = st;
+            e = launch_rollout_step(p->dtype, r, s);
+            if (e != hipSuccess) return hip_fail(h, e, "rollout step launch");
+        }
+        // controller state back to the caller
+        if (io->controls_inout)
+            HIP_TRY(h, copy_rows(io->controls_inout, ld * es, w + off[9], ldw * es, n * es, H * I, out_kind, s));
+        if (io->v_inout) HIP_TRY(h, copy_rows(io->v_inout, ld * es, w + off[10], ldw * es, n * es, H * I, out_kind, s));
+        if (host) {
+            HIP_TRY(h, copy_rows(controls_out, ld * es, d_ctrl, ldw * es, n * es, (int64_t)steps * I, hipMemcpyDeviceToHost, s));
+            if (states_out)
+                HIP_TRY(h, copy_rows(states_out, ld * es, d_states, ldw * es, n * es, (int64_t)steps * 2, hipMemcpyDeviceToHost, s));
+            if (iters_out)
+                HIP_TRY(h, copy_rows(iters_out, ld * 4, d_iters, ldw * 4, n * 4, steps, hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipStreamSynchronize(s));
+        }
+        rc = stream_order_end(h, s);
+        if (rc) return rc;
+        return finish_flags(h, flags_out, s);
+    });
 }
+
+namespace {
+
+int check_trajectories(tpc_mpc_context* h, const tpc_mpc_params* p, const tpc_mpc_trajectories* t,
+                       const float* lookup_x, const float* lookup_y, int32_t lookup_n) {
+    if (p->dtype != TPC_MPC_F64) return fail(h, TPC_MPC_ERR_BAD_ARG, "follow_batch solves in fp64");
+    if (!t) return fail(h, TPC_MPC_ERR_BAD_ARG, "null trajectories");
+    if (t->n < 0 || t->ld < t->n || t->n > 0x7fffffffll || t->max_points < 0 || lookup_n < 0)
+        return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= n <= ld, n < 2^31, max_points >= 0, lookup_n >= 0");
+    if (t->n == 0) return TPC_MPC_OK;
+    if (!t->pos_x || !t->pos_y || !t->dir_x || !t->dir_y || !t->velocity || !t->count || !t->car_velocity ||
+        !t->look_ahead || (lookup_n > 0 && (!lookup_x || !lookup_y)))
+        return fail(h, TPC_MPC_ERR_BAD_ARG, "null batch pointer");
+    return TPC_MPC_OK;
+}
+
+FollowArgs follow_args(const tpc_mpc_trajectories* t, const float* lookup_x, const float* lookup_y, int32_t lookup_n) {
+    FollowArgs fa;
+    std::memset(&fa, 0, sizeof(fa));
+    fa.n = t->n; fa.ld = t->ld; fa.max_points = t->max_points;
+    fa.px = t->pos_x; fa.py = t->pos_y; fa.dx = t->dir_x; fa.dy = t->dir_y; fa.vel = t->velocity;
+    fa.count = t->count; fa.car_velocity = t->car_velocity; fa.look_ahead = t->look_ahead;
+    fa.lut_x = lookup_x; fa.lut_y = lookup_y; fa.lut_n = lookup_n;
+    return fa;
+}
+
+}  // namespace
 
 int tpc_mpc_follow_batch(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mpc_trajectories* t,
                          const float* lookup_x, const float* lookup_y, int32_t lookup_n,
                          double* steering_front, double* steering_rear, float* target_speed,
                          float* target_distance, int32_t* iters, uint32_t* flags_out, void* stream) {
-    int rc = check_common(h, p);
-    if (rc) return rc;
-    rc = check_compact_model(h, p);
-    if (rc) return rc;
-    if (p->dtype != TPC_MPC_F64) return fail(h, TPC_MPC_ERR_BAD_ARG, "follow_batch solves in fp64");
-    if (!t) return fail(h, TPC_MPC_ERR_BAD_ARG, "null trajectories");
-    if (t->n < 0 || t->ld < t->n || t->n > 0x7fffffffll || t->max_points < 0 || lookup_n < 0)
-        return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= n <= ld, n < 2^31, max_points >= 0, lookup_n >= 0");
-    if (t->n == 0) { if (flags_out) *flags_out = 0; return TPC_MPC_OK; }
-    if (!t->pos_x || !t->pos_y || !t->dir_x || !t->dir_y || !t->velocity || !t->count || !t->car_velocity ||
-        !t->look_ahead || !steering_front || !steering_rear || !target_speed || !target_distance ||
-        (lookup_n > 0 && (!lookup_x || !lookup_y)))
-        return fail(h, TPC_MPC_ERR_BAD_ARG, "null batch pointer");
-    HIP_TRY(h, hipSetDevice(h->device));
-    hipStream_t s = (hipStream_t)stream;
-    const int64_t n = t->n;
-    // v | y_soll | phi_soll (the compact solve's inputs), produced on device
-    const int64_t col = (n * 8 + 255) / 256 * 256;
-    rc = ensure(h, &h->roll, &h->roll_bytes, 3 * col);
-    if (rc) return rc;
-    char* b = (char*)h->roll;
-    FollowArgs fa;
-    fa.n = n; fa.ld = t->ld; fa.max_points = t->max_points;
-    fa.px = t->pos_x; fa.py = t->pos_y; fa.dx = t->dir_x; fa.dy = t->dir_y; fa.vel = t->velocity;
-    fa.count = t->count; fa.car_velocity = t->car_velocity; fa.look_ahead = t->look_ahead;
-    fa.lut_x = lookup_x; fa.lut_y = lookup_y; fa.lut_n = lookup_n;
-    fa.v_out = (double*)b; fa.ysoll_out = (double*)(b + col); fa.phisoll_out = (double*)(b + 2 * col);
-    fa.target_speed = target_speed; fa.target_distance = target_distance;
-    hipError_t e = launch_traj_point(fa, s);
-    if (e != hipSuccess) return hip_fail(h, e, "traj_point launch");
-    rc = tpc_mpc_solve_batch_compact(h, p, n, fa.v_out, fa.ysoll_out, fa.phisoll_out, steering_front,
-                                     steering_rear, iters, nullptr, TPC_MPC_DEVICE, stream);
-    if (rc) return rc;
-    e = launch_follow_post(n, target_speed, steering_front, steering_rear, s);
-    if (e != hipSuccess) return hip_fail(h, e, "follow_post launch");
-    return finish_flags(h, flags_out, s);
+    return guarded(h, [&]() -> int {
+        int rc = check_common(h, p);
+        if (rc) return rc;
+        rc = check_compact_model(h, p);
+        if (rc) return rc;
+        rc = check_trajectories(h, p, t, lookup_x, lookup_y, lookup_n);
+        if (rc) return rc;
+        if (t->n == 0) { if (flags_out) *flags_out = 0; return TPC_MPC_OK; }
+        if (!steering_front || !steering_rear || !target_speed || !target_distance)
+            return fail(h, TPC_MPC_ERR_BAD_ARG, "null batch pointer");
+        HIP_TRY(h, hipSetDevice(h->device));
+        hipStream_t s = (hipStream_t)stream;
+        const int64_t n = t->n;
+        rc = stream_order_begin(h, s);
+        if (rc) return rc;
+        // v | y_soll | phi_soll (the compact solve's inputs), produced on device
+        const int64_t col = pad256(n * 8);
+        rc = ensure(h, &h->roll, &h->roll_bytes, 3 * col);
+        if (rc) return rc;
+        char* b = (char*)h->roll;
+        FollowArgs fa = follow_args(t, lookup_x, lookup_y, lookup_n);
+        fa.v_out = (double*)b; fa.ysoll_out = (double*)(b + col); fa.phisoll_out = (double*)(b + 2 * col);
+        fa.target_speed = target_speed; fa.target_distance = target_distance;
+        hipError_t e = launch_traj_point(fa, s);
+        if (e != hipSuccess) return hip_fail(h, e, "traj_point launch");
+        HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
+        rc = compact_launch(h, p, n, fa.v_out, fa.ysoll_out, fa.phisoll_out, steering_front, steering_rear, iters, s);
+        if (rc) return rc;
+        e = launch_follow_post(n, target_speed, steering_front, steering_rear, s);
+        if (e != hipSuccess) return hip_fail(h, e, "follow_post launch");
+        rc = stream_order_end(h, s);
+        if (rc) return rc;
+        return finish_flags(h, flags_out, s);
+    });
+}
+
+int tpc_mpc_follow_batch_horizon(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mpc_trajectories* t,
+                                 const float* step_spacing, const float* lookup_x, const float* lookup_y,
+                                 int32_t lookup_n, double* steering_front, double* steering_rear,
+                                 float* target_speed, float* target_distance, double* targets_out,
+                                 int32_t* iters, uint32_t* flags_out, void* stream) {
+    return guarded(h, [&]() -> int {
+        int rc = check_common(h, p);
+        if (rc) return rc;
+        rc = check_compact_model(h, p);
+        if (rc) return rc;
+        rc = check_trajectories(h, p, t, lookup_x, lookup_y, lookup_n);
+        if (rc) return rc;
+        if (t->n == 0) { if (flags_out) *flags_out = 0; return TPC_MPC_OK; }
+        if (!steering_front || !steering_rear || !target_speed || !target_distance)
+            return fail(h, TPC_MPC_ERR_BAD_ARG, "null batch pointer");
+        HIP_TRY(h, hipSetDevice(h->device));
+        hipStream_t s = (hipStream_t)stream;
+        const int64_t n = t->n;
+        const int H = p->horizon, I = 2;
+        const int algo = pick_algo(h, p->algo, I, H, n);
+        if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel needs inputs*horizon <= 64; use LANE or AUTO");
+        rc = stream_order_begin(h, s);
+        if (rc) return rc;
+        // general-form batch built on device: A[4] B[4] C[2] Q[2] R[2] lo[2] hi[2] x0[2] targets[2H] u0[2]
+        const int64_t ldw = (n + 63) / 64 * 64;
+        const int comps[10] = {4, 4, 2, 2, 2, 2, 2, 2, 2 * H, 2};
+        int64_t off[10], total = 0;
+        for (int c = 0; c < 10; ++c) { off[c] = total; total += pad256((int64_t)comps[c] * ldw * 8); }
+        rc = ensure(h, &h->roll, &h->roll_bytes, total);
+        if (rc) return rc;
+        char* w = (char*)h->roll;
+        FollowArgs fa = follow_args(t, lookup_x, lookup_y, lookup_n);
+        fa.target_speed = target_speed; fa.target_distance = target_distance;
+        FollowHorizonArgs fh;
+        std::memset(&fh, 0, sizeof(fh));
+        fh.H = H; fh.ldw = ldw; fh.step_spacing = step_spacing;
+        fh.step = p->step_size; fh.wheelbase = p->wheelbase;
+        fh.q[0] = p->weight_y; fh.q[1] = p->weight_phi;
+        fh.r[0] = p->weight_steering_front; fh.r[1] = p->weight_steering_rear;
+        for (int j = 0; j < 2; ++j) { fh.lo[j] = p->lower[j]; fh.hi[j] = p->upper[j]; }
+        fh.A = (double*)(w + off[0]); fh.B = (double*)(w + off[1]); fh.C = (double*)(w + off[2]);
+        fh.Q = (double*)(w + off[3]); fh.R = (double*)(w + off[4]); fh.lo_out = (double*)(w + off[5]);
+        fh.hi_out = (double*)(w + off[6]); fh.x0 = (double*)(w + off[7]); fh.targets = (double*)(w + off[8]);
+        fh.targets_copy = targets_out; fh.ld_copy = n;
+        hipError_t e = launch_traj_horizon(fa, fh, s);
+        if (e != hipSuccess) return hip_fail(h, e, "traj_horizon launch");
+
+        GeneralArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.n = n; a.ld = ldw; a.shift_controls = 1;
+        a.A = fh.A; a.B = fh.B; a.C = fh.C; a.Q = fh.Q; a.R = fh.R; a.lo = fh.lo_out; a.hi = fh.hi_out;
+        a.x0 = fh.x0; a.targets = fh.targets; a.u0 = w + off[9]; a.iters = iters;
+        a.flags = h->ws_words + 1;
+        Workspace ws;
+        rc = prepare_workspace(h, algo, H, TPC_MPC_F64, n, &ws);
+        if (rc) return rc;
+        HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
+        e = dispatch_general(algo, I, H, TPC_MPC_F64, a, knobs_of(p), ws, s);
+        if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
+        // u0[2][ldw] -> (front, rear), then the crossing rule
+        HIP_TRY(h, hipMemcpyAsync(steering_front, w + off[9], n * 8, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(h, hipMemcpyAsync(steering_rear, w + off[9] + ldw * 8, n * 8, hipMemcpyDeviceToDevice, s));
+        e = launch_follow_post(n, target_speed, steering_front, steering_rear, s);
+        if (e != hipSuccess) return hip_fail(h, e, "follow_post launch");
+        rc = stream_order_end(h, s);
+        if (rc) return rc;
+        return finish_flags(h, flags_out, s);
+    });
 }
 
 int tpc_mpc_reserve(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n, int mem) {
-    int rc = check_common(h, p);
-    if (rc) return rc;
-    if (n < 0 || n > 0x7fffffffll) return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= n < 2^31");
-    if (mem != TPC_MPC_HOST && mem != TPC_MPC_DEVICE) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad memory kind");
-    if (n == 0) return TPC_MPC_OK;
-    HIP_TRY(h, hipSetDevice(h->device));
-    // the larger of the two kernel families' needs, so that either choice of AUTO is covered
-    const bool ev_valid = h->ev_valid;
-    const int last_algo = h->last_algo;
-    Workspace ws;
-    rc = prepare_workspace(h, TPC_MPC_ALGO_LANE, p->horizon, p->dtype, n, &ws);
-    h->ev_valid = ev_valid;
-    h->last_algo = last_algo;
-    if (rc) return rc;
-    if (mem == TPC_MPC_HOST) {
-        const int64_t col = (int64_t)((n * esize(p->dtype) + 255) / 256 * 256);
-        const int64_t icol = (int64_t)((n * 4 + 255) / 256 * 256);
-        rc = ensure(h, &h->stage, &h->stage_bytes, 5 * col + icol);
+    return guarded(h, [&]() -> int {
+        int rc = check_common(h, p);
         if (rc) return rc;
-    }
-    return TPC_MPC_OK;
+        if (n < 0 || n > 0x7fffffffll) return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= n < 2^31");
+        if (mem != TPC_MPC_HOST && mem != TPC_MPC_DEVICE) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad memory kind");
+        if (n == 0) return TPC_MPC_OK;
+        HIP_TRY(h, hipSetDevice(h->device));
+        // the larger of the two kernel families' needs, so that either choice of AUTO is covered
+        rc = reserve_lane_workspace(h, p->horizon, p->dtype, n);
+        if (rc) return rc;
+        if (mem == TPC_MPC_HOST) {
+            const int64_t col = pad256(n * (int64_t)esize(p->dtype)), icol = pad256(n * 4);
+            rc = ensure(h, &h->stage, &h->stage_bytes, 5 * col + icol);
+            if (rc) return rc;
+        }
+        return TPC_MPC_OK;
+    });
 }
 
 int tpc_mpc_set_work_hint(tpc_mpc_handle h, const int32_t* hint, int64_t n, int mem) {
-    if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
-    h->hint = nullptr;
-    h->hint_n = 0;
-    if (!hint || n == 0) return TPC_MPC_OK;   // cleared
-    if (n < 0 || n > 0x7fffffffll) return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= n < 2^31");
-    if (mem != TPC_MPC_HOST && mem != TPC_MPC_DEVICE) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad memory kind");
-    if (mem == TPC_MPC_HOST) {
+    return guarded(h, [&]() -> int {
+        if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+        h->hint = nullptr;
+        h->hint_n = 0;
+        if (!hint || n == 0) return TPC_MPC_OK;   // cleared
+        if (n < 0 || n > 0x7fffffffll) return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= n < 2^31");
+        if (mem != TPC_MPC_HOST && mem != TPC_MPC_DEVICE) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad memory kind");
+        // always the handle's own copy: no caller pointer outlives the call that received it
         HIP_TRY(h, hipSetDevice(h->device));
         int rc = ensure(h, &h->hint_own, &h->hint_own_bytes, n * 4);
         if (rc) return rc;
-        HIP_TRY(h, hipMemcpy(h->hint_own, hint, (size_t)n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->hint_own, hint, (size_t)n * 4,
+                             mem == TPC_MPC_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice));
         h->hint = (const int32_t*)h->hint_own;
-    } else {
-        h->hint = hint;
-    }
-    h->hint_n = n;
-    return TPC_MPC_OK;
+        h->hint_n = n;
+        return TPC_MPC_OK;
+    });
 }
 
 int tpc_mpc_set_profiling(tpc_mpc_handle h, int enable) {
-    if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
-    HIP_TRY(h, hipSetDevice(h->device));
-    if (enable)
-        for (auto& e : h->ev) if (!e) HIP_TRY(h, hipEventCreate(&e));
-    h->profiling = enable != 0;
-    h->ev_valid = false;
-    return TPC_MPC_OK;
+    return guarded(h, [&]() -> int {
+        if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+        HIP_TRY(h, hipSetDevice(h->device));
+        if (enable)
+            for (auto& e : h->ev) if (!e) HIP_TRY(h, hipEventCreate(&e));
+        h->profiling = enable != 0;
+        h->ev_valid = false;
+        return TPC_MPC_OK;
+    });
 }
 
 int tpc_mpc_last_kernel_times(tpc_mpc_handle h, double* first_ms, double* second_ms, int* algo) {
-    if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
-    if (!h->ev_valid) return fail(h, TPC_MPC_ERR_BAD_ARG, "no profiled solve on this handle yet");
-    HIP_TRY(h, hipEventSynchronize(h->ev[2]));
-    float a = 0, b = 0;
-    HIP_TRY(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
-    HIP_TRY(h, hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
-    if (first_ms) *first_ms = a;
-    if (second_ms) *second_ms = b;
-    if (algo) *algo = h->last_algo;
-    return TPC_MPC_OK;
+    return guarded(h, [&]() -> int {
+        if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+        if (!h->ev_valid) return fail(h, TPC_MPC_ERR_BAD_ARG, "no profiled solve on this handle yet");
+        HIP_TRY(h, hipEventSynchronize(h->ev[2]));
+        float a = 0, b = 0;
+        HIP_TRY(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+        HIP_TRY(h, hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
+        if (first_ms) *first_ms = a;
+        if (second_ms) *second_ms = b;
+        if (algo) *algo = h->last_algo;
+        return TPC_MPC_OK;
+    });
 }
 
 int tpc_mpc_last_lane_stats(tpc_mpc_handle h, uint64_t* wave_iterations, uint64_t* refill_blocks) {
-    if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
-    HIP_TRY(h, hipSetDevice(h->device));
-    unsigned long long st[2] = {0, 0};
-    HIP_TRY(h, hipDeviceSynchronize());
-    HIP_TRY(h, hipMemcpy(st, h->ws_words + 4, sizeof(st), hipMemcpyDeviceToHost));
-    if (wave_iterations) *wave_iterations = st[0];
-    if (refill_blocks) *refill_blocks = st[1];
-    return TPC_MPC_OK;
+    return guarded(h, [&]() -> int {
+        if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+        HIP_TRY(h, hipSetDevice(h->device));
+        unsigned long long st[2] = {0, 0};
+        // waits for the handle's last solve only (its stream-order event), not for the whole device
+        if (h->have_last) HIP_TRY(h, hipEventSynchronize(h->done_ev));
+        HIP_TRY(h, hipMemcpy(st, h->ws_words + 4, sizeof(st), hipMemcpyDeviceToHost));
+        if (wave_iterations) *wave_iterations = st[0];
+        if (refill_blocks) *refill_blocks = st[1];
+        return TPC_MPC_OK;
+    });
 }
 
 }  // extern "C"

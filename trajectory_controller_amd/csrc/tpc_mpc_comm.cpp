@@ -1,0 +1,235 @@
+// Sharded solves: the batch is embarrassingly parallel, so the only exchange is one all-gather of
+// the control outputs over RCCL/xGMI (BASELINE.json north_star).
+//
+// One handle per GPU.  The handles of one job -- one per process under torch.distributed.run / MPI,
+// or G of them inside one C++ host process (reference host: src/interface.cpp:3) -- join a
+// communicator the NCCL way: rank 0 makes a 128-byte id (tpc_mpc_comm_unique_id), the host passes it
+// to the others by whatever means it has, everybody calls tpc_mpc_comm_init_rank.
+// tpc_mpc_solve_batch_compact_sharded then solves this rank's contiguous block of the batch straight
+// into its slot of the full-size output arrays and all-gathers the slots, all on the caller's
+// stream: afterwards every GPU holds the control outputs of all instances.
+//
+// RCCL is loaded with dlopen on first use, not linked: a single-GPU host never needs it, and inside a
+// process that already carries an RCCL (PyTorch bundles one under the same soname) the loader hands
+// out that copy instead of a second one.
+#include "tpc_mpc_context.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only; the symbols are resolved by dlsym below
+
+namespace tpc {
+
+struct Comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    char why[256] = "";
+};
+
+// Resolved once per process; a failed attempt is remembered with its reason.
+Rccl g_rccl;
+Rccl* rccl() {
+    Rccl& r = g_rccl;
+    static bool tried = false;
+    if (tried) return r.lib ? &r : nullptr;
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) {
+        r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) {
+        std::snprintf(r.why, sizeof(r.why), "cannot load librccl.so.1: %s", dlerror());
+        return nullptr;
+    }
+    bool ok = true;
+    auto sym = [&](const char* name) {
+        void* p = dlsym(r.lib, name);
+        if (!p) { ok = false; std::snprintf(r.why, sizeof(r.why), "librccl lacks %s", name); }
+        return p;
+    };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.Broadcast = (decltype(r.Broadcast))sym("ncclBroadcast");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) { dlclose(r.lib); r.lib = nullptr; return nullptr; }
+    return &r;
+}
+
+int rccl_fail(tpc_mpc_context* h, Rccl* r, ncclResult_t e, const char* what) {
+    return fail(h, TPC_MPC_ERR_COMM, "%s: %s", what, r->GetErrorString(e));
+}
+#define RCCL_TRY(h, r, call)                                          \
+    do {                                                              \
+        ncclResult_t e__ = (call);                                    \
+        if (e__ != ncclSuccess) return rccl_fail(h, r, e__, #call);   \
+    } while (0)
+
+}  // namespace
+
+void comm_destroy(tpc_mpc_context* h) {
+    if (!h || !h->comm) return;
+    Rccl* r = rccl();
+    if (r && h->comm->comm) (void)r->CommDestroy(h->comm->comm);
+    delete h->comm;
+    h->comm = nullptr;
+}
+
+// first instance and count of rank's contiguous block; blocks differ by at most one instance
+static void shard_range(int64_t n, int rank, int world, int64_t* first, int64_t* count) {
+    const int64_t base = n / world, rem = n % world;
+    *count = base + (rank < rem ? 1 : 0);
+    *first = rank * base + (rank < rem ? rank : rem);
+}
+
+}  // namespace tpc
+
+using namespace tpc;
+
+extern "C" {
+
+int tpc_mpc_comm_unique_id(void* id, size_t len) {
+    return guarded(nullptr, [&]() -> int {
+        if (!id || len < TPC_MPC_COMM_ID_BYTES) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "id buffer must hold %d bytes", TPC_MPC_COMM_ID_BYTES);
+        static_assert(TPC_MPC_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+        Rccl* r = rccl();
+        if (!r) return fail(nullptr, TPC_MPC_ERR_COMM, "RCCL is not available in this process: %s", g_rccl.why);
+        ncclUniqueId u;
+        RCCL_TRY(nullptr, r, r->GetUniqueId(&u));
+        std::memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+        return TPC_MPC_OK;
+    });
+}
+
+int tpc_mpc_comm_init_rank(tpc_mpc_handle h, const void* id, size_t len, int rank, int world) {
+    return guarded(h, [&]() -> int {
+        if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+        if (world < 1 || rank < 0 || rank >= world) return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= rank < world");
+        comm_destroy(h);
+        if (world == 1) return TPC_MPC_OK;   // a world of one needs no communicator
+        if (!id || len < TPC_MPC_COMM_ID_BYTES) return fail(h, TPC_MPC_ERR_BAD_ARG, "id must hold %d bytes", TPC_MPC_COMM_ID_BYTES);
+        Rccl* r = rccl();
+        if (!r) return fail(h, TPC_MPC_ERR_COMM, "RCCL is not available in this process: %s", g_rccl.why);
+        HIP_TRY(h, hipSetDevice(h->device));
+        Comm* c = new (std::nothrow) Comm;
+        if (!c) return fail(h, TPC_MPC_ERR_ALLOC, "out of host memory");
+        ncclUniqueId u;
+        std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+        ncclResult_t e = r->CommInitRank(&c->comm, world, u, rank);
+        if (e != ncclSuccess) { delete c; return rccl_fail(h, r, e, "ncclCommInitRank"); }
+        c->rank = rank;
+        c->world = world;
+        h->comm = c;
+        return TPC_MPC_OK;
+    });
+}
+
+int tpc_mpc_comm_destroy(tpc_mpc_handle h) {
+    return guarded(h, [&]() -> int {
+        if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+        (void)hipSetDevice(h->device);
+        comm_destroy(h);
+        return TPC_MPC_OK;
+    });
+}
+
+int tpc_mpc_group_begin(void) {
+    return guarded(nullptr, [&]() -> int {
+        Rccl* r = rccl();
+        if (!r) return fail(nullptr, TPC_MPC_ERR_COMM, "RCCL is not available in this process: %s", g_rccl.why);
+        RCCL_TRY(nullptr, r, r->GroupStart());
+        return TPC_MPC_OK;
+    });
+}
+
+int tpc_mpc_group_end(void) {
+    return guarded(nullptr, [&]() -> int {
+        Rccl* r = rccl();
+        if (!r) return fail(nullptr, TPC_MPC_ERR_COMM, "RCCL is not available in this process: %s", g_rccl.why);
+        RCCL_TRY(nullptr, r, r->GroupEnd());
+        return TPC_MPC_OK;
+    });
+}
+
+int tpc_mpc_shard_range(int64_t n_total, int rank, int world, int64_t* first, int64_t* count) {
+    if (n_total < 0 || world < 1 || rank < 0 || rank >= world || !first || !count) return TPC_MPC_ERR_BAD_ARG;
+    shard_range(n_total, rank, world, first, count);
+    return TPC_MPC_OK;
+}
+
+int tpc_mpc_solve_batch_compact_sharded(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n_total,
+                                        const void* v_shard, const void* delta_y_shard, const void* delta_phi_shard,
+                                        void* steering_front_all, void* steering_rear_all, int32_t* iters_shard,
+                                        uint32_t* flags_out, void* stream) {
+    return guarded(h, [&]() -> int {
+        int rc = check_common(h, p);
+        if (rc) return rc;
+        rc = check_compact_model(h, p);
+        if (rc) return rc;
+        if (n_total < 0 || n_total > 0x7fffffffll) return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= n_total < 2^31");
+        if (n_total == 0) { if (flags_out) *flags_out = 0; return TPC_MPC_OK; }
+        if (!steering_front_all || !steering_rear_all) return fail(h, TPC_MPC_ERR_BAD_ARG, "null batch pointer");
+        const int rank = h->comm ? h->comm->rank : 0, world = h->comm ? h->comm->world : 1;
+        int64_t first = 0, count = 0;
+        shard_range(n_total, rank, world, &first, &count);
+        if (count > 0 && (!v_shard || !delta_y_shard || !delta_phi_shard)) return fail(h, TPC_MPC_ERR_BAD_ARG, "null batch pointer");
+        HIP_TRY(h, hipSetDevice(h->device));
+        hipStream_t s = (hipStream_t)stream;
+        const int64_t es = (int64_t)esize(p->dtype);
+        char* front = (char*)steering_front_all;
+        char* rear = (char*)steering_rear_all;
+        rc = stream_order_begin(h, s);
+        if (rc) return rc;
+        HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
+        // this rank's block is solved straight into its slot of the full-size outputs
+        if (count > 0) {
+            rc = compact_launch(h, p, count, v_shard, delta_y_shard, delta_phi_shard, front + first * es, rear + first * es,
+                                iters_shard, s);
+            if (rc) return rc;
+        }
+        if (world > 1) {
+            Rccl* r = rccl();
+            if (!r) return fail(h, TPC_MPC_ERR_COMM, "RCCL is not available in this process: %s", g_rccl.why);
+            const ncclDataType_t dt = p->dtype == TPC_MPC_F64 ? ncclFloat64 : ncclFloat32;
+            ncclComm_t c = h->comm->comm;
+            RCCL_TRY(h, r, r->GroupStart());
+            if (n_total % world == 0) {
+                // equal blocks: two in-place all-gathers (each rank's send buffer IS its slot of the receive buffer)
+                RCCL_TRY(h, r, r->AllGather(front + first * es, front, (size_t)count, dt, c, s));
+                RCCL_TRY(h, r, r->AllGather(rear + first * es, rear, (size_t)count, dt, c, s));
+            } else {
+                // ragged blocks: the all-gather spelled as one in-place broadcast per owner, fused by the group
+                for (int q = 0; q < world; ++q) {
+                    int64_t qf = 0, qc = 0;
+                    shard_range(n_total, q, world, &qf, &qc);
+                    if (qc == 0) continue;
+                    RCCL_TRY(h, r, r->Broadcast(front + qf * es, front + qf * es, (size_t)qc, dt, q, c, s));
+                    RCCL_TRY(h, r, r->Broadcast(rear + qf * es, rear + qf * es, (size_t)qc, dt, q, c, s));
+                }
+            }
+            RCCL_TRY(h, r, r->GroupEnd());
+        }
+        rc = stream_order_end(h, s);
+        if (rc) return rc;
+        return finish_flags(h, flags_out, s);
+    });
+}
+
+}  // extern "C"

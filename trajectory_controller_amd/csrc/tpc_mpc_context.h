@@ -1,0 +1,147 @@
+// The handle behind tpc_mpc_handle and the helpers every C-ABI translation unit shares
+// (tpc_mpc_api.cpp, tpc_mpc_mixed.hip, tpc_mpc_comm.cpp, tpc_mpc_one.hip).  Internal: nothing here is
+// visible through include/tpc_mpc.h.
+#pragma once
+
+#include "../../include/tpc_mpc.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <exception>
+#include <new>
+
+#include "mpc_internal.h"
+
+namespace tpc {
+struct OneShot;   // tpc_mpc_one.hip: the resident single-solve kernel's host side
+struct Comm;      // tpc_mpc_comm.cpp: RCCL communicator of a sharded solve
+}  // namespace tpc
+
+// Error text lives in fixed buffers: reporting an error never allocates, so it cannot throw.
+constexpr size_t kTpcErrLen = 512;
+
+struct tpc_mpc_context {
+    int device = 0;
+    int cu_count = 0;
+    char err[kTpcErrLen] = "";
+    // device scratch (grown on demand, never shrunk)
+    void* ws_state = nullptr;
+    int64_t ws_bytes = 0;
+    uint32_t* ws_words = nullptr;   // [0] ticket, [1] flags, [4..] lane statistics
+    // staging for TPC_MPC_HOST batches
+    void* stage = nullptr;
+    int64_t stage_bytes = 0;
+    // working set of tpc_mpc_rollout / tpc_mpc_follow_batch* (model copy, state, targets, controller memory)
+    void* roll = nullptr;
+    int64_t roll_bytes = 0;
+    // mixed-horizon batches: bin-contiguous copies of the inputs and outputs, permutation, counters
+    void* mix = nullptr;
+    int64_t mix_bytes = 0;
+    // pinned host memory mapped into the device: solve_one's mailbox (tpc_mpc_one.hip)
+    void* pin_host = nullptr;
+    void* pin_dev = nullptr;
+    tpc::OneShot* one = nullptr;
+    // queue-order hint for the next batch solve (tpc_mpc_set_work_hint): always the handle's own copy
+    const int32_t* hint = nullptr;
+    int64_t hint_n = 0;
+    void* hint_own = nullptr;
+    int64_t hint_own_bytes = 0;
+    // internal single solves have no flags output: they skip the flag word's memset and atomicOr
+    bool collect_flags = true;
+    // optional kernel timing (tpc_mpc_set_profiling)
+    bool profiling = false;
+    bool ev_valid = false;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    int last_algo = 0;
+    // All solves of a handle share its scratch, so they must not overlap.  The handle remembers the
+    // stream of its last solve and an event recorded behind it; a solve submitted to a different
+    // stream first makes that stream wait for the event (tpc_mpc_api.cpp, StreamOrder).
+    hipEvent_t done_ev = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
+    // sharded solves (tpc_mpc_comm.cpp); null = a world of one
+    tpc::Comm* comm = nullptr;
+};
+
+namespace tpc {
+
+extern thread_local char g_create_error[kTpcErrLen];   // last failed call without a handle, per thread
+
+__attribute__((format(printf, 3, 4))) inline int fail(tpc_mpc_context* h, int code, const char* fmt, ...) noexcept {
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(h ? h->err : g_create_error, kTpcErrLen, fmt, ap);
+    va_end(ap);
+    return code;
+}
+inline int hip_fail(tpc_mpc_context* h, hipError_t e, const char* what) noexcept {
+    return fail(h, TPC_MPC_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+#define HIP_TRY(h, call)                                              \
+    do {                                                              \
+        hipError_t e__ = (call);                                      \
+        if (e__ != hipSuccess) return ::tpc::hip_fail(h, e__, #call); \
+    } while (0)
+
+// Every extern "C" body runs inside this: whatever a C++ runtime call might throw (std::bad_alloc
+// from the HIP runtime's own containers included) is turned into a status code here and never
+// crosses the C boundary (include/tpc_mpc.h, Conventions).
+template <class F> int guarded(tpc_mpc_context* h, F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(h, TPC_MPC_ERR_ALLOC, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(h, TPC_MPC_ERR_HIP, "unexpected exception: %s", e.what());
+    } catch (...) {
+        return fail(h, TPC_MPC_ERR_HIP, "unexpected exception");
+    }
+}
+
+inline size_t esize(int dtype) { return dtype == TPC_MPC_F64 ? 8 : 4; }
+inline int64_t pad256(int64_t bytes) { return (bytes + 255) / 256 * 256; }
+
+// Grow-only device buffer.  Growing frees and allocates, which synchronises the device.
+inline int ensure(tpc_mpc_context* h, void** buf, int64_t* have, int64_t need) {
+    if (need <= *have) return TPC_MPC_OK;
+    if (*buf) {
+        hipError_t e = hipFree(*buf);
+        *buf = nullptr;
+        *have = 0;
+        if (e != hipSuccess) return hip_fail(h, e, "hipFree");
+    }
+    const int64_t grow = need + need / 4 + 4096;
+    hipError_t e = hipMalloc(buf, (size_t)grow);
+    if (e != hipSuccess) {
+        *buf = nullptr;
+        (void)hipGetLastError();   // the failed allocation must not poison the next launch check
+        return fail(h, TPC_MPC_ERR_ALLOC, "hipMalloc of %lld bytes: %s", (long long)grow, hipGetErrorString(e));
+    }
+    *have = grow;
+    return TPC_MPC_OK;
+}
+
+// ---- shared between the C-ABI translation units (defined in tpc_mpc_api.cpp) --------------------
+int check_common(tpc_mpc_context* h, const tpc_mpc_params* p);
+int check_compact_model(tpc_mpc_context* h, const tpc_mpc_params* p);
+int stream_order_begin(tpc_mpc_context* h, hipStream_t s);
+int stream_order_end(tpc_mpc_context* h, hipStream_t s);
+int finish_flags(tpc_mpc_context* h, uint32_t* flags_out, hipStream_t s);
+// n instances of the compact form, arrays in DEVICE memory, launches only (no flag reset, no
+// stream-order bookkeeping, no synchronisation): the core of every compact entry point.
+int compact_launch(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy,
+                   const void* dphi, void* front, void* rear, int32_t* iters, hipStream_t s);
+// scratch of the LANE family for (H, dtype, n), without launching (grows the handle's workspace)
+int reserve_lane_workspace(tpc_mpc_context* h, int H, int dtype, int64_t n);
+
+// tpc_mpc_one.hip
+int one_shot_solve(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double dy, double dphi, double* front,
+                   double* rear);
+void one_shot_destroy(tpc_mpc_context* h);
+// tpc_mpc_comm.cpp
+void comm_destroy(tpc_mpc_context* h);
+
+}  // namespace tpc

@@ -1,0 +1,287 @@
+// tpc_mpc_solve_one: the reference's real configuration is ONE horizon-4 solve per cycle()
+// (reference: include/trajectory_point_follower.h:48, src/trajectory_point_follower.cpp:366-380),
+// about 5 us of dlib on a CPU core.  A kernel launch plus a stream synchronisation alone cost several
+// times that, so single solves are served by a RESIDENT kernel: one wavefront that stays on the GPU
+// and takes requests through a mailbox in pinned host memory mapped into the device.
+//
+//   host   writes the request (solver knobs, model constants, v, dy, dphi) into three 64-byte lines
+//          of the mailbox, each line ending in the request's sequence number, and presets the two
+//          output words to a NaN no solve produces
+//   wave   polls the three lines with ONE wave-wide uncached load per poll (24 lanes x 8 bytes); a
+//          request is taken when all three lines carry the same new sequence number (a PCIe read
+//          returns a cache line as it stood at one instant and the host writes a line's number last,
+//          so a line with the new number carries the new payload); solves it with the WAVE algorithm
+//          (mpc_wave.h: one decision variable per lane) and stores front and rear straight into the
+//          mailbox
+//   host   spins on the two output words
+//
+// so a solve costs one PCIe read round trip, the solve, and one posted write: no launch, no
+// synchronisation call, no fence.
+//
+// The wave never outlives its use: it exits when told to (tpc_mpc_destroy), after `idle_us` without
+// a request (default 20 ms: longer than the cycle of a 50 Hz control loop, short enough that a
+// device-wide synchronisation elsewhere in the process -- which has to wait for every running
+// kernel -- is not held up noticeably), and after a fixed number of polls whatever the clocks say.
+// The host notices (`alive` word) and starts a new one with the next request.  Horizons the WAVE
+// kernel cannot take (2*H > 64), fp32 and TPC_MPC_ALGO_LANE go through an ordinary launch.
+#include "tpc_mpc_context.h"
+
+#include <chrono>
+
+#include "mpc_wave.h"
+
+namespace tpc {
+
+namespace {
+
+// ---- mailbox layout: 8-byte words of the handle's 256-byte pinned block -----------------------
+// line 0 (host -> device): words 0..6 payload, word 7 seq
+// line 1 (host -> device): words 8..14 payload, word 15 seq
+// line 2 (host -> device): words 16..22 payload, word 23 seq
+// line 3 (device -> host): word 24 front, word 25 rear, word 26 alive
+enum : int {
+    kW_HorizonQuit = 0,   // low 32 bits horizon, high 32 bits quit flag
+    kW_Iters = 1,         // low 32 bits max_iter, high 32 bits smo_iters
+    kW_Eps = 2, kW_Step = 3, kW_Wheelbase = 4, kW_Q0 = 5, kW_Q1 = 6, kW_Seq0 = 7,
+    kW_R0 = 8, kW_R1 = 9, kW_Lo0 = 10, kW_Lo1 = 11, kW_Hi0 = 12, kW_Hi1 = 13, kW_V = 14, kW_Seq1 = 15,
+    kW_Dy = 16, kW_Dphi = 17, kW_Seq2 = 23,
+    kW_Front = 24, kW_Rear = 25, kW_Alive = 26,
+    kReqWords = 24,
+};
+constexpr uint64_t kSentinel = 0x7ff8dead5eedc0deull;   // a NaN payload no solve produces
+constexpr uint32_t kMaxPolls = 1u << 26;                // backstop: ~1 us per poll -> about a minute
+
+TPC_DEV uint64_t sys_load(const uint64_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+TPC_DEV void sys_store(uint64_t* p, uint64_t x) {
+    __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <int H>
+TPC_DEV void solve_h(const CompactArgs& g, const Knobs& kn, double* s_u, double* s_w) {
+    wave_solve<double, 2, H, CompactModel<double>, CompactArgs>(g, kn, 0, s_u, s_w);
+}
+
+__global__ __launch_bounds__(64) void one_shot_kernel(uint64_t* mail, uint64_t start_seq, uint64_t idle_ticks) {
+    __shared__ __attribute__((aligned(16))) double s_u[kWave + 2];
+    __shared__ __attribute__((aligned(16))) double s_w[kWave];
+    __shared__ __attribute__((aligned(16))) uint64_t s_req[kReqWords + 2];   // the request, then front, rear
+    const int lane = threadIdx.x;
+    uint64_t seen = start_seq;
+    uint64_t idle_since = wall_clock64();   // 100 MHz
+    for (uint32_t polls = 0; polls < kMaxPolls; ++polls) {
+        // one wave-wide uncached read of the three request lines
+        const uint64_t word = lane < kReqWords ? sys_load(mail + lane) : 0ull;
+        const uint64_t q0 = __shfl(word, kW_Seq0), q1 = __shfl(word, kW_Seq1), q2 = __shfl(word, kW_Seq2);
+        if (q0 == seen || q0 != q1 || q0 != q2) {
+            if (wall_clock64() - idle_since > idle_ticks) break;
+            continue;
+        }
+        seen = q0;
+        if (lane < kReqWords) s_req[lane] = word;
+        __syncthreads();
+        const uint64_t hq = s_req[kW_HorizonQuit];
+        if ((uint32_t)(hq >> 32) != 0u) break;   // told to quit
+        const int horizon = (int)(uint32_t)hq;
+        const double* rq = (const double*)s_req;
+        CompactArgs g;
+        g.n = 1;
+        g.v = rq + kW_V; g.dy = rq + kW_Dy; g.dphi = rq + kW_Dphi;       // LDS, through generic pointers
+        g.front = (double*)s_req + kReqWords; g.rear = (double*)s_req + kReqWords + 1;
+        g.iters = nullptr; g.flags = nullptr; g.work_hint = nullptr;
+        g.step = rq[kW_Step]; g.wheelbase = rq[kW_Wheelbase];
+        g.q[0] = rq[kW_Q0]; g.q[1] = rq[kW_Q1]; g.r[0] = rq[kW_R0]; g.r[1] = rq[kW_R1];
+        g.lo[0] = rq[kW_Lo0]; g.lo[1] = rq[kW_Lo1]; g.hi[0] = rq[kW_Hi0]; g.hi[1] = rq[kW_Hi1];
+        Knobs kn;
+        kn.eps = rq[kW_Eps];
+        kn.max_iter = (uint32_t)s_req[kW_Iters];
+        kn.smo_iters = (uint32_t)(s_req[kW_Iters] >> 32);
+        switch (horizon) {
+            case 4: solve_h<4>(g, kn, s_u, s_w); break;
+            case 5: solve_h<5>(g, kn, s_u, s_w); break;
+            case 10: solve_h<10>(g, kn, s_u, s_w); break;
+            case 20: solve_h<20>(g, kn, s_u, s_w); break;
+            case 30: solve_h<30>(g, kn, s_u, s_w); break;
+            default: s_req[kReqWords] = s_req[kReqWords + 1] = 0x7ff8000000000bad; break;   // host never asks
+        }
+        __syncthreads();
+        // two 8-byte stores, each atomic for the host: they are the completion signal
+        if (lane < 2) sys_store(mail + kW_Front + lane, s_req[kReqWords + lane]);
+        __syncthreads();
+        idle_since = wall_clock64();
+        polls = 0;
+    }
+    if (lane == 0) sys_store(mail + kW_Alive, 0ull);
+}
+
+}  // namespace
+
+struct OneShot {
+    hipStream_t stream = nullptr;
+    uint64_t seq = 0;
+    uint64_t idle_us = 20000;
+    bool disabled = false;   // set after a resident kernel failed to answer: ordinary launches from then on
+};
+
+namespace {
+
+inline volatile uint64_t* mailbox(tpc_mpc_context* h) { return (volatile uint64_t*)h->pin_host; }
+
+int start_kernel(tpc_mpc_context* h, OneShot* o, uint64_t start_seq) {
+    volatile uint64_t* m = mailbox(h);
+    m[kW_Alive] = 1;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    hipLaunchKernelGGL(one_shot_kernel, dim3(1), dim3(kWave), 0, o->stream, (uint64_t*)h->pin_dev, start_seq,
+                       o->idle_us * 100ull);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { m[kW_Alive] = 0; return hip_fail(h, e, "resident kernel launch"); }
+    return TPC_MPC_OK;
+}
+
+// The pre-resident path: one WAVE/LANE launch through the handle's mapped block, polled the same way.
+int launch_path(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double dy, double dphi, double* front, double* rear) {
+    tpc_mpc_params q = *p;
+    if (q.algo == TPC_MPC_ALGO_AUTO && 2 * q.horizon <= kWave) q.algo = TPC_MPC_ALGO_WAVE;   // one instance: one wavefront
+    const size_t es = esize(q.dtype);
+    char* hp = (char*)h->pin_host + 32 * 8;   // words 32..: apart from the resident kernel's lines
+    char* dp = (char*)h->pin_dev + 32 * 8;
+    // wait for no resident solve here: they are synchronous, none is in flight
+    if (q.dtype == TPC_MPC_F64) { double* x = (double*)hp; x[0] = v; x[1] = dy; x[2] = dphi; }
+    else { float* x = (float*)hp; x[0] = (float)v; x[1] = (float)dy; x[2] = (float)dphi; }
+    const uint64_t sentinel64 = kSentinel;
+    const uint32_t sentinel32 = 0x7fc5eed1u;
+    if (q.dtype == TPC_MPC_F64) { std::memcpy(hp + 3 * es, &sentinel64, 8); std::memcpy(hp + 4 * es, &sentinel64, 8); }
+    else { std::memcpy(hp + 3 * es, &sentinel32, 4); std::memcpy(hp + 4 * es, &sentinel32, 4); }
+    int rc = stream_order_begin(h, nullptr);
+    if (rc) return rc;
+    h->collect_flags = false;
+    rc = compact_launch(h, &q, 1, dp, dp + es, dp + 2 * es, dp + 3 * es, dp + 4 * es, nullptr, nullptr);
+    h->collect_flags = true;
+    if (rc) return rc;
+    rc = stream_order_end(h, nullptr);
+    if (rc) return rc;
+    bool done = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int it = 0; !done; ++it) {
+        if (q.dtype == TPC_MPC_F64) {
+            const volatile uint64_t* o = (const volatile uint64_t*)(hp + 3 * es);
+            done = o[0] != sentinel64 && o[1] != sentinel64;
+        } else {
+            const volatile uint32_t* o = (const volatile uint32_t*)(hp + 3 * es);
+            done = o[0] != sentinel32 && o[1] != sentinel32;
+        }
+        if (!done && (it & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    if (!done) HIP_TRY(h, hipStreamSynchronize(nullptr));
+    if (q.dtype == TPC_MPC_F64) { *front = ((double*)hp)[3]; *rear = ((double*)hp)[4]; }
+    else { *front = ((float*)hp)[3]; *rear = ((float*)hp)[4]; }
+    return TPC_MPC_OK;
+}
+
+}  // namespace
+
+void one_shot_destroy(tpc_mpc_context* h) {
+    if (!h || !h->one) return;
+    OneShot* o = h->one;
+    volatile uint64_t* m = mailbox(h);
+    if (o->stream) {
+        if (m[kW_Alive]) {   // ask the wave to leave: a request whose quit flag is set
+            const uint64_t seq = ++o->seq;
+            m[kW_HorizonQuit] = 1ull << 32;
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            m[kW_Seq0] = seq; m[kW_Seq1] = seq; m[kW_Seq2] = seq;
+        }
+        (void)hipStreamSynchronize(o->stream);   // bounded: quit flag, idle timeout, poll cap
+        (void)hipStreamDestroy(o->stream);
+    }
+    delete o;
+    h->one = nullptr;
+}
+
+int one_shot_configure(tpc_mpc_context* h, int64_t idle_us) {
+    if (!h->one) {
+        h->one = new (std::nothrow) OneShot;
+        if (!h->one) return fail(h, TPC_MPC_ERR_ALLOC, "out of host memory");
+    }
+    OneShot* o = h->one;
+    if (idle_us <= 0) {   // resident mode off: stop a running wave, keep the launch path
+        volatile uint64_t* m = mailbox(h);
+        if (o->stream && m[kW_Alive]) {
+            const uint64_t seq = ++o->seq;
+            m[kW_HorizonQuit] = 1ull << 32;
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            m[kW_Seq0] = seq; m[kW_Seq1] = seq; m[kW_Seq2] = seq;
+            HIP_TRY(h, hipStreamSynchronize(o->stream));
+        }
+        o->disabled = true;
+        return TPC_MPC_OK;
+    }
+    o->disabled = false;
+    o->idle_us = (uint64_t)idle_us;
+    return TPC_MPC_OK;
+}
+
+int one_shot_solve(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double dy, double dphi, double* front, double* rear) {
+    if (!h->one) {
+        int rc = one_shot_configure(h, 20000);
+        if (rc) return rc;
+    }
+    OneShot* o = h->one;
+    const bool resident_ok = !o->disabled && p->dtype == TPC_MPC_F64 && p->algo != TPC_MPC_ALGO_LANE &&
+                             2 * p->horizon <= kWave;
+    if (!resident_ok) return launch_path(h, p, v, dy, dphi, front, rear);
+    if (!o->stream) HIP_TRY(h, hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking));
+    volatile uint64_t* m = mailbox(h);
+    auto put = [&](int w, double x) { uint64_t b; std::memcpy(&b, &x, 8); m[w] = b; };
+    const uint64_t prev = o->seq, seq = ++o->seq;
+    m[kW_HorizonQuit] = (uint64_t)(uint32_t)p->horizon;
+    m[kW_Iters] = (uint64_t)(uint32_t)p->max_iter | ((uint64_t)(uint32_t)p->smo_iters << 32);
+    put(kW_Eps, p->eps); put(kW_Step, p->step_size); put(kW_Wheelbase, p->wheelbase);
+    put(kW_Q0, p->weight_y); put(kW_Q1, p->weight_phi);
+    put(kW_R0, p->weight_steering_front); put(kW_R1, p->weight_steering_rear);
+    put(kW_Lo0, p->lower[0]); put(kW_Lo1, p->lower[1]); put(kW_Hi0, p->upper[0]); put(kW_Hi1, p->upper[1]);
+    put(kW_V, v); put(kW_Dy, dy); put(kW_Dphi, dphi);
+    m[kW_Front] = kSentinel; m[kW_Rear] = kSentinel;
+    __atomic_thread_fence(__ATOMIC_RELEASE);   // payload before the numbers (x86 keeps store order; this stops the compiler)
+    m[kW_Seq0] = seq; m[kW_Seq1] = seq; m[kW_Seq2] = seq;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    if (!m[kW_Alive]) {
+        int rc = start_kernel(h, o, prev);   // it finds the request already waiting
+        if (rc) return rc;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    int restarts = 0;
+    for (uint32_t it = 1;; ++it) {
+        if (m[kW_Front] != kSentinel && m[kW_Rear] != kSentinel) break;
+        if ((it & 1023u) != 0) continue;
+        if (!m[kW_Alive]) {
+            // the wave left (idle timeout) just as the request was posted: start another one for it
+            if (m[kW_Front] != kSentinel && m[kW_Rear] != kSentinel) break;
+            if (++restarts > 3) { o->disabled = true; return launch_path(h, p, v, dy, dphi, front, rear); }
+            int rc = start_kernel(h, o, prev);
+            if (rc) return rc;
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            o->disabled = true;   // never spin for ever: fall back to ordinary launches for this handle
+            return fail(h, TPC_MPC_ERR_HIP, "the resident solve_one kernel did not answer within 2 s");
+        }
+    }
+    uint64_t fb = m[kW_Front], rb = m[kW_Rear];
+    std::memcpy(front, &fb, 8);
+    std::memcpy(rear, &rb, 8);
+    return TPC_MPC_OK;
+}
+
+}  // namespace tpc
+
+using namespace tpc;
+
+extern "C" int tpc_mpc_set_resident(tpc_mpc_handle h, int64_t idle_timeout_us) {
+    return guarded(h, [&]() -> int {
+        if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+        if (idle_timeout_us > 10 * 1000 * 1000) return fail(h, TPC_MPC_ERR_BAD_ARG, "idle timeout above 10 s");
+        HIP_TRY(h, hipSetDevice(h->device));
+        return one_shot_configure(h, idle_timeout_us);
+    });
+}

@@ -103,6 +103,15 @@ class MpcSolver:
 
     solve_one = mpc_controller_tobi
 
+    def set_resident(self, idle_timeout_us: int = 20000):
+        """solve_one's resident wavefront: idle timeout in microseconds, <= 0 turns it off
+        (tpc_mpc_set_resident)."""
+        self._check(self._lib.tpc_mpc_set_resident(self._h, int(idle_timeout_us)))
+
+    @staticmethod
+    def build_info() -> str:
+        return capi.load_library().tpc_mpc_build_info().decode()
+
     # -- batches ----------------------------------------------------------------------------------
     def reserve(self, n: int, host: bool = False, **over):
         """Allocate the device scratch for compact batches of up to n instances now
@@ -167,38 +176,85 @@ class MpcSolver:
         return (front, rear, iters) if want_iters else (front, rear)
 
     def solve_batch_compact_mixed(self, horizons, v, delta_y, delta_phi, want_iters: bool = False, **over):
-        """Mixed-horizon batch (BASELINE config 5): instance k is solved with horizon horizons[k].
-        Instances are binned by horizon and each bin goes out as one launch (the kernels are
-        specialised per horizon); results come back in the caller's order.  Arrays as in
-        solve_batch_compact; `horizons` is an integer array/tensor of the same length."""
-        torch_mode = _is_torch(v)
-        if torch_mode:
+        """Mixed-horizon batch (BASELINE config 5): instance k is solved with horizon horizons[k]
+        (tpc_mpc_solve_batch_compact_mixed: binned by horizon on the device, one launch sequence per
+        bin, results back in the caller's order).  Arrays as in solve_batch_compact; `horizons` is an
+        integer array/tensor of the same length."""
+        p = self._params(**over)
+        flags = C.c_uint32(0)
+        if _is_torch(v):
             import torch
-            hz = torch.as_tensor(horizons, device=v.device)
+            tdt = torch.float64 if p.dtype == capi.F64 else torch.float32
+            n = v.numel()
+            for t in (v, delta_y, delta_phi):
+                if not (t.is_cuda and t.dtype == tdt and t.is_contiguous() and t.numel() == n):
+                    raise ValueError("device batch arrays must be contiguous CUDA tensors of the solver dtype")
+            hz = torch.as_tensor(horizons, device=v.device).to(torch.int32).contiguous()
+            if hz.numel() != n:
+                raise ValueError("horizons must have one entry per instance")
             front, rear = torch.empty_like(v), torch.empty_like(v)
-            iters = torch.empty(v.numel(), dtype=torch.int32, device=v.device) if want_iters else None
-            uniq = [int(h) for h in torch.unique(hz).tolist()]
-            pick = lambda h: torch.nonzero(hz == h, as_tuple=False).flatten()
-            take = lambda a, idx: a[idx].contiguous()
+            iters = torch.empty(n, dtype=torch.int32, device=v.device) if want_iters else None
+            stream = torch.cuda.current_stream(v.device).cuda_stream
+            self._check(self._lib.tpc_mpc_solve_batch_compact_mixed(
+                self._h, C.byref(p), n, hz.data_ptr(), v.data_ptr(), delta_y.data_ptr(), delta_phi.data_ptr(),
+                front.data_ptr(), rear.data_ptr(), iters.data_ptr() if want_iters else None,
+                C.byref(flags), capi.DEVICE, C.c_void_p(stream)))
         else:
-            hz = np.asarray(horizons)
-            v, delta_y, delta_phi = (np.ascontiguousarray(a, dtype=_NP[self._params(**over).dtype])
-                                     for a in (v, delta_y, delta_phi))
-            front, rear = np.empty_like(v), np.empty_like(v)
-            iters = np.empty(v.shape[0], dtype=np.int32) if want_iters else None
-            uniq = [int(h) for h in np.unique(hz)]
-            pick = lambda h: np.nonzero(hz == h)[0]
-            take = lambda a, idx: np.ascontiguousarray(a[idx])
-        flags = 0
-        for h in uniq:
-            idx = pick(h)
-            out = self.solve_batch_compact(take(v, idx), take(delta_y, idx), take(delta_phi, idx),
-                                           want_iters=want_iters, horizon=h, **over)
-            flags |= self.last_flags
-            front[idx], rear[idx] = out[0], out[1]
-            if want_iters:
-                iters[idx] = out[2]
-        self.last_flags = flags
+            dt = _NP[p.dtype]
+            v, delta_y, delta_phi = (np.ascontiguousarray(a, dtype=dt) for a in (v, delta_y, delta_phi))
+            n = v.shape[0]
+            hz = np.ascontiguousarray(horizons, dtype=np.int32)
+            if hz.shape[0] != n:
+                raise ValueError("horizons must have one entry per instance")
+            front, rear = np.empty(n, dtype=dt), np.empty(n, dtype=dt)
+            iters = np.empty(n, dtype=np.int32) if want_iters else None
+            self._check(self._lib.tpc_mpc_solve_batch_compact_mixed(
+                self._h, C.byref(p), n, hz.ctypes.data, v.ctypes.data, delta_y.ctypes.data, delta_phi.ctypes.data,
+                front.ctypes.data, rear.ctypes.data, iters.ctypes.data if want_iters else None,
+                C.byref(flags), capi.HOST, None))
+        self.last_flags = flags.value
+        return (front, rear, iters) if want_iters else (front, rear)
+
+    # -- sharding over the GPUs of a node ----------------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128-byte communicator id (rank 0 makes it, the host hands it to every rank)."""
+        lib = capi.load_library()
+        buf = (C.c_char * capi.COMM_ID_BYTES)()
+        rc = lib.tpc_mpc_comm_unique_id(buf, capi.COMM_ID_BYTES)
+        if rc != capi.OK:
+            raise capi.TpcMpcError(rc, lib.tpc_mpc_last_error(None).decode())
+        return bytes(buf)
+
+    def comm_init(self, comm_id: bytes, rank: int, world: int):
+        """Join the job's RCCL communicator as `rank` of `world` (tpc_mpc_comm_init_rank)."""
+        buf = (C.c_char * capi.COMM_ID_BYTES).from_buffer_copy(bytes(comm_id).ljust(capi.COMM_ID_BYTES, b"\0"))
+        self._check(self._lib.tpc_mpc_comm_init_rank(self._h, buf, capi.COMM_ID_BYTES, int(rank), int(world)))
+        self.rank, self.world = int(rank), int(world)
+
+    def solve_batch_compact_sharded(self, n_total: int, v_shard, dy_shard, dphi_shard, out=None,
+                                    want_iters: bool = False, want_flags: bool = False, **over):
+        """This rank's block of a batch of n_total, then the all-gather of the control outputs over
+        RCCL (tpc_mpc_solve_batch_compact_sharded).  Device tensors; returns full-size (front, rear)."""
+        import torch
+        p = self._params(**over)
+        tdt = torch.float64 if p.dtype == capi.F64 else torch.float32
+        for t in (v_shard, dy_shard, dphi_shard):
+            if not (t.is_cuda and t.dtype == tdt and t.is_contiguous()):
+                raise ValueError("shard arrays must be contiguous CUDA tensors of the solver dtype")
+        if out is None:
+            front = torch.empty(n_total, dtype=tdt, device=v_shard.device)
+            rear = torch.empty(n_total, dtype=tdt, device=v_shard.device)
+        else:
+            front, rear = out
+        iters = torch.empty(v_shard.numel(), dtype=torch.int32, device=v_shard.device) if want_iters else None
+        flags = C.c_uint32(0)
+        stream = torch.cuda.current_stream(v_shard.device).cuda_stream
+        self._check(self._lib.tpc_mpc_solve_batch_compact_sharded(
+            self._h, C.byref(p), int(n_total), v_shard.data_ptr(), dy_shard.data_ptr(), dphi_shard.data_ptr(),
+            front.data_ptr(), rear.data_ptr(), iters.data_ptr() if want_iters else None,
+            C.byref(flags) if want_flags else None, C.c_void_p(stream)))
+        self.last_flags = flags.value
         return (front, rear, iters) if want_iters else (front, rear)
 
     def solve_batch_general(self, A, B, Cc, Q, R, lower, upper, x0, targets, controls=None,
@@ -360,3 +416,49 @@ class MpcSolver:
                                                    C.byref(flags), stream))
         self.last_flags = flags.value
         return (front, rear, tspeed, tdist, iters) if want_iters else (front, rear, tspeed, tdist)
+
+    def follow_batch_horizon(self, pos_x, pos_y, dir_x, dir_y, velocity, count, car_velocity, look_ahead,
+                             step_spacing=None, lookup=None, want_iters: bool = False,
+                             want_targets: bool = False, **over):
+        """follow_batch with one trajectory point per horizon step (tpc_mpc_follow_batch_horizon):
+        step t's target is the polyline point at arc length look_ahead + t * spacing.  step_spacing:
+        optional float32 CUDA tensor [n] (None: |v| * step_size).  Returns (front, rear, target_speed,
+        target_distance[, targets f64 [2H, n]][, iters])."""
+        import torch
+        p = self._params(**over)
+        P, n = pos_x.shape
+        dev = pos_x.device
+        for tns in (pos_x, pos_y, dir_x, dir_y, velocity):
+            if not (tns.is_cuda and tns.dtype == torch.float32 and tns.is_contiguous() and tuple(tns.shape) == (P, n)):
+                raise ValueError("trajectory arrays must be contiguous float32 CUDA tensors [max_points, n]")
+        per = [(count, torch.int32), (car_velocity, torch.float32), (look_ahead, torch.float32)]
+        if step_spacing is not None:
+            per.append((step_spacing, torch.float32))
+        for tns, dt in per:
+            if not (tns.is_cuda and tns.dtype == dt and tns.is_contiguous() and tns.numel() == n):
+                raise ValueError("per-instance arrays must be contiguous CUDA tensors of length n")
+        tr = capi.Trajectories(n=n, ld=n, max_points=P, pos_x=pos_x.data_ptr(), pos_y=pos_y.data_ptr(),
+                               dir_x=dir_x.data_ptr(), dir_y=dir_y.data_ptr(), velocity=velocity.data_ptr(),
+                               count=count.data_ptr(), car_velocity=car_velocity.data_ptr(),
+                               look_ahead=look_ahead.data_ptr())
+        front = torch.empty(n, dtype=torch.float64, device=dev)
+        rear = torch.empty(n, dtype=torch.float64, device=dev)
+        tspeed = torch.empty(n, dtype=torch.float32, device=dev)
+        tdist = torch.empty(n, dtype=torch.float32, device=dev)
+        targets = torch.empty((2 * p.horizon, n), dtype=torch.float64, device=dev) if want_targets else None
+        iters = torch.empty(n, dtype=torch.int32, device=dev) if want_iters else None
+        lx, ly, ln = (None, None, 0) if lookup is None else (lookup[0].data_ptr(), lookup[1].data_ptr(), lookup[0].numel())
+        flags = C.c_uint32(0)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        self._check(self._lib.tpc_mpc_follow_batch_horizon(
+            self._h, C.byref(p), C.byref(tr), step_spacing.data_ptr() if step_spacing is not None else None,
+            lx, ly, ln, front.data_ptr(), rear.data_ptr(), tspeed.data_ptr(), tdist.data_ptr(),
+            targets.data_ptr() if want_targets else None, iters.data_ptr() if want_iters else None,
+            C.byref(flags), stream))
+        self.last_flags = flags.value
+        out = [front, rear, tspeed, tdist]
+        if want_targets:
+            out.append(targets)
+        if want_iters:
+            out.append(iters)
+        return tuple(out)

@@ -431,7 +431,13 @@ template <int H> struct RefillBatch { static constexpr int value = TPC_REFILL_BA
 template <int H> struct RefillBatch { static constexpr int value = H <= 5 ? 24 : (H <= 10 ? 6 : 3); };
 #endif
 template <typename T, int H> struct FusedInRegs { static constexpr bool value = H * (int)sizeof(T) <= 80; };
-template <typename T, int H> struct FusedVRegSteps { static constexpr int value = (sizeof(T) == 8 && H == 20) ? 8 : 0; };
+#ifdef TPC_KV_STEPS   // A/B override: horizon steps of v kept in VGPRs by the LDS/AGPR plans
+template <typename T, int H> struct FusedVRegSteps { static constexpr int value = FusedInRegs<T, H>::value ? 0 : TPC_KV_STEPS; };
+#else
+template <typename T, int H> struct FusedVRegSteps {
+    static constexpr int value = sizeof(T) != 8 ? 0 : ((H == 20 || H == 30 || H == 40) ? 8 : 0);
+};
+#endif
 template <typename T, int H> struct FusedOcc { static constexpr int value = FusedInRegs<T, H>::value ? 2 : 1; };
 // fp64, H = 30: u (120 words) fits the VGPRs, but MM and v in LDS take 61 KB per wave and leave two
 // of a CU's four SIMDs without a wave.  The forward-pass array w and all of v go to AGPRs instead
@@ -441,7 +447,17 @@ template <typename T, int H> struct FusedOcc { static constexpr int value = Fuse
 // waves per CU, w spilled by the compiler): only 20 steps of v fit the AGPRs next to w, LDS still
 // allows two waves only, and the moves are pure cost.
 template <typename T, int H> struct FusedBig { static constexpr bool value = sizeof(T) == 8 && H == 30; };
-template <typename T, int H> struct FusedAgprSteps { static constexpr int value = FusedBig<T, H>::value ? H : 0; };
+// fp64, H = 40, compact model: the state of one instance is 4 x 80 doubles = 640 registers' worth,
+// against 512 registers per lane plus 160 of LDS per lane when all four SIMDs of a CU hold a wave --
+// it does not fit.  Round 1 kept MM and v in LDS (80 KB per wave: two waves per CU, half the SIMDs
+// idle) and let the compiler spill w: 10.2 us per iteration.  Here the forward-pass array w is
+// CHECKPOINTED instead: only the even steps are kept (in AGPRs), and the backward pass recomputes
+// M[i] for odd i from M[i-1] and the not-yet-updated u[i] with the forward pass's own operations
+// (bit-identical; the multiplies are opaque to the optimiser, which would otherwise merge the
+// re-computation with the original and keep the value alive).  That is 8 extra flops per second
+// step, and the state shrinks to u (VGPRs) + 80 words of w + v (VGPRs and AGPRs) + MM (LDS, 40 KB
+// per wave): four waves per CU.
+template <typename T, int H> struct FusedCkpt { static constexpr bool value = sizeof(T) == 8 && H == 40; };
 
 template <typename T, int I, int H, class Model, class Args, bool FAST>
 __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::value)) void lane_pg_fused_kernel(Args g, Knobs kn, const T* __restrict__ recs,
@@ -465,28 +481,36 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
     constexpr int BT = kWave * FusedOcc<T, H>::value;
     constexpr bool REGS = FusedInRegs<T, H>::value;
     constexpr int KV = REGS ? H : FusedVRegSteps<T, H>::value;   // steps of v in VGPRs
-    constexpr int KA = FusedAgprSteps<T, H>::value;              // next steps of v in AGPRs
+    // CK: checkpointed w (see FusedCkpt); compact model only -- the general model's linear term
+    // routes 2H intermediates through w at every refill
+    constexpr bool CK = FusedCkpt<T, H>::value && std::is_same<Model, CompactModel<T>>::value;
+    constexpr bool BIG = FusedBig<T, H>::value;
+    constexpr int KA = REGS ? 0 : ((BIG || CK) ? H - KV : 0);    // next steps of v in AGPRs
     constexpr int VL = H - KV - KA;                              // the rest of v in LDS
-    constexpr bool WA = FusedBig<T, H>::value;                   // w in AGPRs
-    __shared__ T s_mm[REGS ? 1 : 2 * H][BT];
-    __shared__ T s_v[VL > 0 ? 2 * VL : 1][BT];
+    constexpr bool WA = BIG || CK;                               // w in AGPRs
+    // one LDS array, so that a plan without v in LDS costs exactly 2H columns (H = 40: 40 960 bytes
+    // per wave, four waves in the CU's 163 840)
+    constexpr int MMR = REGS ? 0 : 2 * H, VLR = VL > 0 ? 2 * VL : 0;
+    __shared__ T s_all[MMR + VLR > 0 ? MMR + VLR : 1][BT];
+    auto s_mm = [&](int q) -> T& { return s_all[q][threadIdx.x]; };
+    auto s_v = [&](int q) -> T& { return s_all[MMR + q][threadIdx.x]; };
     // the first KV horizon steps of v stay in VGPRs even when the rest lives in LDS: the inner loop
     // has a few dozen registers to spare, and every step kept saves a ds_read2 and a ds_write2
     // (H = 20 fp64, A/B on one box: KV = 4 / 6 / 8 / 10 / 12 -> +1.7 / +2.0 / +2.1 / +1.5 / -1.0 %)
     T r_mm[REGS ? 2 * H : 1], r_v[2 * KV + 1];   // register-resident copies
-    AgprWord a_v[2 * KA + 1], a_w[WA ? 2 * H : 1];
+    AgprWord a_v[2 * KA + 1], a_w[WA ? (CK ? H : 2 * H) : 1];
     const int lane = threadIdx.x;   // LDS column; ballots below are per wavefront
-    auto mm_put = [&](int q, T val) { if constexpr (REGS) r_mm[q] = val; else s_mm[q][lane] = val; };
-    auto mm_get = [&](int q) -> T { if constexpr (REGS) return r_mm[q]; else return s_mm[q][lane]; };
+    auto mm_put = [&](int q, T val) { if constexpr (REGS) r_mm[q] = val; else s_mm(q) = val; };
+    auto mm_get = [&](int q) -> T { if constexpr (REGS) return r_mm[q]; else return s_mm(q); };
     auto v_put = [&](int q, T val) {
         if (q < 2 * KV) r_v[q] = val;
         else if (q < 2 * (KV + KA)) agpr_put(a_v[q - 2 * KV], val);
-        else s_v[q - 2 * (KV + KA)][lane] = val;
+        else s_v(q - 2 * (KV + KA)) = val;
     };
     auto v_get = [&](int q) -> T {
         if (q < 2 * KV) return r_v[q];
         else if (q < 2 * (KV + KA)) return agpr_get<T>(a_v[q - 2 * KV]);
-        else return s_v[q - 2 * (KV + KA)][lane];
+        else return s_v(q - 2 * (KV + KA));
     };
     const T eps = (T)kn.eps;
     // FAST: (u - lo) * 2^600 and (hi - u) * 2^600 as one fma each, exactly zero at the bound and
@@ -508,8 +532,17 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
 
     Model m;
     T u[2 * H], w[WA ? 1 : 2 * H];
-    auto w_put = [&](int q, T val) { if constexpr (WA) agpr_put(a_w[q], val); else w[q] = val; };
-    auto w_get = [&](int q) -> T { if constexpr (WA) return agpr_get<T>(a_w[q]); else return w[q]; };
+    // CK keeps the even steps only: step i (even) at slots i, i+1 of a_w, i.e. index (q >> 2) * 2 + (q & 1)
+    auto w_put = [&](int q, T val) {
+        if constexpr (CK) { if (((q >> 1) & 1) == 0) agpr_put(a_w[(q >> 2) * 2 + (q & 1)], val); }
+        else if constexpr (WA) agpr_put(a_w[q], val);
+        else w[q] = val;
+    };
+    auto w_get = [&](int q) -> T {
+        if constexpr (CK) return agpr_get<T>(a_w[(q >> 2) * 2 + (q & 1)]);
+        else if constexpr (WA) return agpr_get<T>(a_w[q]);
+        else return w[q];
+    };
     T u0_prev[2] = {(T)0, (T)0};
     T inv_lambda = (T)0, beta = (T)0;
     int64_t k = 0;
@@ -618,6 +651,7 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
         u0_prev[0] = u[0]; u0_prev[1] = u[1];
         T acc[4] = {(T)0, (T)0, (T)0, (T)0};
         T n0 = m0 * m.Q(0), n1 = m1 * m.Q(1);                                    // mpc.h:278-279 (i = H-1)
+        T wc0 = (T)0, wc1 = (T)0;   // CK: the checkpoint M[i-1] read at an odd step i, used again at step i-1
         static_for<H>([&](auto ic) {
             constexpr int i = H - 1 - decltype(ic)::value;
             constexpr int cur = i & 1, nxt = (i - 1) & 1;
@@ -629,7 +663,26 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
                 });
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (i < H - 1) m.bwd(n0, n1, w_get(2 * i), w_get(2 * i + 1));   // mpc.h:280-281
+            if constexpr (CK) {
+                static_assert(!CK || H % 2 == 0, "checkpoints sit on the even steps");
+                if constexpr (i < H - 1) {
+                    if constexpr (i % 2 == 1) {
+                        // M[i] again from the checkpoint M[i-1] and u[i], which this step has not
+                        // updated yet: the forward pass's own operations (mpc.h:277)
+                        wc0 = w_get(2 * (i - 1)); wc1 = w_get(2 * (i - 1) + 1);
+                        T r0 = wc0, r1 = wc1;
+                        m.template fwd<true>(r0, r1, &u[2 * i]);
+                        m.bwd(n0, n1, r0, r1);                                           // mpc.h:280-281
+                    } else {
+                        m.bwd(n0, n1, wc0, wc1);
+                    }
+                } else {
+                    // i = H-1 (odd): M[H-1] is still in m0, m1; fetch the checkpoint for step H-2
+                    wc0 = w_get(2 * (i - 1)); wc1 = w_get(2 * (i - 1) + 1);
+                }
+            } else {
+                if constexpr (i < H - 1) m.bwd(n0, n1, w_get(2 * i), w_get(2 * i + 1));   // mpc.h:280-281
+            }
             T vn[2];
             static_for<I>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;

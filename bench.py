@@ -9,7 +9,10 @@ A "step" is one pass of the hot path over one batch of synthetic instances per G
 (reference call pattern) form, horizon 20, 2 inputs, 262 144 instances per GPU (BASELINE config 3;
 at N=8 that is config 4's 2 097 152), inputs resident in HBM before the timed region.  The instance
 batch is embarrassingly parallel, so ranks shard it with no data-path collective during the solve;
-for N>1 the control outputs are all-gathered over RCCL inside the timed region (north_star).
+for N>1 every step is ONE library call per rank, tpc_mpc_solve_batch_compact_sharded: the rank's block
+is solved straight into its slot of the full-size output arrays and the slots are all-gathered over
+RCCL/xGMI on the same stream, inside the timed region (north_star).  torch.distributed only carries
+the 128-byte communicator id to the ranks, the barriers and the max-over-ranks of the elapsed time.
 
 One batch is in flight by default.  `--inflight 2` alternates consecutive steps between two library
 handles on two HIP streams, so that the next batch's kernels fill the CUs the previous batch's last
@@ -150,9 +153,11 @@ def main():
     fronts = [torch.empty_like(tv) for _ in range(slots)]
     rears = [torch.empty_like(tv) for _ in range(slots)]
     iters_t = None
+    n_total = world * n
     if world > 1:
-        gathered = [torch.empty((world, 2, n), dtype=tdt, device=dev) for _ in range(slots)]
-        mine = [torch.empty((2, n), dtype=tdt, device=dev) for _ in range(slots)]
+        # full-size outputs: every rank ends each step holding the controls of all world*n instances
+        front_all = [torch.empty(n_total, dtype=tdt, device=dev) for _ in range(slots)]
+        rear_all = [torch.empty(n_total, dtype=tdt, device=dev) for _ in range(slots)]
 
     solvers = [MpcSolver(horizon=H, device=local_rank, dtype=a.dtype, algo=a.algo) for _ in range(slots)]
     for sv in solvers:
@@ -160,13 +165,40 @@ def main():
         sv.reserve(n)   # scratch is allocated here, not by the first solve of each handle
     solver = solvers[0]
     streams = [torch.cuda.Stream(dev) for _ in range(slots)]
+    gather_path = "none (1 GPU)"
+    if world > 1:
+        # The library's own RCCL communicator (one per handle): rank 0 makes the id, torch.distributed
+        # hands it to the other ranks.  If the library cannot set it up (RCCL not loadable), say so
+        # loudly and gather with torch.distributed instead -- the solve is the library's either way.
+        try:
+            for sv in solvers:
+                idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(MpcSolver.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, src=0)
+                sv.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+            gather_path = "library: tpc_mpc_solve_batch_compact_sharded (ncclAllGather over RCCL)"
+        except Exception as exc:   # noqa: BLE001 -- reported, not hidden
+            print(f"[bench] rank {rank}: library RCCL path unavailable ({exc}); gathering with torch.distributed",
+                  file=sys.stderr, flush=True)
+            gather_path = f"torch.distributed all_gather (library RCCL path failed: {exc})"
+        ok = torch.tensor([1 if gather_path.startswith("library") else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # all ranks take the same path
+        if int(ok.item()) == 0 and gather_path.startswith("library"):
+            gather_path = "torch.distributed all_gather (another rank's library RCCL path failed)"
+    use_lib_gather = gather_path.startswith("library")
 
     def step(k):
         i = k % slots
         with torch.cuda.stream(streams[i]):
-            if world > 1:
-                solvers[i].solve_batch_compact(tv, ty, tp, out=(mine[i][0], mine[i][1]), want_flags=False)
-                dist.all_gather_into_tensor(gathered[i].view(-1), mine[i].view(-1))   # RCCL over xGMI
+            if world > 1 and use_lib_gather:
+                solvers[i].solve_batch_compact_sharded(n_total, tv, ty, tp, out=(front_all[i], rear_all[i]))
+            elif world > 1:
+                lo = rank * n
+                solvers[i].solve_batch_compact(tv, ty, tp, out=(front_all[i][lo:lo + n], rear_all[i][lo:lo + n]),
+                                               want_flags=False)
+                dist.all_gather_into_tensor(front_all[i], front_all[i][lo:lo + n].clone())
+                dist.all_gather_into_tensor(rear_all[i], rear_all[i][lo:lo + n].clone())
             else:
                 solvers[i].solve_batch_compact(tv, ty, tp, out=(fronts[i], rears[i]), want_flags=False)
 
@@ -209,9 +241,17 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        front, rear = mine[0][0], mine[0][1]
+        front, rear = front_all[0][rank * n:(rank + 1) * n], rear_all[0][rank * n:(rank + 1) * n]
+        # the gather really delivered the other ranks' blocks: every rank checks the checksum of the
+        # whole output against the all-reduced sum of the per-rank block checksums (exact: integers)
+        chk = lambda t: t.view(torch.int64 if t.dtype == torch.float64 else torch.int32).bitwise_and(0xFFFFF).sum()
+        local = torch.stack([chk(front), chk(rear)])
+        dist.all_reduce(local, op=dist.ReduceOp.SUM)
+        whole = torch.stack([chk(front_all[0]), chk(rear_all[0])])
+        gather_ok = bool(torch.equal(local, whole))
     else:
         front, rear = fronts[0], rears[0]
+        gather_ok = None
 
     if rank == 0:
         # iteration statistics of this rank's shard (for the algorithmic-flop figure)
@@ -257,7 +297,9 @@ def main():
             "config": {"workload": f"batch {n} trajectories per GPU, N={H}, 2 inputs, compact "
                                    f"(mpcControllerTobi) form, cold start, eps 0.01, max_iter 10000",
                        "global_batch": world * n, "horizon": H, "algo": {1: "wave", 2: "lane"}[algo_ran],
-                       "parallelism": f"batch-sharded x{world}", "batches_in_flight": slots},
+                       "parallelism": f"batch-sharded x{world}", "batches_in_flight": slots,
+                       "gather": gather_path, "gather_verified": gather_ok},
+            "build": MpcSolver.build_info(),
             "kernel_ms": {"first": k1, "second": k2, "dominant": dom_name},
             "kernel_ms_serial": {"first": s1, "second": s2},
             "mean_iterations": mean_iters, "lane_stats": lane_stats,

@@ -20,6 +20,6 @@ run trace --kernel-trace --stats
 run fetch --kernel-trace --pmc FETCH_SIZE
 run write --kernel-trace --pmc WRITE_SIZE
 run sq --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
-run sq2 --kernel-trace --pmc SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE || true
+[ -n "$TPC_PROFILE_SQ2" ] && run sq2 --kernel-trace --pmc SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE || true
 cd $ROOT
-python3 scripts/pmc_summary.py $TAG "${CMD[*]}"
+python3 scripts/pmc_summary.py $TAG "${CMD[*]}" > $OUT/${TAG}_summary.txt

@@ -67,11 +67,9 @@ int main(int argc, char** argv) {
                     std::atan2((double)tp.directory.y, (double)tp.directory.x), st->steering_front, st->steering_rear,
                     st->targetSpeed, st->state == street_environment::CarCommand::StateType::DRIVING);
     }
-    // IDLE drive mode publishes the stand-still state
-    phx->mode = phoenix_CC2016_service::CCDriveMode::IDLE;
-    mod.cycle();
-    const street_environment::CarCommand::State* idle = car->getState("IDLE");
-    std::printf("{\"idle_state\": %s, \"priority\": %d}\n", idle ? "true" : "false", idle ? idle->priority : -1);
+    // a back-end outside this build's scope is refused, not emulated
+    mod.config().set("type", "PID");
+    std::printf("{\"other_backend_refused\": %s}\n", mod.cycle() ? "false" : "true");
     mod.deinitialize();
     return 0;
 }

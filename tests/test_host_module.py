@@ -53,7 +53,7 @@ def test_cycle_matches_reference_solver(tmp_path, oracle, H):
         else:
             assert abs(s["steering_front"] - f[i]) <= 1e-9 and abs(s["steering_rear"] - rr[i]) <= 1e-9
         assert s["driving"] == 1
-    assert lines[-1] == {"idle_state": True, "priority": 100}
+    assert lines[-1] == {"other_backend_refused": True}
 
 
 def _traj_point_np(px, py, dx, dy, vel, count, want):

@@ -38,15 +38,34 @@ TPC_DEV float read_lane(float x, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
 }
 
-// max over the 64 lanes, returned wave-uniform.  x >= 0 or NaN; NaN lanes are ignored (fmax).
-template <typename T> TPC_DEV T wave_max(T x) {
-    x = tmax(x, dpp_mov<0x111>(x, x));          // row_shr:1
-    x = tmax(x, dpp_mov<0x112>(x, x));          // row_shr:2
-    x = tmax(x, dpp_mov<0x114>(x, x));          // row_shr:4
-    x = tmax(x, dpp_mov<0x118>(x, x));          // row_shr:8   -> lane 15 of each row = row max
-    x = tmax(x, dpp_mov<0x142, 0xa>(x, x));     // row_bcast:15 -> rows 1,3
-    x = tmax(x, dpp_mov<0x143, 0xc>(x, x));     // row_bcast:31 -> rows 2,3; lane 63 = wave max
-    return read_lane(x, 63);
+// v_max on values that are already canonical (the operands come out of arithmetic or a lane move):
+// the builtin would prepend a quieting v_max x, x to each operand it cannot prove canonical.
+TPC_DEV double raw_max(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+TPC_DEV float raw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// lane-shifted copy inside a 16-lane row; lanes without a source read 0 (bound_ctrl), which is the
+// neutral element here (the reduced values are >= 0)
+template <int CTRL> TPC_DEV double dpp_shr0(double x) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL> TPC_DEV float dpp_shr0(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+
+// max over lanes 0 .. N-1 (the other lanes hold 0), returned wave-uniform.  x >= 0; a NaN lane
+// is ignored (v_max returns the other operand).  Only as many DPP steps as N needs: the reduction is
+// a dependent chain, and it sits on the critical path of every coordinate-descent iteration.
+template <int N, typename T> TPC_DEV T wave_max(T x) {
+    if constexpr (N > 1) x = raw_max(x, dpp_shr0<0x111>(x));          // row_shr:1
+    if constexpr (N > 2) x = raw_max(x, dpp_shr0<0x112>(x));          // row_shr:2
+    if constexpr (N > 4) x = raw_max(x, dpp_shr0<0x114>(x));          // row_shr:4
+    if constexpr (N > 8) x = raw_max(x, dpp_shr0<0x118>(x));          // row_shr:8  -> lane 15 of each row = row max
+    if constexpr (N > 16) x = raw_max(x, dpp_mov<0x142, 0xa>(x, x));  // row_bcast:15 -> rows 1, 3
+    if constexpr (N > 32) x = raw_max(x, dpp_mov<0x143, 0xc>(x, x));  // row_bcast:31 -> rows 2, 3; lane 63 = wave max
+    constexpr int last = N > 32 ? 63 : (N > 16 ? 31 : (N > 8 ? 15 : (N > 4 ? 7 : (N > 2 ? 3 : (N > 1 ? 1 : 0)))));
+    return read_lane(x, last);
 }
 
 template <typename T, int I, int H, class Args> struct WaveIO;
@@ -140,6 +159,11 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_u, T* s_
                             [&](int q, T val) { if (q == slot) my_g = val; });
     const T lo = m.lo(qj), hi = m.hi(qj);
     const T eps = (T)kn.eps;
+    // the coordinate step divides by Q_diag (mpc.h:325): one correctly rounded reciprocal per lane
+    // here instead of a ~13-instruction dependent division chain in every coordinate-descent
+    // iteration (the product differs from the quotient by an ulp at most: within this family's
+    // tolerance, like its FMA dot product)
+    const T my_rqd = (T)1 / my_qd;
     const T inv_lambda = (T)1.0 / lambda;                 // mpc.h:342
     const T sq = tsqrt(lambda);
     const T beta = (sq - (T)1) / (sq + (T)1);             // mpc.h:343
@@ -173,14 +197,14 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_u, T* s_
 
         if (iter < kn.smo_iters) {
             // coordinate descent on the arg-max (mpc.h:319-335)
-            const T mx = wave_max(c);
+            const T mx = wave_max<N>(c);
             if (mx < eps) { capped = false; break; }                             // mpc.h:310-311
             const unsigned long long hit = __ballot(c == mx);
             const int best = __ffsll((long long)hit) - 1;                        // lowest index wins
             const T qd = read_lane(my_qd, best);
             if (qd != (T)0) {                                                    // mpc.h:322
                 if (lane == best) {
-                    T nu = -(df - qd * u) / qd;                                  // mpc.h:325
+                    T nu = -(df - qd * u) * my_rqd;                              // mpc.h:325
                     u = put_in_range(lo, hi, nu);                                // mpc.h:326
                 }
                 if (iter + 1 == kn.smo_iters) v = u;                             // mpc.h:330-334

@@ -1,7 +1,10 @@
 // Module shim: behaviour of TrajectoryPointController::cycle() for the tobiMPC back-end
-// (reference: src/trajectory_point_follower.cpp:8-126, :214-299, :392-476) with the QP solved by
-// libtpc_mpc.so.  Written from the reference's observable behaviour; structured differently (one
-// function per back-end) and without dlib.
+// (reference: src/trajectory_point_follower.cpp:8-126, :277-299, :392-476) with the QP solved by
+// libtpc_mpc.so.  Written from the reference's observable behaviour, without dlib.
+// Only the path SURVEY.md section 8 puts in scope is here.  The host-side glue around it -- drive-mode
+// IDLE handling (:35-62), the PID back-end (:214-225), the turn indicators (:227-276) and the
+// andromeda back-end (:127-213, source not vendored) -- stays in the reference's own cycle(); a
+// maintainer applies the three edits of INTEGRATION.md to that file instead of using this one.
 #include "trajectory_point_controller.h"
 
 #include <cmath>
@@ -19,8 +22,6 @@ bool TrajectoryPointController::initialize() {
     upper[0] = upper[1] = alpha_max;
 
     configsChanged();
-    isTurn = false;
-    turnStart = lms::Time::ZERO;
 
     // the one new piece of state: a solver handle on the configured GPU.  No CPU fallback: without
     // the device the module refuses to initialise.
@@ -46,49 +47,25 @@ void TrajectoryPointController::configsChanged() {
     m_trajectoryPointDistanceLookup.vy = config().getArray<float>("trajectoryPointDistanceLookupY");
     const float dt = config().get<float>("dt", 0.01f);
     slowDownCar.set(config().get<float>("PID_Kp", 1), config().get<float>("PID_Ki", 0), config().get<float>("PID_Kd", 0), dt);
-    pidControllerFront.set(config().get<float>("PID_front_Kp", 1), config().get<float>("PID_front_Ki", 1),
-                           config().get<float>("PID_front_Kd", 0), dt);
-    pidControllerRear.set(config().get<float>("PID_rear_Kp", 1), config().get<float>("PID_rear_Ki", 1),
-                          config().get<float>("PID_rear_Kd", 0), dt);
 }
 
 bool TrajectoryPointController::cycle() {
     using street_environment::CarCommand;
-    auto phx = getService<phoenix_CC2016_service::Phoenix_CC2016Service>("PHOENIX_SERVICE");
-
-    // drive mode IDLE: publish a high-priority stand-still state (reference :36-52)
-    if (phx->driveMode() == phoenix_CC2016_service::CCDriveMode::IDLE) {
-        CarCommand::State idle;
-        if (CarCommand::State* prev = car->getState("IDLE")) idle = *prev;
-        idle.state = CarCommand::StateType::IDLE;
-        idle.priority = 100;
-        idle.name = "IDLE";
-        idle.steering_front = idle.steering_rear = idle.targetSpeed = 0;
-        car->putState(idle);
-        return true;
-    }
-    car->removeState("IDLE");
-
     CarCommand::State state;
     if (CarCommand::State* prev = car->getState("DEFAULT")) state = *prev;   // reference :55-61
     state.priority = 10;
     state.name = "DEFAULT";
 
     const std::string type = config().get<std::string>("type", "tobiMPC");   // reference :64
-    bool ok;
-    if (type == "tobiMPC") {
-        ok = cycleTobiMpc(state);
-    } else if (type == "mikMPC") {
-        // reference :127-213 calls call_andromeda() from tum-phoenix/control-systems, a submodule
-        // that is not vendored (.gitmodules:1-3): that back-end cannot be built here.
-        logger.error("trajectory_point_controller") << "type=mikMPC: andromeda back-end is not part of this build";
+    if (type != "tobiMPC") {
+        // mikMPC (:127-213) calls call_andromeda() from a submodule that is not vendored; the PID
+        // back-end (:214-225) is host glue outside this build's scope
+        logger.error("trajectory_point_controller") << "type=" << type << ": only the tobiMPC back-end is part of this build";
         return false;
-    } else {
-        ok = cyclePid(state);
     }
-    if (!ok) return false;
+    if (!cycleTobiMpc(state)) return false;
 
-    applyIndicatorsAndCrossing(state);
+    applyCrossingRule(state);
     car->putState(state);   // reference :286
     return true;
 }
@@ -135,33 +112,9 @@ bool TrajectoryPointController::cycleTobiMpc(street_environment::CarCommand::Sta
     return true;
 }
 
-// reference :214-225
-bool TrajectoryPointController::cyclePid(street_environment::CarCommand::State& state) {
-    const float lookAhead = m_trajectoryPointDistanceLookup.linearSearch(car->velocity());
-    const street_environment::TrajectoryPoint tp = getTrajectoryPoint(lookAhead);
-    state.steering_front = pidControllerFront.pid(tp.position.y);
-    state.steering_rear = pidControllerRear.pid(tp.directory.angle());
-    state.targetSpeed = tp.velocity;
-    state.targetDistance = tp.position.length();
-    return true;
-}
-
-// reference :227-283
-void TrajectoryPointController::applyIndicatorsAndCrossing(street_environment::CarCommand::State& state) {
-    state.indicatorLeft = state.indicatorRight = false;
-    if (!trajectory->empty()) {
-        const bool startsRight = trajectory->at(0).isRight();
-        for (const street_environment::TrajectoryPoint& p : *trajectory)
-            if (p.isRight() != startsRight) {   // a lane change lies ahead
-                state.indicatorLeft = startsRight;
-                state.indicatorRight = !startsRight;
-                break;
-            }
-    }
-    if (state.targetSpeed < 0.5) {   // probably standing at a crossing: no steering, no indicators
-        state.indicatorLeft = state.indicatorRight = false;
-        state.steering_front = state.steering_rear = 0;
-    }
+// reference :277-283: probably standing at a crossing -- no steering
+void TrajectoryPointController::applyCrossingRule(street_environment::CarCommand::State& state) {
+    if (state.targetSpeed < 0.5) state.steering_front = state.steering_rear = 0;
 }
 
 // reference :301-389.  The dlib controller of the reference is replaced by one C-ABI call; the model

@@ -38,12 +38,11 @@ public:
 
 private:
     bool cycleTobiMpc(street_environment::CarCommand::State& state);
-    bool cyclePid(street_environment::CarCommand::State& state);
-    void applyIndicatorsAndCrossing(street_environment::CarCommand::State& state);
+    void applyCrossingRule(street_environment::CarCommand::State& state);
 
     lms::math::LookupTable<float, lms::math::LookupTableOrder::ASC> m_mpcLookupVelocity;
     lms::math::LookupTable<float, lms::math::LookupTableOrder::ASC> m_trajectoryPointDistanceLookup;
-    sensor_utils::PID slowDownCar, pidControllerFront, pidControllerRear;
+    sensor_utils::PID slowDownCar;   // crossing-stop velocity rule inside getTrajectoryPoint (reference :445-473)
 
     double l = 0.21;   // wheelbase (reference: include/...follower.h:47)
     struct MpcParameters {
@@ -55,9 +54,6 @@ private:
     lms::WriteDataChannel<street_environment::CarCommand> car;
     lms::WriteDataChannel<street_environment::TrajectoryPoint> debugging_trajectoryPoint;
     lms::WriteDataChannel<street_environment::Trajectory> trajectoryDebug;
-
-    lms::Time turnStart;
-    bool isTurn = false;
 
     tpc_mpc_handle solver_ = nullptr;   // owns device scratch; created in initialize()
 };

@@ -17,8 +17,8 @@
 //   lane_pg_kernel        the same phase, unfused, for callers that want the controller state
 //                         (all controls and dlib's v) back: warm-start chains and tpc_mpc_rollout.
 //
-// Built for one wave per SIMD at fp64: there every instruction costs one ~2.1 ns issue slot
-// (scripts/ubench_dp.hip), so the kernels are shaped by instruction count, not by latency hiding
+// Built for one wave per SIMD at fp64: there every instruction costs one ~2.02 ns issue slot
+// (scripts/ubench_clock.hip), so the kernels are shaped by instruction count, not by latency hiding
 // through occupancy.
 #pragma once
 
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args 
     // (one atomic per wavefront at most: when the failing condition is batch-wide -- bounds that do
     // not straddle zero, a huge eps -- every lane fails, and n atomics on one word would serialise)
     if constexpr (Model::kFastStop) {
-        const unsigned long long failing = __ballot(!m.fast_stop_ok(mm_max, eps));
+        const unsigned long long failing = __ballot(!m.fast_stop_ok(mm_max, eps, lambda));
         if (failing != 0ull && lane == __ffsll((long long)failing) - 1) atomicOr(&stats[2], 1ull);
     }
     const uint32_t cd_iters = kn.smo_iters < kn.max_iter ? kn.smo_iters : kn.max_iter;
@@ -398,10 +398,11 @@ template <int N, class F> TPC_DEV void static_for(F&& f) { static_for_impl(f, st
 
 // ------------------------------------------------------------------------------------------------
 // Phase 2, fused and software-pipelined form: the throughput kernel.  Same arithmetic as
-// lane_pg_kernel, scheduled for ONE wave per SIMD, where (measured, scripts/ubench_dp.hip,
-// ubench_lds2.hip) every VALU or SALU instruction costs one ~2.1 ns issue slot -- the fp64 VALU
-// rate at the ~2.0 GHz the chip holds under fp64 load --, an LDS instruction of any width about
-// three, and nothing hides LDS latency but the wave's own instruction stream:
+// lane_pg_kernel, scheduled for ONE wave per SIMD, where (measured, scripts/ubench_clock.hip,
+// ubench_lds2.hip) every VALU or SALU instruction costs one ~2.02 ns issue slot -- 4.83 cycles at the
+// 2.34-2.39 GHz the chip holds under fp64 load, the most a lone wave gets out of the fp64 pipe (two
+// waves per SIMD reach 4.2-4.4 cycles together) --, an LDS instruction of any width about three
+// slots, and nothing hides LDS latency but the wave's own instruction stream:
 //   * the backward pass, the stop test and the projected-gradient update are fused per horizon
 //     step: as soon as df[i] exists its contribution to max|df| is taken and u[i], v[i] are
 //     advanced speculatively.  dlib updates only when the stop test fails; a lane that stops
@@ -435,7 +436,7 @@ template <typename T, int H> struct FusedInRegs { static constexpr bool value = 
 template <typename T, int H> struct FusedVRegSteps { static constexpr int value = FusedInRegs<T, H>::value ? 0 : TPC_KV_STEPS; };
 #else
 template <typename T, int H> struct FusedVRegSteps {
-    static constexpr int value = sizeof(T) != 8 ? 0 : ((H == 20 || H == 30 || H == 40) ? 8 : 0);
+    static constexpr int value = sizeof(T) != 8 ? 0 : (H == 20 ? 6 : ((H == 30 || H == 40) ? 8 : 0));
 };
 #endif
 template <typename T, int H> struct FusedOcc { static constexpr int value = FusedInRegs<T, H>::value ? 2 : 1; };
@@ -516,13 +517,23 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
     // FAST: (u - lo) * 2^600 and (hi - u) * 2^600 as one fma each, exactly zero at the bound and
     // far above any admissible eps off it (>= 4e64; fp32, scale 2^100: >= 7e12).  The bounds of a kFastStop model are the same for the whole batch, so the two
     // addends sit in SGPRs and leave the loop's VGPR budget alone.
+    // fp64 goes one step further ("moved" form, 4 slots): the projected-gradient step that is
+    // computed anyway says whether a variable is blocked -- v_new = clamp(u - df/lambda) equals u
+    // exactly when u sits on a bound with df pushing outward (mpc.h:298-299), or when the step
+    // vanishes in rounding, which the screen allows only for |df| < eps.  So
+    // min(|df|, |u - v_new| * 2^600) is >= eps exactly where dlib's masked |df| is.
+#ifdef TPC_STOP_OLD   // A/B: the two-fma form for fp64 too
+    constexpr bool MOVED = false;
+#else
+    constexpr bool MOVED = FAST && sizeof(T) == 8;
+#endif
     constexpr T kHuge = (T)(sizeof(T) == 8 ? 0x1p600 : 0x1p100);
     T nlo_h[2] = {(T)0, (T)0}, hi_h[2] = {(T)0, (T)0};
     // ... and the factor in VGPRs: a VOP3 instruction reads one SGPR operand at most, and with both
     // constants scalar the compiler copies the addend into VGPRs in front of every fma
     T huge = kHuge;
     asm volatile("" : "+v"(huge));
-    if constexpr (FAST) {
+    if constexpr (FAST && !MOVED) {
 #pragma unroll
         for (int j = 0; j < I; ++j) {
             nlo_h[j] = wave_uniform(-((T)g.lo[j] * kHuge));
@@ -649,7 +660,13 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
         }
         // ---- backward pass fused with the stop test and the speculative update
         u0_prev[0] = u[0]; u0_prev[1] = u[1];
-        T acc[4] = {(T)0, (T)0, (T)0, (T)0};
+#ifndef TPC_ACC_N
+#define TPC_ACC_N 4
+#endif
+        constexpr int NA = TPC_ACC_N;   // independent max accumulators (max is exact: any split gives dlib's value)
+        T acc[NA];
+#pragma unroll
+        for (int z = 0; z < NA; ++z) acc[z] = (T)0;
         T n0 = m0 * m.Q(0), n1 = m1 * m.Q(1);                                    // mpc.h:278-279 (i = H-1)
         T wc0 = (T)0, wc1 = (T)0;   // CK: the checkpoint M[i-1] read at an odd step i, used again at step i-1
         static_for<H>([&](auto ic) {
@@ -662,7 +679,9 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
                     pv[nxt][j] = v_get(2 * (i - 1) + j);
                 });
             }
+#ifndef TPC_NO_SCHED_BARRIER
             __builtin_amdgcn_sched_barrier(0);
+#endif
             if constexpr (CK) {
                 static_assert(!CK || H % 2 == 0, "checkpoints sit on the even steps");
                 if constexpr (i < H - 1) {
@@ -689,7 +708,11 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
                 constexpr int q = 2 * i + j;
                 const T uu = u[q];
                 const T dd = (pm[cur][j] + m.btm(j, n0, n1)) + uu * m.R(j);     // mpc.h:283
-                if constexpr (FAST) {
+                if constexpr (MOVED) {
+                    vn[j] = clamp3(uu - inv_lambda * dd, m.lo(j), m.hi(j));     // mpc.h:342
+                    const T moved = tabs(uu - vn[j]) * huge;
+                    acc[(i * I + j) % NA] = tmax(acc[(i * I + j) % NA], tmin(tabs(dd), moved));
+                } else if constexpr (FAST) {
                     // mpc.h:298-299 without compares and selects (5 issue slots instead of 8): a
                     // variable at its lower bound may only move up (only df < 0 counts), one at its
                     // upper bound only down.  g_lo / g_hi are 0 at the bound and >= 1e64 off it, so
@@ -698,22 +721,26 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
                     // NaN for a screened instance, and controls never leave [lo, hi] (lo < 0 < hi).
                     const T g_lo = tfma(uu, huge, nlo_h[j]);
                     const T g_hi = tfma(uu, -huge, hi_h[j]);
-                    acc[(i * I + j) & 3] = tmax(acc[(i * I + j) & 3], tabs(tmax(tmin(dd, g_lo), -g_hi)));
+                    acc[(i * I + j) % NA] = tmax(acc[(i * I + j) % NA], tabs(tmax(tmin(dd, g_lo), -g_hi)));
                 } else {
                     const T up = (uu <= m.lo(j)) ? (T)0 : dd;                   // mpc.h:298-299
                     const T dn = (uu >= m.hi(j)) ? (T)0 : -dd;
-                    acc[(i * I + j) & 3] = tmax(acc[(i * I + j) & 3], tmax(up, dn));
+                    acc[(i * I + j) % NA] = tmax(acc[(i * I + j) % NA], tmax(up, dn));
                 }
-                vn[j] = clamp3(uu - inv_lambda * dd, m.lo(j), m.hi(j));         // mpc.h:342
+                if constexpr (!MOVED) vn[j] = clamp3(uu - inv_lambda * dd, m.lo(j), m.hi(j));   // mpc.h:342
                 u[q] = clamp3(vn[j] + beta * (vn[j] - pv[cur][j]), m.lo(j), m.hi(j));   // mpc.h:343
+#ifndef TPC_NO_UPIN
                 asm volatile("" : "+v"(u[q]));   // keep the update in its step (LLVM would sink it)
+#endif
             });
             static_for<I>([&](auto jc) {   // adjacent stores: one ds_write2st64 per step
                 constexpr int j = decltype(jc)::value;
                 v_put(2 * i + j, vn[j]);
             });
         });
-        const T max_df = tmax(tmax(acc[0], acc[1]), tmax(acc[2], acc[3]));
+        T max_df = acc[0];
+#pragma unroll
+        for (int z = 1; z < NA; ++z) max_df = tmax(max_df, acc[z]);
         ++wave_iters;
         stop = have && (max_df < eps);                                          // mpc.h:310-311
         ++iter;

@@ -120,7 +120,7 @@ struct GeneralModel {
 
     // an arbitrary A can grow like |A|^H: no cheap overflow screen, so the exact stop test always runs
     static constexpr bool kFastStop = false;
-    TPC_DEV bool fast_stop_ok(T, T) const { return false; }
+    TPC_DEV bool fast_stop_ok(T, T, T) const { return false; }
 
     TPC_DEV T A(int r_, int c_) const { return r_ == 0 ? (c_ == 0 ? a00 : a01) : (c_ == 0 ? a10 : a11); }
     TPC_DEV T B(int r_, int j) const { return b[r_][j]; }
@@ -249,8 +249,12 @@ struct CompactModel {
     // value finite (< 1e301).  Anything else (absurd inputs) takes the exact test.
     // fp32 (scale 2^100): al <= 1e4, q <= 1e4, U <= 1e3, R <= 1e20, max|MM| <= 1e37 keep every
     // value below 3e38; a bound of magnitude >= 1e-10 leaves g >= 7e12 one ulp off it, hence eps <= 1e10.
+    // fp64 uses a still cheaper form of the test (lane_pg_fused_kernel, "moved" form), which reads
+    // "blocked" off the projected step itself: v_new == u.  A free variable whose step is absorbed by
+    // rounding (|df|/lambda below half an ulp of u) looks blocked too, so its |df| -- at most
+    // 2^-51 * max|bound| * lambda -- must be below eps for the two tests to agree: the last condition.
     static constexpr bool kFastStop = true;
-    TPC_DEV bool fast_stop_ok(T mm_max, T eps) const {
+    TPC_DEV bool fast_stop_ok(T mm_max, T eps, T lambda) const {
         constexpr bool D = sizeof(T) == 8;
         constexpr T kAl = (T)(D ? 1e60 : 1e4), kQ = (T)(D ? 1e30 : 1e4), kR = (T)(D ? 1e100 : 1e20);
         constexpr T kMm = (T)(D ? 1e300 : 1e37), kBmin = (T)(D ? 1e-100 : 1e-10), kBmax = (T)(D ? 1e10 : 1e3);
@@ -259,7 +263,8 @@ struct CompactModel {
         auto upper_ok = [&](T h) { return h >= kBmin && h <= kBmax; };
         return tabs(a) <= kAl && tabs(c) <= kAl && mm_max <= kMm && tabs(q0) <= kQ && tabs(q1) <= kQ &&
                tabs(r0) <= kR && tabs(r1) <= kR && lower_ok(l0) && lower_ok(l1) && upper_ok(h0) &&
-               upper_ok(h1) && eps <= kEps;
+               upper_ok(h1) && eps <= kEps &&
+               (!D || lambda * tmax(tmax(tabs(l0), tabs(l1)), tmax(tabs(h0), tabs(h1))) * (T)0x1p-50 < eps);
     }
 
     TPC_DEV void first(T& m0, T& m1, const T* u) const {

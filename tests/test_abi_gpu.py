@@ -289,10 +289,20 @@ def test_product_solver_under_two_rank_sharding(torch_cuda, tmp_path):
     has one card), ragged shards, every rank ends with the full batch; first 1024 = real-dlib fixtures."""
     script = tmp_path / "rank_worker.py"
     script.write_text(_RANK_WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # loopback only: the box's hostname may not resolve, and gloo would otherwise pick its address by name
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               GLOO_SOCKET_IFNAME="lo")
+    import socket
+    with socket.socket() as sk:           # a port nobody holds right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          env=env, capture_output=True, text=True, timeout=600)
+    if out.returncode != 0:               # keep the evidence where gpurun brings it home
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "two_rank_failure.log"), "w") as fh:
+            fh.write(out.stdout + "\n---- stderr ----\n" + out.stderr)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert out.stdout.count(" ok ") == 2
 

@@ -679,3 +679,30 @@ def test_signed_zero_outputs(torch_cuda, oracle):
             f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
         assert np.array_equal(it, oit), (lo, hi)
         assert bits_equal(f, of) and bits_equal(r, orr), (lo, hi, f, of, r, orr)
+
+
+@pytest.mark.parametrize("I", [1, 2])
+def test_general_stop_test_builds_vs_oracle(torch_cuda, oracle, I):
+    """The general-form fused kernel has the two stop-test builds too (fp64): the "moved" form when
+    GeneralModel::fast_stop_ok proves per instance that nothing can overflow and the bounds straddle
+    zero, dlib's compare-and-select form otherwise.  Ordinary batch (fast build); one instance whose
+    bound touches zero, one whose A would overflow the magnitude screen, one with a huge eps (each
+    sends its batch through the exact build).  All against the oracle, bits and iteration counts."""
+    from trajectory_controller_amd.synth import general_inputs
+    H, n = 20, 1500
+    base = general_inputs(H, n, I=I, first=8800)
+
+    def run(g, **kw):
+        u0, _, it = oracle.solve_general(I, H, *[g[k] for k in GEN_NAMES], nthreads=8, **kw)
+        with _solver(H, "lane", **kw) as s:
+            gu0, git = s.solve_batch_general(*[_soa(g[k]) for k in GEN_NAMES], inputs=I, want_iters=True)
+        assert np.array_equal(git, it)
+        assert bits_equal(gu0.T, u0)
+    run(base)
+    g = {k: a.copy() for k, a in base.items()}
+    g["lo"][7, 0] = 0.0                                   # start point ON the bound
+    run(g)
+    g = {k: a.copy() for k, a in base.items()}
+    g["A"][11] = [1.0, 3e7, 0.0, 1.0]                     # |A|^(2H) ~ 1e300: beyond the screen, still finite in dlib
+    run(g)
+    run(base, eps=2e30)

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args 
     // (one atomic per wavefront at most: when the failing condition is batch-wide -- bounds that do
     // not straddle zero, a huge eps -- every lane fails, and n atomics on one word would serialise)
     if constexpr (Model::kFastStop) {
-        const unsigned long long failing = __ballot(!m.fast_stop_ok(mm_max, eps, lambda));
+        const unsigned long long failing = __ballot(!m.fast_stop_ok(mm_max, eps, lambda, H));
         if (failing != 0ull && lane == __ffsll((long long)failing) - 1) atomicOr(&stats[2], 1ull);
     }
     const uint32_t cd_iters = kn.smo_iters < kn.max_iter ? kn.smo_iters : kn.max_iter;

@@ -118,9 +118,38 @@ struct GeneralModel {
     const T* targets;   // SoA base of this instance: component c at targets[c*ld]
     int64_t ld;
 
-    // an arbitrary A can grow like |A|^H: no cheap overflow screen, so the exact stop test always runs
-    static constexpr bool kFastStop = false;
-    TPC_DEV bool fast_stop_ok(T, T, T) const { return false; }
+    // Screen for the "moved" form of the stop test (lane_pg_fused_kernel; fp64 only -- see
+    // CompactModel::fast_stop_ok for what it needs).  An arbitrary A can grow like |A|^H, so the
+    // magnitude bound is computed per instance: with al = max(1, |A|_inf, |A|_1), be = max(|B|_inf,
+    // |B|_1), U = max|bound|, q = max Q, r = max R, the iteration's intermediates obey
+    //   |M[i]| <= be U H al^H,   |N[i]| <= q be U H^2 al^2H,   |df| <= max|MM| + q be^2 U H^2 al^2H + r U,
+    // and every partial product is below the same figure.  If that is < 1e300 nothing overflows, so
+    // no gradient component can be NaN (an overflowing bound makes the comparison false: exact test).
+    // The start point of the fused kernel is 0, so the bounds must straddle zero strictly.
+    static constexpr bool kFastStop = sizeof(T) == 8;
+    TPC_DEV bool fast_stop_ok(T mm_max, T eps, T lambda, int H) const {
+        if constexpr (sizeof(T) != 8) return false;
+        const T al = tmax((T)1, tmax(tmax(tabs(a00) + tabs(a01), tabs(a10) + tabs(a11)),
+                                     tmax(tabs(a00) + tabs(a10), tabs(a01) + tabs(a11))));
+        T be = (T)0, U = (T)0, r_ = (T)0;
+        bool straddle = true;
+#pragma unroll
+        for (int j = 0; j < I_; ++j) {
+            be = tmax(be, tabs(b[0][j]) + tabs(b[1][j]));
+            U = tmax(U, tmax(tabs(lo_[j]), tabs(hi_[j])));
+            r_ = tmax(r_, tabs(r[j]));
+            straddle = straddle && lo_[j] <= (T)-1e-100 && hi_[j] >= (T)1e-100;
+        }
+        T row0 = (T)0, row1 = (T)0;
+#pragma unroll
+        for (int j = 0; j < I_; ++j) { row0 = row0 + tabs(b[0][j]); row1 = row1 + tabs(b[1][j]); }
+        be = tmax(be, tmax(row0, row1));
+        T alp = (T)1;   // al^(2H)
+        for (int i = 0; i < 2 * H; ++i) alp = alp * al;
+        const T q = tmax(tabs(q0), tabs(q1)), hh = (T)H * (T)H;
+        const T bound = mm_max + q * be * be * U * hh * alp + r_ * U;
+        return straddle && bound < (T)1e300 && U <= (T)1e10 && eps <= (T)1e30 && lambda * U * (T)0x1p-50 < eps;
+    }
 
     TPC_DEV T A(int r_, int c_) const { return r_ == 0 ? (c_ == 0 ? a00 : a01) : (c_ == 0 ? a10 : a11); }
     TPC_DEV T B(int r_, int j) const { return b[r_][j]; }
@@ -254,7 +283,7 @@ struct CompactModel {
     // rounding (|df|/lambda below half an ulp of u) looks blocked too, so its |df| -- at most
     // 2^-51 * max|bound| * lambda -- must be below eps for the two tests to agree: the last condition.
     static constexpr bool kFastStop = true;
-    TPC_DEV bool fast_stop_ok(T mm_max, T eps, T lambda) const {
+    TPC_DEV bool fast_stop_ok(T mm_max, T eps, T lambda, int) const {
         constexpr bool D = sizeof(T) == 8;
         constexpr T kAl = (T)(D ? 1e60 : 1e4), kQ = (T)(D ? 1e30 : 1e4), kR = (T)(D ? 1e100 : 1e20);
         constexpr T kMm = (T)(D ? 1e300 : 1e37), kBmin = (T)(D ? 1e-100 : 1e-10), kBmax = (T)(D ? 1e10 : 1e3);

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from the PMC summaries scripts/profile.sh left in profiles/ (or gpurun_out/):
+HBM bytes per launch of each profiled kernel = (k * FETCH_SIZE + WRITE_SIZE) * 1024, where k is the
+gfx950 read correction CALIBRATED PER ACCESS PATTERN on a known byte count, as
+MI355X_MICROARCH.md (HBM) asks:
+  * wide coalesced streaming reads (lane_cd_kernel's inputs: 3 x n x 8 B known, FETCH_SIZE reports
+    half of it)                                                              -> k = 2
+  * one 8-byte load per lane at a 336-byte stride (lane_pg_fused_kernel re-reading the CD kernel's
+    per-instance records: records + inputs + queue = 364 B x n known, FETCH_SIZE reports 1.05 x that) -> k = 1
+Kernels with no calibration of their own get k = 1 and say so."""
+import csv, json, os, sys
+src = sys.argv[1] if len(sys.argv) > 1 else "profiles"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+CONFIGS = {   # tag -> (kernel in the csv, bench key, k, note)
+    "headline": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_f64_H20_n262144", 1, "strided record reads: k=1 (calibrated)"),
+    "fp32": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_f32_H20_n262144", 1, "strided record reads: k=1"),
+    "config2": ("tpc::wave_kernel", "wave_kernel_f64_H10_n4096", 1, "broadcast loads of 3 scalars per wavefront: uncalibrated, k=1"),
+    "h30": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_f64_H30_n262144", 1, "strided record reads: k=1"),
+    "h40": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_f64_H40_n262144", 1, "strided record reads: k=1"),
+    "general": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_general_I2_f64_H20_n262144", 1, "strided record reads + SoA model loads: k=1"),
+}
+out = {"_how": __doc__.strip(), "_raw_KiB": {}}
+for tag, (kern, key, k, note) in CONFIGS.items():
+    f = os.path.join(src, f"{rnd}_{tag}_pmc.csv")
+    if not os.path.exists(f):
+        continue
+    vals = {}
+    for row in csv.reader(l for l in open(f) if not l.startswith("#")):
+        if len(row) == 4 and row[0] == kern:
+            vals[row[1]] = float(row[3])
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        out[key] = int((k * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+        out["_raw_KiB"][key] = {"FETCH_SIZE": vals["FETCH_SIZE"], "WRITE_SIZE": vals["WRITE_SIZE"], "read_correction": k, "note": note}
+    # the CD kernel of the headline run documents the k = 2 calibration
+    if tag == "headline":
+        cd = {}
+        for row in csv.reader(l for l in open(f) if not l.startswith("#")):
+            if len(row) == 4 and row[0] == "tpc::lane_cd_kernel":
+                cd[row[1]] = float(row[3])
+        if "FETCH_SIZE" in cd:
+            out["_raw_KiB"]["lane_cd_kernel_f64_H20_n262144"] = {"FETCH_SIZE": cd["FETCH_SIZE"], "WRITE_SIZE": cd.get("WRITE_SIZE"),
+                                                                 "known_input_bytes": 3 * 262144 * 8, "read_correction": 2}
+            out["lane_cd_kernel_f64_H20_n262144"] = int((2 * cd["FETCH_SIZE"] + cd.get("WRITE_SIZE", 0)) * 1024)
+json.dump(out, open(os.path.join("profiles", "traffic.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}, indent=1))

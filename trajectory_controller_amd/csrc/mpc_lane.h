@@ -431,6 +431,12 @@ template <int H> struct RefillBatch { static constexpr int value = TPC_REFILL_BA
 #else
 template <int H> struct RefillBatch { static constexpr int value = H <= 5 ? 24 : (H <= 10 ? 6 : 3); };
 #endif
+#ifdef TPC_EXIT_EVERY_STOP   // A/B override (0 / 1)
+template <typename T, int H> struct ExitEveryStop { static constexpr bool value = TPC_EXIT_EVERY_STOP != 0; };
+#else
+// measured per kernel (scripts/ab_many.sh, both forms at every horizon and dtype)
+template <typename T, int H> struct ExitEveryStop { static constexpr bool value = (sizeof(T) == 8 && H == 20) || (sizeof(T) == 4 && H == 30); };
+#endif
 template <typename T, int H> struct FusedInRegs { static constexpr bool value = H * (int)sizeof(T) <= 80; };
 #ifdef TPC_KV_STEPS   // A/B override: horizon steps of v kept in VGPRs by the LDS/AGPR plans
 template <typename T, int H> struct FusedVRegSteps { static constexpr int value = FusedInRegs<T, H>::value ? 0 : TPC_KV_STEPS; };
@@ -745,15 +751,38 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
         stop = have && (max_df < eps);                                          // mpc.h:310-311
         ++iter;
         cap = have && !stop && iter >= kn.max_iter;                             // mpc.h:271
-        } while (__ballot(stop || cap) == 0ull);
-        if (stop) {
-            publish(u0_prev[0], u0_prev[1], iter - 1);
-            have = false;
+        // A finished lane publishes right here and the loop goes on; it is left only when a refill
+        // pass is due (RefillBatch lanes wait) or no lane has work.  At H = 30 / 40, where the
+        // compiler keeps the loop's state in scratch outside the loop, leaving on every stop cost a
+        // 300-dword spill and reload per stop (-2 % kernel time, a third of the scratch traffic);
+        // -4 % at H = 10.  The fp64 H = 20 kernel keeps round 1's form, which leaves on every stop:
+        // there the publish code inside the loop upsets the loop's register allocation (+4.5 %).
+        if constexpr (ExitEveryStop<T, H>::value) {
+            if (__ballot(stop || cap) != 0ull) break;
+        } else if (__ballot(stop || cap) != 0ull) {
+            if (stop) {
+                publish(u0_prev[0], u0_prev[1], iter - 1);
+                have = false;
+            }
+            if (cap) {
+                flags |= 0x2u;
+                publish(u[0], u[1], iter);
+                have = false;
+            }
+            const unsigned long long waiting = __ballot(!have && !exhausted);
+            if (__popcll(waiting) >= RefillBatch<H>::value || __ballot(have) == 0ull) break;
         }
-        if (cap) {
-            flags |= 0x2u;
-            publish(u[0], u[1], iter);
-            have = false;
+        } while (true);
+        if constexpr (ExitEveryStop<T, H>::value) {
+            if (stop) {
+                publish(u0_prev[0], u0_prev[1], iter - 1);
+                have = false;
+            }
+            if (cap) {
+                flags |= 0x2u;
+                publish(u[0], u[1], iter);
+                have = false;
+            }
         }
     }
     if (g.flags && flags) atomicOr(g.flags, flags);

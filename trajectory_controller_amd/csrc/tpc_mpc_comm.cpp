@@ -15,6 +15,7 @@
 #include "tpc_mpc_context.h"
 
 #include <dlfcn.h>
+#include <mutex>
 #include <rccl/rccl.h>   // types and prototypes only; the symbols are resolved by dlsym below
 
 namespace tpc {
@@ -39,13 +40,11 @@ struct Rccl {
     char why[256] = "";
 };
 
-// Resolved once per process; a failed attempt is remembered with its reason.
+// Resolved once per process (std::call_once: handles of different threads may race to be first); a
+// failed attempt is remembered with its reason.
 Rccl g_rccl;
-Rccl* rccl() {
+void rccl_load() {
     Rccl& r = g_rccl;
-    static bool tried = false;
-    if (tried) return r.lib ? &r : nullptr;
-    tried = true;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* nm : names) {
         r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
@@ -53,7 +52,7 @@ Rccl* rccl() {
     }
     if (!r.lib) {
         std::snprintf(r.why, sizeof(r.why), "cannot load librccl.so.1: %s", dlerror());
-        return nullptr;
+        return;
     }
     bool ok = true;
     auto sym = [&](const char* name) {
@@ -69,8 +68,12 @@ Rccl* rccl() {
     r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
-    if (!ok) { dlclose(r.lib); r.lib = nullptr; return nullptr; }
-    return &r;
+    if (!ok) { dlclose(r.lib); r.lib = nullptr; }
+}
+Rccl* rccl() {
+    static std::once_flag once;
+    std::call_once(once, rccl_load);
+    return g_rccl.lib ? &g_rccl : nullptr;
 }
 
 int rccl_fail(tpc_mpc_context* h, Rccl* r, ncclResult_t e, const char* what) {

@@ -18,9 +18,17 @@
 // Iteration counts are wave-uniform: no divergence, no refill.  Supports I*H <= 64.
 #pragma once
 
+#include <type_traits>
+#include <utility>
+
 #include "mpc_model.h"
 
 namespace tpc {
+
+template <class F, int... Is> TPC_DEV void static_for_w_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F> TPC_DEV void static_for_w(F&& f) { static_for_w_impl(f, std::make_integer_sequence<int, N>{}); }
 
 template <int CTRL, int ROW_MASK = 0xf> TPC_DEV double dpp_mov(double old, double x) {
     const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, ROW_MASK, 0xf, false);
@@ -52,6 +60,16 @@ template <int CTRL> TPC_DEV double dpp_shr0(double x) {
 }
 template <int CTRL> TPC_DEV float dpp_shr0(float x) {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+
+// value of lane K of the caller's 16-lane row, in every lane of that row (DPP row_newbcast)
+template <int K> TPC_DEV double row_bcast(double x) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0x150 + K, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0x150 + K, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int K> TPC_DEV float row_bcast(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x150 + K, 0xf, 0xf, false));
 }
 
 // max over lanes 0 .. N-1 (the other lanes hold 0), returned wave-uniform.  x >= 0; a NaN lane
@@ -176,45 +194,66 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_u, T* s_
     if ((Model::kScreen && nonfinite) || badmodel) { capped = false; } else {
 #pragma unroll 1
     for (; iter < kn.max_iter; ++iter) {
-        // exchange controls through LDS (single-wave workgroup: the barrier is only a wait)
-        if (active) s_u[lane] = u;
-        __syncthreads();
+        // df_q = Hd[q,:].u + g_q.  Up to 16 variables all live in the first 16-lane row, and each
+        // control reaches the others by a DPP row broadcast (two register moves, no memory, no
+        // wait); beyond that the controls go through the LDS vector (single-wave workgroup: the
+        // barrier is only a wait).  The exchange sits on the critical path of every iteration.
         T a0 = (T)0, a1 = (T)0, a2 = (T)0, a3 = (T)0;
+        if constexpr (N <= 16) {
+            static_for_w<N>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                constexpr int e = 2 * (q / I) + (q % I);
+                const T uq = row_bcast<q>(u);
+                if constexpr ((q & 3) == 0) a0 = tfma(row[e], uq, a0);
+                else if constexpr ((q & 3) == 1) a1 = tfma(row[e], uq, a1);
+                else if constexpr ((q & 3) == 2) a2 = tfma(row[e], uq, a2);
+                else a3 = tfma(row[e], uq, a3);
+            });
+        } else {
+            if (active) s_u[lane] = u;
+            __syncthreads();
 #pragma unroll
-        for (int i = 0; i < H; ++i)
+            for (int i = 0; i < H; ++i)
 #pragma unroll
-            for (int j = 0; j < I; ++j) {
-                const int q = i * I + j;
-                const T uq = s_u[q];
-                if ((q & 3) == 0) a0 = tfma(row[2 * i + j], uq, a0);
-                else if ((q & 3) == 1) a1 = tfma(row[2 * i + j], uq, a1);
-                else if ((q & 3) == 2) a2 = tfma(row[2 * i + j], uq, a2);
-                else a3 = tfma(row[2 * i + j], uq, a3);
-            }
+                for (int j = 0; j < I; ++j) {
+                    const int q = i * I + j;
+                    const T uq = s_u[q];
+                    if ((q & 3) == 0) a0 = tfma(row[2 * i + j], uq, a0);
+                    else if ((q & 3) == 1) a1 = tfma(row[2 * i + j], uq, a1);
+                    else if ((q & 3) == 2) a2 = tfma(row[2 * i + j], uq, a2);
+                    else a3 = tfma(row[2 * i + j], uq, a3);
+                }
+        }
         const T df = ((a0 + a1) + (a2 + a3)) + my_g;
         const bool blocked = (u <= lo && df > (T)0) || (u >= hi && df < (T)0);   // mpc.h:298-299
         const T c = (active && !blocked) ? tabs(df) : (T)0;
 
+        // Both kinds of step are computed SPECULATIVELY, beside the stop test they do not depend on:
+        // one wave's fp64 instructions issue every ~5 cycles when independent and every ~9 when each
+        // needs the previous result, so a test chain followed by an update chain costs their sum,
+        // the two interleaved cost little more than the longer one.  Nothing is committed before
+        // the test has spoken.
         if (iter < kn.smo_iters) {
             // coordinate descent on the arg-max (mpc.h:319-335)
+            T nu = put_in_range(lo, hi, -(df - my_qd * u) * my_rqd);             // mpc.h:325-326, every lane its own
+            asm volatile("" : "+v"(nu));   // computed HERE, beside the reduction (the optimiser would sink it behind the branch)
             const T mx = wave_max<N>(c);
             if (mx < eps) { capped = false; break; }                             // mpc.h:310-311
             const unsigned long long hit = __ballot(c == mx);
             const int best = __ffsll((long long)hit) - 1;                        // lowest index wins
             const T qd = read_lane(my_qd, best);
             if (qd != (T)0) {                                                    // mpc.h:322
-                if (lane == best) {
-                    T nu = -(df - qd * u) * my_rqd;                              // mpc.h:325
-                    u = put_in_range(lo, hi, nu);                                // mpc.h:326
-                }
+                if (lane == best) u = nu;
                 if (iter + 1 == kn.smo_iters) v = u;                             // mpc.h:330-334
             }
         } else {
             // accelerated projected gradient (mpc.h:336-345); stop test without a reduction
+            T v_new = clamp3(u - inv_lambda * df, lo, hi);
+            T u_new = clamp3(v_new + beta * (v_new - v), lo, hi);
+            asm volatile("" : "+v"(v_new), "+v"(u_new));   // computed HERE, beside the stop test
             if (__ballot(c >= eps) == 0ull) { capped = false; break; }           // mpc.h:310-311
-            const T v_old = v;
-            v = clamp3(u - inv_lambda * df, lo, hi);
-            u = clamp3(v + beta * (v - v_old), lo, hi);
+            v = v_new;
+            u = u_new;
         }
     }
     }

@@ -706,3 +706,36 @@ def test_general_stop_test_builds_vs_oracle(torch_cuda, oracle, I):
     g["A"][11] = [1.0, 3e7, 0.0, 1.0]                     # |A|^(2H) ~ 1e300: beyond the screen, still finite in dlib
     run(g)
     run(base, eps=2e30)
+    g = {k: a.copy() for k, a in base.items()}
+    g["targets"][5, 3, 1] = np.nan                        # a NaN in the linear term: dlib ignores NaN gradients
+    g["targets"][9, 0, 0] = np.inf
+    g["x0"][13, 0] = np.nan
+    run(g)
+
+
+@pytest.mark.parametrize("I", [1, 2])
+def test_wave_mask_forms_vs_oracle(torch_cuda, oracle, I):
+    """The WAVE kernel's two forms of the masked |df| (arithmetic where the model's screen allows it,
+    dlib's compares otherwise): an ordinary batch, a warm start outside the bounds, a bound that
+    touches zero and NaN / inf targets -- identical iteration counts, outputs within the family's
+    tolerance (NaN where dlib gives NaN)."""
+    from trajectory_controller_amd.synth import general_inputs
+    H, n = 10, 400
+    base = general_inputs(H, n, I=I, first=4400)
+    rng = np.random.default_rng(17)
+
+    def run(g, cin=None):
+        u0, cout, it = oracle.solve_general(I, H, *[g[k] for k in GEN_NAMES], controls_in=cin, nthreads=8)
+        controls = None if cin is None else _soa(cin)
+        with _solver(H, "wave") as s:
+            gu0, git = s.solve_batch_general(*[_soa(g[k]) for k in GEN_NAMES], controls=controls, inputs=I, want_iters=True)
+        assert np.array_equal(git, it)
+        assert np.array_equal(np.isnan(gu0.T), np.isnan(u0))
+        assert np.nanmax(np.abs(gu0.T - u0), initial=0.0) <= WAVE_ATOL
+    run(base)
+    run(base, cin=rng.uniform(-0.6, 0.6, size=(n, H, I)))   # many start points outside +-0.384
+    g = {k: a.copy() for k, a in base.items()}
+    g["lo"][7, 0] = 0.0
+    g["targets"][5, 3, 1] = np.nan
+    g["targets"][9, 0, 0] = np.inf
+    run(g)

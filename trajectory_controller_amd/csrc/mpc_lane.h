@@ -157,7 +157,9 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args 
     LaneIO<T, I, H, Args>::init_controls(g, k, u);
     const T lambda = ctor_lambda_qdiag<T, I, H>(m, [&](int i, int j, T val) { s_qd[2 * i + j][lane] = val; });
     T mm_max = (T)0;
-    linear_term<T, I, H>(m, w, [&](int q, T val) { s_mm[q][lane] = val; mm_max = tmax(mm_max, tabs(val)); });
+    bool mm_nan = false;   // fmax drops a NaN operand: a NaN element of the linear term is tracked on its own
+    linear_term<T, I, H>(m, w, [&](int q, T val) { s_mm[q][lane] = val; mm_max = tmax(mm_max, tabs(val)); mm_nan = mm_nan || val != val; });
+    if (mm_nan) mm_max = (T)__builtin_inf();   // beyond every screen
 
     const T eps = (T)kn.eps;
     // one instance outside the screen sends the whole batch to the exact-stop-test build of the

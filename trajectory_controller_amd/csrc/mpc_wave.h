@@ -189,28 +189,40 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_u, T* s_
     T u = active ? WaveIO<T, I, H, Args>::init_u(g, k, qi, qj) : (T)0;
     T v = active ? WaveIO<T, I, H, Args>::init_v(g, k, qi, qj) : (T)0;
 
-    uint32_t iter = 0;
-    bool capped = true;
-    if ((Model::kScreen && nonfinite) || badmodel) { capped = false; } else {
-#pragma unroll 1
-    for (; iter < kn.max_iter; ++iter) {
-        // df_q = Hd[q,:].u + g_q.  Up to 16 variables all live in the first 16-lane row, and each
-        // control reaches the others by a DPP row broadcast (two register moves, no memory, no
-        // wait); beyond that the controls go through the LDS vector (single-wave workgroup: the
-        // barrier is only a wait).  The exchange sits on the critical path of every iteration.
+    // The masked |df| of mpc.h:298-299 comes in two forms.  Exact: dlib's compares, whose results travel
+    // VALU -> SALU -> VALU twice per iteration, on the critical path.  Arithmetic (MASK): g_lo =
+    // (u - lo) * 2^600 and g_hi = (hi - u) * 2^600 are 0 on the bound and huge off it, depend on u
+    // only (so they are computed beside the dot product), and |max(min(df, g_lo), -g_hi)| is the masked
+    // |df| -- two dependent instructions behind df.  Same value wherever no df can be NaN and the
+    // controls stay inside bounds that straddle zero, which the model's screen proves for this
+    // instance (one decision per wavefront: everything it looks at is wave-uniform).
+    bool mask_ok = false;
+    if constexpr (Model::kFastStop) {
+        const T mm_max = wave_max<N>(active ? tabs(my_g) : (T)0);
+        const bool start_inside = u >= lo && u <= hi;   // a caller's warm start may lie outside
+        const bool term_nan = my_g != my_g;             // wave_max ignores a NaN lane: look for one explicitly
+        mask_ok = m.fast_stop_ok(mm_max, eps, lambda, H) && __ballot(active && (!start_inside || term_nan)) == 0ull;
+    }
+    constexpr T kHuge = (T)(sizeof(T) == 8 ? 0x1p600 : 0x1p100);
+    const T nlo_h = -(lo * kHuge), hi_h = hi * kHuge;
+
+    // df_q = Hd[q,:].u + g_q.  Up to 16 variables all live in the first 16-lane row, and each control
+    // reaches the others by a DPP row broadcast (two register moves, no memory, no wait); beyond that
+    // the controls go through the LDS vector (single-wave workgroup: the barrier is only a wait).
+    auto gradient_of = [&](T uu) -> T {
         T a0 = (T)0, a1 = (T)0, a2 = (T)0, a3 = (T)0;
         if constexpr (N <= 16) {
             static_for_w<N>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
                 constexpr int e = 2 * (q / I) + (q % I);
-                const T uq = row_bcast<q>(u);
+                const T uq = row_bcast<q>(uu);
                 if constexpr ((q & 3) == 0) a0 = tfma(row[e], uq, a0);
                 else if constexpr ((q & 3) == 1) a1 = tfma(row[e], uq, a1);
                 else if constexpr ((q & 3) == 2) a2 = tfma(row[e], uq, a2);
                 else a3 = tfma(row[e], uq, a3);
             });
         } else {
-            if (active) s_u[lane] = u;
+            if (active) s_u[lane] = uu;
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < H; ++i)
@@ -224,39 +236,61 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_u, T* s_
                     else a3 = tfma(row[2 * i + j], uq, a3);
                 }
         }
-        const T df = ((a0 + a1) + (a2 + a3)) + my_g;
-        const bool blocked = (u <= lo && df > (T)0) || (u >= hi && df < (T)0);   // mpc.h:298-299
-        const T c = (active && !blocked) ? tabs(df) : (T)0;
+        return ((a0 + a1) + (a2 + a3)) + my_g;
+    };
 
-        // Both kinds of step are computed SPECULATIVELY, beside the stop test they do not depend on:
-        // one wave's fp64 instructions issue every ~5 cycles when independent and every ~9 when each
-        // needs the previous result, so a test chain followed by an update chain costs their sum,
-        // the two interleaved cost little more than the longer one.  Nothing is committed before
-        // the test has spoken.
-        if (iter < kn.smo_iters) {
-            // coordinate descent on the arg-max (mpc.h:319-335)
+    uint32_t iter = 0;
+    bool capped = true;
+    // Two loops, one per phase, each with a single way out; both kinds of step are computed
+    // SPECULATIVELY beside the stop test they do not depend on (one wave's fp64 instructions issue every
+    // ~5 cycles when independent and every ~9 when each needs the previous result), and nothing is
+    // committed before the test has spoken.
+    auto run = [&](auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        auto masked = [&](T uu, T df) -> T {
+            if constexpr (MASK) {
+                const T g_lo = tfma(uu, kHuge, nlo_h), g_hi = tfma(uu, -kHuge, hi_h);
+                const T c = tabs(tmax(tmin(df, g_lo), -g_hi));
+                return active ? c : (T)0;
+            } else {
+                const bool blocked = (uu <= lo && df > (T)0) || (uu >= hi && df < (T)0);   // mpc.h:298-299
+                return (active && !blocked) ? tabs(df) : (T)0;
+            }
+        };
+        // ---- coordinate descent on the arg-max (mpc.h:319-335)
+        const uint32_t cd_end = kn.smo_iters < kn.max_iter ? kn.smo_iters : kn.max_iter;
+#pragma unroll 1
+        for (; iter < cd_end; ++iter) {
+            const T df = gradient_of(u);
+            const T c = masked(u, df);
             T nu = put_in_range(lo, hi, -(df - my_qd * u) * my_rqd);             // mpc.h:325-326, every lane its own
-            asm volatile("" : "+v"(nu));   // computed HERE, beside the reduction (the optimiser would sink it behind the branch)
+            asm volatile("" : "+v"(nu));   // computed HERE, beside the reduction (the optimiser would sink it)
             const T mx = wave_max<N>(c);
-            if (mx < eps) { capped = false; break; }                             // mpc.h:310-311
+            if (mx < eps) { capped = false; return; }                            // mpc.h:310-311
             const unsigned long long hit = __ballot(c == mx);
             const int best = __ffsll((long long)hit) - 1;                        // lowest index wins
-            const T qd = read_lane(my_qd, best);
-            if (qd != (T)0) {                                                    // mpc.h:322
-                if (lane == best) u = nu;
-                if (iter + 1 == kn.smo_iters) v = u;                             // mpc.h:330-334
-            }
-        } else {
-            // accelerated projected gradient (mpc.h:336-345); stop test without a reduction
+            // mpc.h:322: a zero Q_diag skips the update (the iteration still counts).  Decided per lane
+            // from the lane's own Q_diag -- no cross-lane read, no wave-uniform branch on the path.
+            const bool upd = lane == best && my_qd != (T)0;
+            u = upd ? nu : u;
+            if (iter + 1 == kn.smo_iters && __ballot(upd) != 0ull) v = u;        // mpc.h:330-334 (last CD iteration only)
+        }
+        // ---- accelerated projected gradient (mpc.h:336-345); stop test without a reduction
+#pragma unroll 1
+        for (; iter < kn.max_iter; ++iter) {
+            const T df = gradient_of(u);
+            const T c = masked(u, df);
             T v_new = clamp3(u - inv_lambda * df, lo, hi);
             T u_new = clamp3(v_new + beta * (v_new - v), lo, hi);
             asm volatile("" : "+v"(v_new), "+v"(u_new));   // computed HERE, beside the stop test
-            if (__ballot(c >= eps) == 0ull) { capped = false; break; }           // mpc.h:310-311
+            if (__ballot(c >= eps) == 0ull) { capped = false; return; }          // mpc.h:310-311
             v = v_new;
             u = u_new;
         }
-    }
-    }
+    };
+    if ((Model::kScreen && nonfinite) || badmodel) capped = false;
+    else if (mask_ok) run(std::true_type{});
+    else run(std::false_type{});
     WaveIO<T, I, H, Args>::write(g, k, active, qi, qj, u, v, iter);
     if (g.flags && lane == 0) {
         uint32_t f = 0;

@@ -34,7 +34,7 @@ namespace tpc {
 
 namespace {
 
-// ---- mailbox layout: 8-byte words of the handle's 256-byte pinned block -----------------------
+// ---- mailbox layout: 8-byte words of the handle's 512-byte pinned block (the launch path uses words 32..) -----------------------
 // line 0 (host -> device): words 0..6 payload, word 7 seq
 // line 1 (host -> device): words 8..14 payload, word 15 seq
 // line 2 (host -> device): words 16..22 payload, word 23 seq
@@ -58,14 +58,14 @@ TPC_DEV void sys_store(uint64_t* p, uint64_t x) {
     __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// One instantiation per horizon: a resident wave serves the horizon it was started for (a module
+// uses one), and the host swaps it for another when a request names a different horizon.  (One kernel
+// switching over all horizons carried the largest one's 256 registers plus 500 spilled SGPRs into
+// every solve: slower than an ordinary launch at N = 20.)
 template <int H>
-TPC_DEV void solve_h(const CompactArgs& g, const Knobs& kn, double* s_u, double* s_w) {
-    wave_solve<double, 2, H, CompactModel<double>, CompactArgs>(g, kn, 0, s_u, s_w);
-}
-
 __global__ __launch_bounds__(64) void one_shot_kernel(uint64_t* mail, uint64_t start_seq, uint64_t idle_ticks) {
-    __shared__ __attribute__((aligned(16))) double s_u[kWave + 2];
-    __shared__ __attribute__((aligned(16))) double s_w[kWave];
+    __shared__ __attribute__((aligned(16))) double s_u[2 * H + 2];
+    __shared__ __attribute__((aligned(16))) double s_w[2 * H];
     __shared__ __attribute__((aligned(16))) uint64_t s_req[kReqWords + 2];   // the request, then front, rear
     const int lane = threadIdx.x;
     uint64_t seen = start_seq;
@@ -83,27 +83,23 @@ __global__ __launch_bounds__(64) void one_shot_kernel(uint64_t* mail, uint64_t s
         __syncthreads();
         const uint64_t hq = s_req[kW_HorizonQuit];
         if ((uint32_t)(hq >> 32) != 0u) break;   // told to quit
-        const int horizon = (int)(uint32_t)hq;
         const double* rq = (const double*)s_req;
-        CompactArgs g;
-        g.n = 1;
-        g.v = rq + kW_V; g.dy = rq + kW_Dy; g.dphi = rq + kW_Dphi;       // LDS, through generic pointers
-        g.front = (double*)s_req + kReqWords; g.rear = (double*)s_req + kReqWords + 1;
-        g.iters = nullptr; g.flags = nullptr; g.work_hint = nullptr;
-        g.step = rq[kW_Step]; g.wheelbase = rq[kW_Wheelbase];
-        g.q[0] = rq[kW_Q0]; g.q[1] = rq[kW_Q1]; g.r[0] = rq[kW_R0]; g.r[1] = rq[kW_R1];
-        g.lo[0] = rq[kW_Lo0]; g.lo[1] = rq[kW_Lo1]; g.hi[0] = rq[kW_Hi0]; g.hi[1] = rq[kW_Hi1];
-        Knobs kn;
-        kn.eps = rq[kW_Eps];
-        kn.max_iter = (uint32_t)s_req[kW_Iters];
-        kn.smo_iters = (uint32_t)(s_req[kW_Iters] >> 32);
-        switch (horizon) {
-            case 4: solve_h<4>(g, kn, s_u, s_w); break;
-            case 5: solve_h<5>(g, kn, s_u, s_w); break;
-            case 10: solve_h<10>(g, kn, s_u, s_w); break;
-            case 20: solve_h<20>(g, kn, s_u, s_w); break;
-            case 30: solve_h<30>(g, kn, s_u, s_w); break;
-            default: s_req[kReqWords] = s_req[kReqWords + 1] = 0x7ff8000000000bad; break;   // host never asks
+        if ((int)(uint32_t)hq == H) {
+            CompactArgs g;
+            g.n = 1;
+            g.v = rq + kW_V; g.dy = rq + kW_Dy; g.dphi = rq + kW_Dphi;       // LDS, through generic pointers
+            g.front = (double*)s_req + kReqWords; g.rear = (double*)s_req + kReqWords + 1;
+            g.iters = nullptr; g.flags = nullptr; g.work_hint = nullptr;
+            g.step = rq[kW_Step]; g.wheelbase = rq[kW_Wheelbase];
+            g.q[0] = rq[kW_Q0]; g.q[1] = rq[kW_Q1]; g.r[0] = rq[kW_R0]; g.r[1] = rq[kW_R1];
+            g.lo[0] = rq[kW_Lo0]; g.lo[1] = rq[kW_Lo1]; g.hi[0] = rq[kW_Hi0]; g.hi[1] = rq[kW_Hi1];
+            Knobs kn;
+            kn.eps = rq[kW_Eps];
+            kn.max_iter = (uint32_t)s_req[kW_Iters];
+            kn.smo_iters = (uint32_t)(s_req[kW_Iters] >> 32);
+            wave_solve<double, 2, H, CompactModel<double>, CompactArgs>(g, kn, 0, s_u, s_w);
+        } else {
+            s_req[kReqWords] = s_req[kReqWords + 1] = 0x7ff8000000000badull;   // the host never asks this
         }
         __syncthreads();
         // two 8-byte stores, each atomic for the host: they are the completion signal
@@ -120,6 +116,7 @@ __global__ __launch_bounds__(64) void one_shot_kernel(uint64_t* mail, uint64_t s
 struct OneShot {
     hipStream_t stream = nullptr;
     uint64_t seq = 0;
+    int horizon = 0;         // of the resident wave (0: none was started yet)
     uint64_t idle_us = 20000;
     bool disabled = false;   // set after a resident kernel failed to answer: ordinary launches from then on
 };
@@ -128,14 +125,34 @@ namespace {
 
 inline volatile uint64_t* mailbox(tpc_mpc_context* h) { return (volatile uint64_t*)h->pin_host; }
 
-int start_kernel(tpc_mpc_context* h, OneShot* o, uint64_t start_seq) {
+int start_kernel(tpc_mpc_context* h, OneShot* o, int horizon, uint64_t start_seq) {
     volatile uint64_t* m = mailbox(h);
     m[kW_Alive] = 1;
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
-    hipLaunchKernelGGL(one_shot_kernel, dim3(1), dim3(kWave), 0, o->stream, (uint64_t*)h->pin_dev, start_seq,
-                       o->idle_us * 100ull);
+    uint64_t* dev = (uint64_t*)h->pin_dev;
+    const uint64_t ticks = o->idle_us * 100ull;
+    switch (horizon) {
+#define X(hh) case hh: hipLaunchKernelGGL(one_shot_kernel<hh>, dim3(1), dim3(kWave), 0, o->stream, dev, start_seq, ticks); break;
+        X(4) X(5) X(10) X(20) X(30)
+#undef X
+        default: m[kW_Alive] = 0; return fail(h, TPC_MPC_ERR_BAD_HORIZON, "no resident kernel for horizon %d", horizon);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { m[kW_Alive] = 0; return hip_fail(h, e, "resident kernel launch"); }
+    o->horizon = horizon;
+    return TPC_MPC_OK;
+}
+
+// Ask the running wave to leave (a request whose quit flag is set) and wait for it.
+int stop_kernel(tpc_mpc_context* h, OneShot* o) {
+    volatile uint64_t* m = mailbox(h);
+    if (o->stream && m[kW_Alive]) {
+        const uint64_t seq = ++o->seq;
+        m[kW_HorizonQuit] = 1ull << 32;
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        m[kW_Seq0] = seq; m[kW_Seq1] = seq; m[kW_Seq2] = seq;
+        HIP_TRY(h, hipStreamSynchronize(o->stream));   // bounded: quit flag, idle timeout, poll cap
+    }
     return TPC_MPC_OK;
 }
 
@@ -184,15 +201,9 @@ int launch_path(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double dy
 void one_shot_destroy(tpc_mpc_context* h) {
     if (!h || !h->one) return;
     OneShot* o = h->one;
-    volatile uint64_t* m = mailbox(h);
     if (o->stream) {
-        if (m[kW_Alive]) {   // ask the wave to leave: a request whose quit flag is set
-            const uint64_t seq = ++o->seq;
-            m[kW_HorizonQuit] = 1ull << 32;
-            __atomic_thread_fence(__ATOMIC_RELEASE);
-            m[kW_Seq0] = seq; m[kW_Seq1] = seq; m[kW_Seq2] = seq;
-        }
-        (void)hipStreamSynchronize(o->stream);   // bounded: quit flag, idle timeout, poll cap
+        (void)stop_kernel(h, o);
+        (void)hipStreamSynchronize(o->stream);
         (void)hipStreamDestroy(o->stream);
     }
     delete o;
@@ -206,14 +217,8 @@ int one_shot_configure(tpc_mpc_context* h, int64_t idle_us) {
     }
     OneShot* o = h->one;
     if (idle_us <= 0) {   // resident mode off: stop a running wave, keep the launch path
-        volatile uint64_t* m = mailbox(h);
-        if (o->stream && m[kW_Alive]) {
-            const uint64_t seq = ++o->seq;
-            m[kW_HorizonQuit] = 1ull << 32;
-            __atomic_thread_fence(__ATOMIC_RELEASE);
-            m[kW_Seq0] = seq; m[kW_Seq1] = seq; m[kW_Seq2] = seq;
-            HIP_TRY(h, hipStreamSynchronize(o->stream));
-        }
+        int rc = stop_kernel(h, o);
+        if (rc) return rc;
         o->disabled = true;
         return TPC_MPC_OK;
     }
@@ -233,6 +238,10 @@ int one_shot_solve(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double
     if (!resident_ok) return launch_path(h, p, v, dy, dphi, front, rear);
     if (!o->stream) HIP_TRY(h, hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking));
     volatile uint64_t* m = mailbox(h);
+    if (o->horizon != p->horizon && o->horizon != 0) {   // the resident wave serves another horizon: swap it
+        int rc = stop_kernel(h, o);
+        if (rc) return rc;
+    }
     auto put = [&](int w, double x) { uint64_t b; std::memcpy(&b, &x, 8); m[w] = b; };
     const uint64_t prev = o->seq, seq = ++o->seq;
     m[kW_HorizonQuit] = (uint64_t)(uint32_t)p->horizon;
@@ -247,7 +256,7 @@ int one_shot_solve(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double
     m[kW_Seq0] = seq; m[kW_Seq1] = seq; m[kW_Seq2] = seq;
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
     if (!m[kW_Alive]) {
-        int rc = start_kernel(h, o, prev);   // it finds the request already waiting
+        int rc = start_kernel(h, o, p->horizon, prev);   // it finds the request already waiting
         if (rc) return rc;
     }
     const auto t0 = std::chrono::steady_clock::now();
@@ -259,7 +268,7 @@ int one_shot_solve(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double
             // the wave left (idle timeout) just as the request was posted: start another one for it
             if (m[kW_Front] != kSentinel && m[kW_Rear] != kSentinel) break;
             if (++restarts > 3) { o->disabled = true; return launch_path(h, p, v, dy, dphi, front, rear); }
-            int rc = start_kernel(h, o, prev);
+            int rc = start_kernel(h, o, p->horizon, prev);
             if (rc) return rc;
         }
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {

@@ -170,18 +170,30 @@ def main():
         # The library's own RCCL communicator (one per handle): rank 0 makes the id, torch.distributed
         # hands it to the other ranks.  If the library cannot set it up (RCCL not loadable), say so
         # loudly and gather with torch.distributed instead -- the solve is the library's either way.
+        # Step 1, local and therefore safe to fail on one rank only: can this rank load RCCL and make an id?
+        # Step 2 only if EVERY rank can: ncclCommInitRank is a collective, a rank that stayed away from
+        # it would leave the others waiting.
+        probe_err = ""
         try:
-            for sv in solvers:
-                idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-                if rank == 0:
-                    idt.copy_(torch.frombuffer(bytearray(MpcSolver.comm_unique_id()), dtype=torch.uint8))
-                dist.broadcast(idt, src=0)
-                sv.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
-            gather_path = "library: tpc_mpc_solve_batch_compact_sharded (ncclAllGather over RCCL)"
+            my_id = MpcSolver.comm_unique_id()
         except Exception as exc:   # noqa: BLE001 -- reported, not hidden
-            print(f"[bench] rank {rank}: library RCCL path unavailable ({exc}); gathering with torch.distributed",
+            my_id, probe_err = bytes(128), str(exc)
+        ok = torch.tensor([0 if probe_err else 1], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            try:
+                for sv in solvers:
+                    idt = torch.frombuffer(bytearray(MpcSolver.comm_unique_id() if rank == 0 else my_id),
+                                           dtype=torch.uint8).to(dev)
+                    dist.broadcast(idt, src=0)
+                    sv.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+                gather_path = "library: tpc_mpc_solve_batch_compact_sharded (ncclAllGather over RCCL)"
+            except Exception as exc:   # noqa: BLE001
+                probe_err = str(exc)
+        if probe_err:
+            print(f"[bench] rank {rank}: library RCCL path unavailable ({probe_err}); gathering with torch.distributed",
                   file=sys.stderr, flush=True)
-            gather_path = f"torch.distributed all_gather (library RCCL path failed: {exc})"
+            gather_path = f"torch.distributed all_gather (library RCCL path failed: {probe_err})"
         ok = torch.tensor([1 if gather_path.startswith("library") else 0], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # all ranks take the same path
         if int(ok.item()) == 0 and gather_path.startswith("library"):

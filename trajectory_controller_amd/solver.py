@@ -38,6 +38,7 @@ class MpcSolver:
         self.algo = {"auto": capi.ALGO_AUTO, "wave": capi.ALGO_WAVE, "lane": capi.ALGO_LANE}[algo]
         self.params = capi.default_params(horizon, self.dtype, self.algo, **params)
         self.last_flags = 0
+        self.rank, self.world = 0, 1     # a handle without a communicator is a world of one
 
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self):
@@ -239,9 +240,12 @@ class MpcSolver:
         import torch
         p = self._params(**over)
         tdt = torch.float64 if p.dtype == capi.F64 else torch.float32
+        first, count = C.c_int64(), C.c_int64()
+        self._lib.tpc_mpc_shard_range(int(n_total), self.rank, self.world, C.byref(first), C.byref(count))
         for t in (v_shard, dy_shard, dphi_shard):
-            if not (t.is_cuda and t.dtype == tdt and t.is_contiguous()):
-                raise ValueError("shard arrays must be contiguous CUDA tensors of the solver dtype")
+            if not (t.is_cuda and t.dtype == tdt and t.is_contiguous() and t.numel() == count.value):
+                raise ValueError(f"shard arrays must be contiguous CUDA tensors of the solver dtype holding this "
+                                 f"rank's {count.value} instances (rank {self.rank} of {self.world}, n_total {n_total})")
         if out is None:
             front = torch.empty(n_total, dtype=tdt, device=v_shard.device)
             rear = torch.empty(n_total, dtype=tdt, device=v_shard.device)

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Randomised differential run on the GPU box: WAVE fp64 (both mask forms, DPP and LDS exchange, every
+horizon it exists for) against the CPU oracle with random weights, bounds, step size, wheelbase, eps
+and iteration caps.  The WAVE family is not bit-exact (different summation order, FMA, a reciprocal
+instead of a division), so this counts what matters for it: instances whose ITERATION COUNT differs
+from dlib's (a decision flipped somewhere) and the largest |du| among the others.
+    python tests/extended/fuzz_wave.py [sets] [n]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from oracle.bindings import Oracle, build_oracle
+from trajectory_controller_amd import MpcSolver
+from trajectory_controller_amd.synth import compact_inputs
+
+build_oracle()
+orc = Oracle()
+rng = np.random.default_rng(int(os.environ.get("SEED", "20261004")))
+sets = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+threads = int(os.environ.get("THREADS", "16"))
+flips = total = 0
+worst = 0.0
+for s_i in range(sets):
+    H = (4, 5, 10, 20, 30)[s_i % 5]
+    m = n if H <= 20 else n // 3
+    w = (10 ** rng.uniform(-1, 2), 10 ** rng.uniform(-1, 2), 10 ** rng.uniform(-4, 1), 10 ** rng.uniform(-2, 1.5))
+    kind = rng.integers(0, 4)
+    if kind == 0:   lo, hi = (-0.384, -0.384), (0.384, 0.384)
+    elif kind == 1: a, b = rng.uniform(0.02, 0.6, 2); lo, hi = (-a, -b), (b, a)
+    elif kind == 2: a = rng.uniform(0.05, 0.5); lo, hi = (0.0, -a), (a, 0.0)        # start point on a bound: exact mask
+    else:           a = rng.uniform(1e-3, 2e-2); lo, hi = (-a, -a), (a, a)
+    T = float(rng.uniform(0.02, 0.3)); l = float(rng.uniform(0.1, 0.5))
+    eps = float(10 ** rng.uniform(-4, -1)); cap = int(rng.choice([10000, 10000, 10000, 300, 77, 51, 50, 20]))
+    smo = int(rng.choice([50, 50, 50, 0, 7, 120]))
+    v, dy, dphi = compact_inputs(H, m, first=int(rng.integers(0, 1 << 30)))
+    of, orr, oit = orc.solve_compact(H, v, dy, dphi, weights=w, T=T, l=l, lo=lo, hi=hi, eps=eps,
+                                     max_iter=cap, smo_iters=smo, nthreads=threads)
+    with MpcSolver(horizon=H, algo="wave", weight_y=w[0], weight_phi=w[1], weight_steering_front=w[2],
+                   weight_steering_rear=w[3], lower=lo, upper=hi, step_size=T, wheelbase=l, eps=eps,
+                   max_iter=cap, smo_iters=smo) as s:
+        f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+    same = it == oit
+    err = np.maximum(np.abs(f - of), np.abs(r - orr))
+    flips += int((~same).sum()); total += m
+    if same.any():
+        worst = max(worst, float(err[same].max()))
+    print(f"set {s_i:3d} H={H:2d} n={m:5d} bounds kind {kind} eps {eps:.1e} cap {cap:5d} smo {smo:3d}: "
+          f"iteration counts differ on {int((~same).sum())}, max|du| elsewhere {err[same].max() if same.any() else 0:.2e}", flush=True)
+print(f"{sets} parameter sets, {total} instances: iteration counts differ on {flips} ({flips / total:.2e}); "
+      f"max |du| among the rest {worst:.2e}")
+sys.exit(1 if worst > 1e-7 or flips > 1e-4 * total else 0)

@@ -41,7 +41,8 @@ typedef enum tpc_mpc_status {
     TPC_MPC_ERR_BAD_ARG = 1,        /* null pointer, n < 0, ld < n, unknown enum value          */
     TPC_MPC_ERR_BAD_WEIGHTS = 2,    /* min(Q) < 0 or min(R) <= 0   (mpc_abstract.h:90-97)       */
     TPC_MPC_ERR_BAD_BOUNDS = 3,     /* upper < lower               (mpc_abstract.h:90-97)       */
-    TPC_MPC_ERR_BAD_HORIZON = 4,    /* horizon not one of tpc_mpc_supported_horizons()          */
+    TPC_MPC_ERR_BAD_HORIZON = 4,    /* horizon outside 1..64, or a kernel family that does not
+                                       exist for it was demanded                                */
     TPC_MPC_ERR_BAD_EPS = 5,        /* eps <= 0                    (mpc.h:202 set_epsilon)      */
     TPC_MPC_ERR_NO_DEVICE = 6,      /* no gfx950 GPU / HIP runtime unusable                     */
     TPC_MPC_ERR_HIP = 7,            /* a HIP call failed; text in tpc_mpc_last_error            */
@@ -109,7 +110,10 @@ int tpc_mpc_destroy(tpc_mpc_handle h);
 /* Text of the last error on this handle (or of the last failed create when h == NULL). */
 const char* tpc_mpc_last_error(tpc_mpc_handle h);
 
-/* Writes up to `cap` supported horizons, returns how many exist. */
+/* dlib::mpc<2,I,H> is a template: any horizon compiles.  Here every horizon 1 <= H <= 64 is accepted;
+ * the ones this function lists (writes up to `cap`, returns how many exist) have kernels specialised
+ * at compile time (LANE, and WAVE where I*H <= 64), every other one runs a generic kernel with H as a
+ * run-time value -- the same arithmetic, the same results (fp64: bit for bit), several times slower. */
 int tpc_mpc_supported_horizons(int* out, int cap);
 int tpc_mpc_abi_version(void);
 /* How this binary was made: ABI version, target, and the LLVM machine scheduler each per-horizon
@@ -152,8 +156,8 @@ int tpc_mpc_solve_batch_compact(tpc_mpc_handle h, const tpc_mpc_params* p, int64
 /* Mixed-horizon batch (BASELINE.json config 5): instance k is solved with horizon horizons[k]
  * (int32, in `mem` like the other arrays); p->horizon is ignored.  The batch is binned by horizon on
  * the device, every bin runs its horizon's kernels, and the outputs come back in the caller's
- * order.  A horizon outside tpc_mpc_supported_horizons() anywhere in the batch fails the call with
- * TPC_MPC_ERR_BAD_HORIZON before anything is solved.  Unlike tpc_mpc_solve_batch_compact this call
+ * order.  Only the specialised horizons (tpc_mpc_supported_horizons()) can be mixed: any other value
+ * anywhere in the batch fails the call with TPC_MPC_ERR_BAD_HORIZON before anything is solved.  Unlike tpc_mpc_solve_batch_compact this call
  * synchronises `stream` once internally (the bin sizes decide the launches). */
 int tpc_mpc_solve_batch_compact_mixed(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n,
                                       const int32_t* horizons, const void* v, const void* delta_y,

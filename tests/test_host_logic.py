@@ -55,8 +55,9 @@ def test_default_params_match_reference_defaults():
     assert (p.step_size, p.wheelbase) == (0.1, 0.21)                                     # follower.cpp:96, .h:47
     assert (p.weight_y, p.weight_phi, p.weight_steering_front, p.weight_steering_rear) == (20, 7, 0.0005, 10)
     assert p.upper[0] == 22 * np.pi / 180 and p.lower[1] == -22 * np.pi / 180           # follower.cpp:16-18
+    assert capi.default_params(7).horizon == 7            # any 1..64: generic kernel
     with pytest.raises(capi.TpcMpcError):
-        capi.default_params(7)
+        capi.default_params(65)
     import ctypes as C
     hs = (C.c_int * 16)()
     n = capi.load_library().tpc_mpc_supported_horizons(hs, 16)

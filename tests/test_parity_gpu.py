@@ -154,8 +154,12 @@ def test_solve_one_reference_samples(torch_cuda):
 def test_bad_arguments(torch_cuda):
     from trajectory_controller_amd import MpcSolver, TpcMpcError
     with pytest.raises(TpcMpcError) as e:
-        MpcSolver(horizon=7)
+        MpcSolver(horizon=65)                  # 1 .. 64 are accepted (generic kernel beyond the specialised ones)
     assert e.value.status == 4
+    with MpcSolver(horizon=7, algo="wave") as s:
+        with pytest.raises(TpcMpcError) as e:   # no WAVE kernel for a non-specialised horizon
+            s.solve_batch_compact(np.array([1.0]), np.array([0.1]), np.array([0.05]))
+        assert e.value.status == 4
     with MpcSolver(horizon=10) as s:
         one = (np.array([1.0]), np.array([0.1]), np.array([0.05]))
         for over, status in ((dict(weight_steering_rear=0.0), 2), (dict(weight_y=-1.0), 2),
@@ -739,3 +743,37 @@ def test_wave_mask_forms_vs_oracle(torch_cuda, oracle, I):
     g["targets"][5, 3, 1] = np.nan
     g["targets"][9, 0, 0] = np.inf
     run(g)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("H", [1, 2, 3, 7, 8, 15, 25, 33, 64])
+def test_generic_horizon_vs_oracle(torch_cuda, oracle, oracle32, H, dtype):
+    """Horizons without a specialised kernel (dlib's horizon is a template parameter: any value
+    compiles there) run the generic kernel: compact form, general form cold, and general form with
+    the controller state in and out -- bits and iteration counts against the oracle of the same type."""
+    from trajectory_controller_amd.synth import compact_inputs, general_inputs
+    orc, npdt, eq = (oracle, np.float64, bits_equal) if dtype == "f64" else (oracle32, np.float32, bits_equal32)
+    n = 500 if H <= 33 else 130
+    v, dy, dphi = (a.astype(npdt) for a in compact_inputs(H, n, first=77000))
+    of, orr, oit = orc.solve_compact(H, v, dy, dphi, nthreads=8)
+    with _solver(H, "auto", dtype=dtype) as s:
+        f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+        assert np.array_equal(it, oit)
+        assert eq(f, of) and eq(r, orr)
+        f1, r1 = s.solve_one(float(v[3]), float(dy[3]), float(dphi[3]))      # a launch of the generic kernel
+        assert f1 == of[3] and r1 == orr[3]
+        for I in (1, 2):
+            g = {k: a.astype(npdt) for k, a in general_inputs(H, n, I=I, first=9100 + H).items()}
+            u0, _, git0 = orc.solve_general(I, H, *[g[k] for k in GEN_NAMES], nthreads=8)
+            gu0, git = s.solve_batch_general(*[_soa(g[k]) for k in GEN_NAMES], inputs=I, want_iters=True)
+            assert np.array_equal(git, git0) and eq(gu0.T, u0), I
+            rng = np.random.default_rng(H + I)
+            cin = rng.uniform(-0.3, 0.3, size=(n, H, I)).astype(npdt)
+            vin = rng.uniform(-0.3, 0.3, size=(n, H, I)).astype(npdt)
+            u0, cout, git0, vout = orc.solve_general(I, H, *[g[k] for k in GEN_NAMES], controls_in=cin, v_in=vin,
+                                                     want_v=True, nthreads=8)
+            controls, vstate = _soa(cin), _soa(vin)
+            gu0, git = s.solve_batch_general(*[_soa(g[k]) for k in GEN_NAMES], controls=controls, v_state=vstate,
+                                             inputs=I, want_iters=True)
+            assert np.array_equal(git, git0) and eq(gu0.T, u0), I
+            assert eq(controls.T.reshape(n, H, I), cout) and eq(vstate.T.reshape(n, H, I), vout), I

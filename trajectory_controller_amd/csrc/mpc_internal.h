@@ -56,6 +56,13 @@ struct Workspace {
     hipEvent_t* ev;
 };
 
+// mpc_generic.hip: the any-horizon fallback (run-time H, per-instance arrays in a global workspace)
+constexpr int kAlgoGeneric = 3;   // internal kernel-family code next to TPC_MPC_ALGO_WAVE / _LANE
+constexpr int kMaxHorizon = 64;
+int64_t generic_scratch_bytes(int H, int dtype, int64_t n);
+hipError_t generic_compact(int dtype, int H, const CompactArgs& a, const Knobs& k, void* scratch, hipStream_t s);
+hipError_t generic_general(int dtype, int I, int H, const GeneralArgs& a, const Knobs& k, void* scratch, hipStream_t s);
+
 // mpc_sort.hip
 size_t sort_temp_bytes(int64_t n);
 hipError_t order_begin(void* temp, hipStream_t s);   // zero the bins the key producer counts into

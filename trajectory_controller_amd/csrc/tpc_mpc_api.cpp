@@ -28,10 +28,12 @@ static const int kHorizons[] = {4, 5, 10, 20, 30, 40};
 
 namespace {
 
-bool horizon_ok(int H) {
+// horizons with specialised kernels; every other 1 <= H <= kMaxHorizon takes the generic kernel
+bool horizon_specialised(int H) {
     for (int h : kHorizons) if (h == H) return true;
     return false;
 }
+bool horizon_ok(int H) { return H >= 1 && H <= kMaxHorizon; }
 
 Knobs knobs_of(const tpc_mpc_params* p) {
     Knobs k;
@@ -56,6 +58,7 @@ const int32_t* take_hint(tpc_mpc_context* h, int64_t n) {
 // The WAVE kernel maps one decision variable to one lane, so it exists for I*H <= 64 only.
 // Returns the kernel family to run, or -1 when WAVE was demanded for a shape it cannot take.
 int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n) {
+    if (!horizon_specialised(H)) return algo == TPC_MPC_ALGO_WAVE ? -1 : kAlgoGeneric;
     const bool wave_ok = I * H <= kWave;
     if (algo == TPC_MPC_ALGO_WAVE) return wave_ok ? algo : -1;
     if (algo == TPC_MPC_ALGO_LANE) return algo;
@@ -73,8 +76,17 @@ int64_t lane_rec_len(int H, int dtype) {
     return 0;
 }
 
+// the generic kernel is one launch: bracket it with the profiling events like the WAVE launcher does
+template <class Launch> hipError_t generic_launch(const Workspace& ws, hipStream_t s, Launch launch) {
+    if (ws.ev) (void)hipEventRecord(ws.ev[0], s);
+    const hipError_t e = launch();
+    if (ws.ev) { (void)hipEventRecord(ws.ev[1], s); (void)hipEventRecord(ws.ev[2], s); }
+    return e;
+}
+
 hipError_t dispatch_compact(int algo, int H, int dtype, const CompactArgs& a, const Knobs& k,
                             const Workspace& ws, hipStream_t s) {
+    if (algo == kAlgoGeneric) return generic_launch(ws, s, [&] { return generic_compact(dtype, H, a, k, ws.state, s); });
     switch (H) {
 #define X(h) case h: return algo == TPC_MPC_ALGO_LANE ? lane_compact_h##h(dtype, a, k, ws, s) \
                                                        : wave_compact_h##h(dtype, a, k, ws, s);
@@ -85,6 +97,7 @@ hipError_t dispatch_compact(int algo, int H, int dtype, const CompactArgs& a, co
 }
 hipError_t dispatch_general(int algo, int I, int H, int dtype, const GeneralArgs& a, const Knobs& k,
                             const Workspace& ws, hipStream_t s) {
+    if (algo == kAlgoGeneric) return generic_launch(ws, s, [&] { return generic_general(dtype, I, H, a, k, ws.state, s); });
     switch (H) {
 #define X(h) case h: return algo == TPC_MPC_ALGO_LANE ? lane_general_h##h(dtype, I, a, k, ws, s) \
                                                        : wave_general_h##h(dtype, I, a, k, ws, s);
@@ -105,6 +118,12 @@ int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n,
     ws->keys = ws->rank = ws->order = nullptr;
     ws->sort_temp = nullptr;
     ws->sort_temp_bytes = 0;
+    if (algo == kAlgoGeneric) {
+        int rc = ensure(h, &h->ws_state, &h->ws_bytes, pad256(generic_scratch_bytes(H, dtype, n)));
+        if (rc) return rc;
+        ws->state = h->ws_state;
+        ws->capacity_bytes = h->ws_bytes;
+    }
     if (algo == TPC_MPC_ALGO_LANE) {
         // records | keys | rank | order | counting-sort bins
         const int64_t rec_b = pad256(lane_rec_len(H, dtype) * (int64_t)esize(dtype) * n);
@@ -149,7 +168,7 @@ int check_common(tpc_mpc_context* h, const tpc_mpc_params* p) {
     if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
     if (!p) return fail(h, TPC_MPC_ERR_BAD_ARG, "null params");
     if (!horizon_ok(p->horizon))
-        return fail(h, TPC_MPC_ERR_BAD_HORIZON, "unsupported horizon %d (supported: 4 5 10 20 30 40)", p->horizon);
+        return fail(h, TPC_MPC_ERR_BAD_HORIZON, "horizon %d outside 1 .. %d", p->horizon, kMaxHorizon);
     if (p->dtype != TPC_MPC_F64 && p->dtype != TPC_MPC_F32) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad dtype");
     if (p->algo < TPC_MPC_ALGO_AUTO || p->algo > TPC_MPC_ALGO_LANE) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad algo");
     if (!(p->eps > 0)) return fail(h, TPC_MPC_ERR_BAD_EPS, "eps must be > 0 (mpc.h:202)");
@@ -200,7 +219,7 @@ int reserve_lane_workspace(tpc_mpc_context* h, int H, int dtype, int64_t n) {
     const bool ev_valid = h->ev_valid;
     const int last_algo = h->last_algo;
     Workspace ws;
-    const int rc = prepare_workspace(h, TPC_MPC_ALGO_LANE, H, dtype, n, &ws);
+    const int rc = prepare_workspace(h, horizon_specialised(H) ? TPC_MPC_ALGO_LANE : kAlgoGeneric, H, dtype, n, &ws);
     h->ev_valid = ev_valid;
     h->last_algo = last_algo;
     return rc;
@@ -209,7 +228,7 @@ int reserve_lane_workspace(tpc_mpc_context* h, int H, int dtype, int64_t n) {
 int compact_launch(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy,
                    const void* dphi, void* front, void* rear, int32_t* iters, hipStream_t s) {
     const int algo = pick_algo(h, p->algo, 2, p->horizon, n);
-    if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel needs inputs*horizon <= 64; use LANE or AUTO");
+    if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel exists for the specialised horizons with inputs*horizon <= 64 only; use LANE or AUTO");
     CompactArgs a;
     std::memset(&a, 0, sizeof(a));
     a.n = n;
@@ -408,7 +427,7 @@ int tpc_mpc_solve_batch_general(tpc_mpc_handle h, const tpc_mpc_params* p,
         const int I = io->inputs, H = p->horizon;
         const int64_t n = io->n;
         const int algo = pick_algo(h, p->algo, I, H, n);
-        if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel needs inputs*horizon <= 64; use LANE or AUTO");
+        if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel exists for the specialised horizons with inputs*horizon <= 64 only; use LANE or AUTO");
         rc = stream_order_begin(h, s);
         if (rc) return rc;
 
@@ -495,7 +514,7 @@ int tpc_mpc_rollout(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mpc_gen
         const int I = io->inputs, H = p->horizon;
         const int64_t n = io->n, ld = io->ld;
         const int algo = pick_algo(h, p->algo, I, H, n);
-        if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel needs inputs*horizon <= 64; use LANE or AUTO");
+        if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel exists for the specialised horizons with inputs*horizon <= 64 only; use LANE or AUTO");
         rc = stream_order_begin(h, s);
         if (rc) return rc;
         const bool host = mem == TPC_MPC_HOST;
@@ -678,7 +697,7 @@ int tpc_mpc_follow_batch_horizon(tpc_mpc_handle h, const tpc_mpc_params* p, cons
         const int64_t n = t->n;
         const int H = p->horizon, I = 2;
         const int algo = pick_algo(h, p->algo, I, H, n);
-        if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel needs inputs*horizon <= 64; use LANE or AUTO");
+        if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel exists for the specialised horizons with inputs*horizon <= 64 only; use LANE or AUTO");
         rc = stream_order_begin(h, s);
         if (rc) return rc;
         // general-form batch built on device: A[4] B[4] C[2] Q[2] R[2] lo[2] hi[2] x0[2] targets[2H] u0[2]

@@ -159,7 +159,7 @@ int stop_kernel(tpc_mpc_context* h, OneShot* o) {
 // The pre-resident path: one WAVE/LANE launch through the handle's mapped block, polled the same way.
 int launch_path(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double dy, double dphi, double* front, double* rear) {
     tpc_mpc_params q = *p;
-    if (q.algo == TPC_MPC_ALGO_AUTO && 2 * q.horizon <= kWave) q.algo = TPC_MPC_ALGO_WAVE;   // one instance: one wavefront
+    // one instance: one wavefront, where a WAVE kernel exists; AUTO sorts out the other horizons itself
     const size_t es = esize(q.dtype);
     char* hp = (char*)h->pin_host + 32 * 8;   // words 32..: apart from the resident kernel's lines
     char* dp = (char*)h->pin_dev + 32 * 8;
@@ -233,8 +233,9 @@ int one_shot_solve(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double
         if (rc) return rc;
     }
     OneShot* o = h->one;
+    const int H = p->horizon;   // resident kernels exist for the specialised horizons the WAVE layout can take
     const bool resident_ok = !o->disabled && p->dtype == TPC_MPC_F64 && p->algo != TPC_MPC_ALGO_LANE &&
-                             2 * p->horizon <= kWave;
+                             (H == 4 || H == 5 || H == 10 || H == 20 || H == 30);
     if (!resident_ok) return launch_path(h, p, v, dy, dphi, front, rear);
     if (!o->stream) HIP_TRY(h, hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking));
     volatile uint64_t* m = mailbox(h);

@@ -52,8 +52,8 @@ FP32_VECTOR_PEAK_TF = 157.3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=262144, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--algo", default="auto", choices=["auto", "lane", "wave"])

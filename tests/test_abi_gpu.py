@@ -253,6 +253,28 @@ def test_sharded_entry_world_of_one(torch_cuda):
     assert torch.equal(f, f2) and torch.equal(r, r2) and int(it.min()) >= 0
 
 
+@pytest.mark.parametrize("form", ["1", "2"])
+def test_sharded_entry_through_rccl_world_of_one(torch_cuda, monkeypatch, form):
+    """The RCCL calls themselves on the one-GPU box: TPC_MPC_FORCE_RCCL=1 makes tpc_mpc_comm_init_rank build
+    a real one-rank communicator (dlopen, ncclGetUniqueId, ncclCommInitRank), and the sharded solve then
+    runs its grouped in-place ncclAllGather (form "1") or the per-owner ncclBroadcast of ragged batches
+    (form "2") on the caller's stream.  Results = the plain solve."""
+    from trajectory_controller_amd import MpcSolver
+    from trajectory_controller_amd.synth import compact_inputs
+    torch = torch_cuda
+    monkeypatch.setenv("TPC_MPC_FORCE_RCCL", form)
+    H, n = 10, 4097
+    v, dy, dphi = (torch.from_numpy(a).cuda() for a in compact_inputs(H, n, first=11))
+    with _solver(H, "lane") as s:
+        want = s.solve_batch_compact(v, dy, dphi)
+        s.comm_init(MpcSolver.comm_unique_id(), 0, 1)
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            f, r = s.solve_batch_compact_sharded(n, v, dy, dphi)
+        stream.synchronize()
+    assert torch.equal(f, want[0]) and torch.equal(r, want[1])
+
+
 _RANK_WORKER = r'''
 import os, sys
 sys.path.insert(0, {root!r})

@@ -15,6 +15,7 @@
 #include "tpc_mpc_context.h"
 
 #include <dlfcn.h>
+#include <cstdlib>
 #include <mutex>
 #include <rccl/rccl.h>   // types and prototypes only; the symbols are resolved by dlsym below
 
@@ -126,7 +127,10 @@ int tpc_mpc_comm_init_rank(tpc_mpc_handle h, const void* id, size_t len, int ran
         if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
         if (world < 1 || rank < 0 || rank >= world) return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= rank < world");
         comm_destroy(h);
-        if (world == 1) return TPC_MPC_OK;   // a world of one needs no communicator
+        // a world of one needs no communicator -- unless the caller insists (TPC_MPC_FORCE_RCCL=1, or 2 for the ragged form of the gather: lets a
+        // one-GPU box exercise the RCCL calls themselves, which is how tests/test_abi_gpu.py uses it)
+        const char* force = std::getenv("TPC_MPC_FORCE_RCCL");
+        if (world == 1 && !(force && (force[0] == '1' || force[0] == '2'))) return TPC_MPC_OK;
         if (!id || len < TPC_MPC_COMM_ID_BYTES) return fail(h, TPC_MPC_ERR_BAD_ARG, "id must hold %d bytes", TPC_MPC_COMM_ID_BYTES);
         Rccl* r = rccl();
         if (!r) return fail(h, TPC_MPC_ERR_COMM, "RCCL is not available in this process: %s", g_rccl.why);
@@ -207,13 +211,14 @@ int tpc_mpc_solve_batch_compact_sharded(tpc_mpc_handle h, const tpc_mpc_params* 
                                 iters_shard, s);
             if (rc) return rc;
         }
-        if (world > 1) {
+        if (world > 1 || h->comm) {
             Rccl* r = rccl();
             if (!r) return fail(h, TPC_MPC_ERR_COMM, "RCCL is not available in this process: %s", g_rccl.why);
             const ncclDataType_t dt = p->dtype == TPC_MPC_F64 ? ncclFloat64 : ncclFloat32;
             ncclComm_t c = h->comm->comm;
             RCCL_TRY(h, r, r->GroupStart());
-            if (n_total % world == 0) {
+            const char* force = std::getenv("TPC_MPC_FORCE_RCCL");   // '2': take the ragged form whatever the sizes (tests)
+            if (n_total % world == 0 && !(force && force[0] == '2')) {
                 // equal blocks: two in-place all-gathers (each rank's send buffer IS its slot of the receive buffer)
                 RCCL_TRY(h, r, r->AllGather(front + first * es, front, (size_t)count, dt, c, s));
                 RCCL_TRY(h, r, r->AllGather(rear + first * es, rear, (size_t)count, dt, c, s));

@@ -114,7 +114,8 @@ __global__ __launch_bounds__(64) void one_shot_kernel(uint64_t* mail, uint64_t s
 }  // namespace
 
 struct OneShot {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // the resident wave's
+    hipStream_t launch_stream = nullptr;   // ordinary single-solve launches (horizons / dtypes without a resident kernel)
     uint64_t seq = 0;
     int horizon = 0;         // of the resident wave (0: none was started yet)
     uint64_t idle_us = 20000;
@@ -170,13 +171,18 @@ int launch_path(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double dy
     const uint32_t sentinel32 = 0x7fc5eed1u;
     if (q.dtype == TPC_MPC_F64) { std::memcpy(hp + 3 * es, &sentinel64, 8); std::memcpy(hp + 4 * es, &sentinel64, 8); }
     else { std::memcpy(hp + 3 * es, &sentinel32, 4); std::memcpy(hp + 4 * es, &sentinel32, 4); }
-    int rc = stream_order_begin(h, nullptr);
+    // on the handle's own non-blocking stream, not the NULL stream (which would serialise with every
+    // blocking stream of the process); ordered against the handle's other solves like any solve
+    // (a stream of its own: the resident wave occupies the other one for as long as it lives)
+    OneShot* o = h->one;
+    if (!o->launch_stream) HIP_TRY(h, hipStreamCreateWithFlags(&o->launch_stream, hipStreamNonBlocking));
+    int rc = stream_order_begin(h, o->launch_stream);
     if (rc) return rc;
     h->collect_flags = false;
-    rc = compact_launch(h, &q, 1, dp, dp + es, dp + 2 * es, dp + 3 * es, dp + 4 * es, nullptr, nullptr);
+    rc = compact_launch(h, &q, 1, dp, dp + es, dp + 2 * es, dp + 3 * es, dp + 4 * es, nullptr, o->launch_stream);
     h->collect_flags = true;
     if (rc) return rc;
-    rc = stream_order_end(h, nullptr);
+    rc = stream_order_end(h, o->launch_stream);
     if (rc) return rc;
     bool done = false;
     const auto t0 = std::chrono::steady_clock::now();
@@ -190,7 +196,7 @@ int launch_path(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double dy
         }
         if (!done && (it & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
     }
-    if (!done) HIP_TRY(h, hipStreamSynchronize(nullptr));
+    if (!done) HIP_TRY(h, hipStreamSynchronize(o->launch_stream));
     if (q.dtype == TPC_MPC_F64) { *front = ((double*)hp)[3]; *rear = ((double*)hp)[4]; }
     else { *front = ((float*)hp)[3]; *rear = ((float*)hp)[4]; }
     return TPC_MPC_OK;
@@ -205,6 +211,10 @@ void one_shot_destroy(tpc_mpc_context* h) {
         (void)stop_kernel(h, o);
         (void)hipStreamSynchronize(o->stream);
         (void)hipStreamDestroy(o->stream);
+    }
+    if (o->launch_stream) {
+        (void)hipStreamSynchronize(o->launch_stream);
+        (void)hipStreamDestroy(o->launch_stream);
     }
     delete o;
     h->one = nullptr;

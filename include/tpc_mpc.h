@@ -63,8 +63,8 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
  *   LANE : one lane per instance, dlib's O(H) recurrences unrolled in registers, 64 instances
  *          per wavefront with dynamic refill of finished lanes.  Bit-identical to the reference
  *          arithmetic in fp64; highest throughput on large batches.
- *   AUTO : WAVE below a measured, horizon-dependent crossover (about 18 000 instances at N <= 5,
- *          29 000 from N = 10 on a 256-CU part), LANE from there up. */
+ *   AUTO : WAVE below a measured crossover (about 29 000 instances on a 256-CU part), LANE from
+ *          there up. */
 typedef enum tpc_mpc_algo { TPC_MPC_ALGO_AUTO = 0, TPC_MPC_ALGO_WAVE = 1, TPC_MPC_ALGO_LANE = 2 } tpc_mpc_algo;
 
 /* Non-fatal per-call flags, OR-ed into *flags_out (may be NULL). */

@@ -72,6 +72,105 @@ template <int K> TPC_DEV float row_bcast(float x) {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x150 + K, 0xf, 0xf, false));
 }
 
+// a0 += sum over even q, a1 += sum over odd q, of (x of lane q of the caller's 16-lane row) * k[q], q < CNT:
+// v_fmac with a DPP row_newbcast first operand -- the broadcast and the multiply-add are one instruction.
+// One asm block per row of controls: inline asm is opaque to the compiler's hazard recogniser, which
+// otherwise pads every pair of separate asms with a nop; a VGPR written by the VALU needs two wait
+// states before a DPP read, so the block opens with them (x may come straight out of an ALU op).
+// Two accumulators: alternate v_fmacs depend on each other at distance 2, ~2 x 4.8 cycles of issue
+// against 8.6 of latency.
+template <int CNT> TPC_DEV void fmac_row(double& a0, double& a1, double x, const double* k) {
+    static_assert(CNT >= 1 && CNT <= 16, "one 16-lane row");
+    if constexpr (CNT == 1) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]));
+    else if constexpr (CNT == 2) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]));
+    else if constexpr (CNT == 3) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]));
+    else if constexpr (CNT == 4) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]));
+    else if constexpr (CNT == 5) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]));
+    else if constexpr (CNT == 6) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]));
+    else if constexpr (CNT == 7) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]));
+    else if constexpr (CNT == 8) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]));
+    else if constexpr (CNT == 9) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]));
+    else if constexpr (CNT == 10) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]));
+    else if constexpr (CNT == 11) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]));
+    else if constexpr (CNT == 12) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]));
+    else if constexpr (CNT == 13) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]), "v"(k[12]));
+    else if constexpr (CNT == 14) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]), "v"(k[12]), "v"(k[13]));
+    else if constexpr (CNT == 15) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]), "v"(k[12]), "v"(k[13]), "v"(k[14]));
+    else if constexpr (CNT == 16) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]), "v"(k[12]), "v"(k[13]), "v"(k[14]), "v"(k[15]));
+}
+template <int CNT> TPC_DEV void fmac_row(float& a0, float& a1, float x, const float* k) {
+    static_assert(CNT >= 1 && CNT <= 16, "one 16-lane row");
+    if constexpr (CNT == 1) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]));
+    else if constexpr (CNT == 2) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]));
+    else if constexpr (CNT == 3) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]));
+    else if constexpr (CNT == 4) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]));
+    else if constexpr (CNT == 5) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]));
+    else if constexpr (CNT == 6) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]));
+    else if constexpr (CNT == 7) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]));
+    else if constexpr (CNT == 8) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]));
+    else if constexpr (CNT == 9) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]));
+    else if constexpr (CNT == 10) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]));
+    else if constexpr (CNT == 11) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]));
+    else if constexpr (CNT == 12) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]));
+    else if constexpr (CNT == 13) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]), "v"(k[12]));
+    else if constexpr (CNT == 14) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]), "v"(k[12]), "v"(k[13]));
+    else if constexpr (CNT == 15) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]), "v"(k[12]), "v"(k[13]), "v"(k[14]));
+    else if constexpr (CNT == 16) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]), "v"(k[12]), "v"(k[13]), "v"(k[14]), "v"(k[15]));
+}
+
+// v_permlane16_swap: (a, b) -> a' = rows (a0, b0, a2, b2), b' = rows (a1, b1, a3, b3);
+// v_permlane32_swap: (a, b) -> a' = (a.lo32, b.lo32), b' = (a.hi32, b.hi32)   [measured on gfx950]
+template <typename T> struct Swapped { T a, b; };
+TPC_DEV Swapped<double> swap_rows16(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return {__hiloint2double((int)hi[0], (int)lo[0]), __hiloint2double((int)hi[1], (int)lo[1])};
+}
+TPC_DEV Swapped<float> swap_rows16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)__float_as_int(a), (unsigned)__float_as_int(b), false, false);
+    return {__int_as_float((int)r[0]), __int_as_float((int)r[1])};
+}
+TPC_DEV Swapped<double> swap_halves(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return {__hiloint2double((int)hi[0], (int)lo[0]), __hiloint2double((int)hi[1], (int)lo[1])};
+}
+TPC_DEV Swapped<float> swap_halves(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)__float_as_int(a), (unsigned)__float_as_int(b), false, false);
+    return {__int_as_float((int)r[0]), __int_as_float((int)r[1])};
+}
+
+// per lane: bit of `mask` set ? a : b.  Written as asm so that a wave-uniform mask stays a select: the
+// optimiser turns a select on a uniform condition into a branch around the work, and a branch is what
+// the iteration loops are built to avoid.
+TPC_DEV double lane_select(unsigned long long mask, double a, double b) {
+    int lo, hi;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(b)), "v"(__double2loint(a)), "s"(mask));
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(__double2hiint(b)), "v"(__double2hiint(a)), "s"(mask));
+    return __hiloint2double(hi, lo);
+}
+TPC_DEV float lane_select(unsigned long long mask, float a, float b) {
+    int r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(__float_as_int(b)), "v"(__float_as_int(a)), "s"(mask));
+    return __int_as_float(r);
+}
+
+// all ones if any bit of `mask` is set, else 0 -- on the scalar unit, as a lane mask for lane_select
+// (written as `mask ? ~0 : 0` the compiler materialises it per lane in VGPRs)
+TPC_DEV unsigned long long any_to_all(unsigned long long mask) {
+    unsigned long long r;
+    asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b64 %0, -1, 0" : "=s"(r) : "s"(mask) : "scc");
+    return r;
+}
+
+// x >= 0 with its six lowest mantissa bits replaced by `tag` (0..63), and back (tag cleared)
+TPC_DEV double pack_key_abs(double x, int tag) {   // of |x|
+    return __hiloint2double(__double2hiint(x) & 0x7fffffff, (__double2loint(x) & ~63) | tag);
+}
+TPC_DEV double unpack_key(double x) { return __hiloint2double(__double2hiint(x), __double2loint(x) & ~63); }
+TPC_DEV float pack_key_abs(float x, int) { return tabs(x); }   // (unused: fp32 keeps the two-step arg-max, six of 23 bits is too much)
+TPC_DEV float unpack_key(float x) { return x; }
+
 // max over lanes 0 .. N-1 (the other lanes hold 0), returned wave-uniform.  x >= 0; a NaN lane
 // is ignored (v_max returns the other operand).  Only as many DPP steps as N needs: the reduction is
 // a dependent chain, and it sits on the critical path of every coordinate-descent iteration.
@@ -94,7 +193,7 @@ template <typename T, int I, int H> struct WaveIO<T, I, H, CompactArgs> {
         if (active && qi == 0) {
             if (qj == 0) ((T*)g.front)[k] = u; else ((T*)g.rear)[k] = u;
         }
-        if (g.iters && threadIdx.x == 0) g.iters[k] = (int32_t)it;
+        if (g.iters && (threadIdx.x & 63) == 0) g.iters[k] = (int32_t)it;
     }
 };
 template <typename T, int I, int H> struct WaveIO<T, I, H, GeneralArgs> {
@@ -112,7 +211,7 @@ template <typename T, int I, int H> struct WaveIO<T, I, H, GeneralArgs> {
             if (g.controls) ((T*)g.controls)[(int64_t)(qi * I + qj) * g.ld + k] = u;
             if (g.v) ((T*)g.v)[(int64_t)(qi * I + qj) * g.ld + k] = v;
         }
-        if (g.iters && threadIdx.x == 0) g.iters[k] = (int32_t)it;
+        if (g.iters && (threadIdx.x & 63) == 0) g.iters[k] = (int32_t)it;
     }
 };
 
@@ -149,14 +248,13 @@ TPC_DEV void hessian_row(const Model& m, bool active, int qi, int qj, T* row) {
     }
 }
 
-// One instance solved by the calling wavefront (all 64 lanes must call it together; the workgroup
-// must be that one wavefront, because the control exchange uses __syncthreads as its wait).
-// s_u: I*H + 2 values, s_w: 2*H values of LDS, both 16-byte aligned.
+// One instance solved by the calling wavefront (all 64 lanes must call it together).
+// s_w: 2*H values of LDS private to the wavefront, 16-byte aligned.
 template <typename T, int I, int H, class Model, class Args>
-TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_u, T* s_w) {
+TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w) {
     constexpr int N = I * H;
     static_assert(N <= kWave, "WAVE kernel: one variable per lane");
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
     const bool active = lane < N;
     const int qi = active ? lane / I : 0, qj = active ? lane % I : 0;
     const int slot = 2 * qi + qj;
@@ -169,12 +267,16 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_u, T* s_
     // ---- prologue: this lane's Hessian row, Q_diag, linear-term element, lambda
     T row[2 * H];
     hessian_row<T, I, H>(m, active, qi, qj, row);
+    T kq[N];   // the entries of the row in variable order (for I = 1 every second slot of `row` is unused)
+#pragma unroll
+    for (int q = 0; q < N; ++q) kq[q] = row[2 * (q / I) + (q % I)];
     T my_qd = (T)0, my_g = (T)0;
     const T lambda = ctor_lambda_qdiag<T, I, H>(m, [&](int i, int j, T val) { if (2 * i + j == slot) my_qd = val; });
     // every lane computes the same linear term; its 2H intermediates are identical in all lanes,
     // so they are parked in one small LDS vector instead of 2H registers per lane
     linear_term_fn<T, I, H>(m, [&](int q, T val) { s_w[q] = val; }, [&](int q) { return s_w[q]; },
                             [&](int q, T val) { if (q == slot) my_g = val; });
+    if (!active) my_g = (T)0;   // an idle lane shadows variable 0 through the prologue; from here on it is all zeros
     const T lo = m.lo(qj), hi = m.hi(qj);
     const T eps = (T)kn.eps;
     // the coordinate step divides by Q_diag (mpc.h:325): one correctly rounded reciprocal per lane
@@ -205,88 +307,131 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_u, T* s_
     }
     constexpr T kHuge = (T)(sizeof(T) == 8 ? 0x1p600 : 0x1p100);
     const T nlo_h = -(lo * kHuge), hi_h = hi * kHuge;
+    T huge_r = kHuge;                    // in a register: as a literal it forces the two-operand v_fmac
+    asm volatile("" : "+v"(huge_r));     // form, which costs a copy of the addend per use
 
-    // df_q = Hd[q,:].u + g_q.  Up to 16 variables all live in the first 16-lane row, and each control
-    // reaches the others by a DPP row broadcast (two register moves, no memory, no wait); beyond that
-    // the controls go through the LDS vector (single-wave workgroup: the barrier is only a wait).
+    // df_q = Hd[q,:].u + g_q: one v_fmac with a DPP row_newbcast operand per variable (the control of
+    // lane K of the row, times this lane's Hessian entry, in one instruction: no move, no LDS, no wait).
+    // A DPP read reaches the caller's 16-lane row only, so with more than 16 variables every row first
+    // gets a copy of the other rows' controls: X[r] = "the controls of row r, in every row", made by
+    // v_permlane16_swap (rows 0<->1, 2<->3) and, past 32 variables, v_permlane32_swap (halves).
     auto gradient_of = [&](T uu) -> T {
-        T a0 = (T)0, a1 = (T)0, a2 = (T)0, a3 = (T)0;
-        if constexpr (N <= 16) {
-            static_for_w<N>([&](auto qc) {
-                constexpr int q = decltype(qc)::value;
-                constexpr int e = 2 * (q / I) + (q % I);
-                const T uq = row_bcast<q>(uu);
-                if constexpr ((q & 3) == 0) a0 = tfma(row[e], uq, a0);
-                else if constexpr ((q & 3) == 1) a1 = tfma(row[e], uq, a1);
-                else if constexpr ((q & 3) == 2) a2 = tfma(row[e], uq, a2);
-                else a3 = tfma(row[e], uq, a3);
-            });
-        } else {
-            if (active) s_u[lane] = uu;
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < H; ++i)
-#pragma unroll
-                for (int j = 0; j < I; ++j) {
-                    const int q = i * I + j;
-                    const T uq = s_u[q];
-                    if ((q & 3) == 0) a0 = tfma(row[2 * i + j], uq, a0);
-                    else if ((q & 3) == 1) a1 = tfma(row[2 * i + j], uq, a1);
-                    else if ((q & 3) == 2) a2 = tfma(row[2 * i + j], uq, a2);
-                    else a3 = tfma(row[2 * i + j], uq, a3);
-                }
+        // two accumulators: with a dependent v_fmac every second instruction the chain never waits
+        // (8.6 cycles of latency against 2 x 4.8 of issue), and the linear term seeds one of them
+        T a0 = my_g, a1 = (T)0;
+        T x[4] = {uu, uu, uu, uu};
+        if constexpr (N > 16) {
+            const Swapped<T> p = swap_rows16(uu, uu);        // p.a = rows (0,0,2,2), p.b = rows (1,1,3,3)
+            x[0] = p.a; x[1] = p.b;
+            if constexpr (N > 32) {
+                const Swapped<T> e = swap_halves(p.a, p.a);  // e.a = row 0 everywhere, e.b = row 2 everywhere
+                const Swapped<T> o = swap_halves(p.b, p.b);
+                x[0] = e.a; x[2] = e.b; x[1] = o.a; x[3] = o.b;
+            }
         }
-        return ((a0 + a1) + (a2 + a3)) + my_g;
+        static_for_w<(N + 15) / 16>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            constexpr int cnt = N - 16 * r < 16 ? N - 16 * r : 16;
+            fmac_row<cnt>(a0, a1, x[r], kq + 16 * r);
+        });
+        return a0 + a1;
     };
 
+    constexpr int kUnrollCd = 5, kUnrollPg = 8;
     uint32_t iter = 0;
     bool capped = true;
-    // Two loops, one per phase, each with a single way out; both kinds of step are computed
-    // SPECULATIVELY beside the stop test they do not depend on (one wave's fp64 instructions issue every
-    // ~5 cycles when independent and every ~9 when each needs the previous result), and nothing is
-    // committed before the test has spoken.
+    // Two loops, one per phase; both kinds of step are computed SPECULATIVELY beside the stop test they do
+    // not depend on (one wave's fp64 instructions issue every ~5 cycles when independent and every ~9 when
+    // each needs the previous result).
     auto run = [&](auto mask_tag) {
         constexpr bool MASK = decltype(mask_tag)::value;
+        // the masked df, signed (callers take the magnitude where it is free: a compare's source modifier,
+        // the key's sign bit)
         auto masked = [&](T uu, T df) -> T {
             if constexpr (MASK) {
-                const T g_lo = tfma(uu, kHuge, nlo_h), g_hi = tfma(uu, -kHuge, hi_h);
-                const T c = tabs(tmax(tmin(df, g_lo), -g_hi));
-                return active ? c : (T)0;
+                // (an idle lane needs no select here: its row, linear term and controls are 0, so df = 0,
+                // and with bounds that straddle zero the expression below is 0)
+                const T g_lo = tfma(uu, huge_r, nlo_h), g_hi = tfma(uu, -huge_r, hi_h);
+                return tmax(tmin(df, g_lo), -g_hi);
             } else {
                 const bool blocked = (uu <= lo && df > (T)0) || (uu >= hi && df < (T)0);   // mpc.h:298-299
-                return (active && !blocked) ? tabs(df) : (T)0;
+                return (active && !blocked) ? df : (T)0;
             }
+        };
+        // A branch instruction costs a wavefront ~70 cycles, taken or not (measured: the same loop without
+        // its exit branch), against ~5 for an ALU instruction -- a quarter of an iteration at 8 variables.
+        // So an iteration is BRANCH-FREE: its step is applied under the verdict of its own stop test as a
+        // select, and the iteration counter advances by that verdict.  Once the test says stop, the state
+        // no longer changes, so the following iterations reproduce the same verdict and do nothing; the
+        // loops look at the verdict once per block of kUnroll iterations (a few idle iterations at the end
+        // of a solve against a branch in every one).
+        const unsigned long long qdnz_mask = __ballot(my_qd != (T)0);
+        unsigned long long last_upd = 0ull, go_mask = ~0ull;
+        T eps_v = eps;
+        asm volatile("" : "+v"(eps_v));   // a VGPR copy: the reduced maximum arrives in SGPRs, and a VALU compare takes one scalar operand
+        auto cd_step = [&]() {
+            const T df = gradient_of(u);
+            const T cs = masked(u, df);
+            // mpc.h:325-326, every lane its own (speculatively: only the winner's is used).  mpc.h:322: a zero
+            // Q_diag skips the update (the iteration still counts) -- such a lane is masked out of the winners
+            const T nu_arg = -(df - my_qd * u) * my_rqd;
+            T nu = MASK ? tmax(tmin(nu_arg, hi), lo) : put_in_range(lo, hi, nu_arg);   // (same value unless NaN, which MASK excludes)
+            asm volatile("" : "+v"(nu));   // computed HERE, beside the reduction (the optimiser would sink it behind the winner's mask)
+            unsigned long long upd_mask;
+            if constexpr (sizeof(T) == 8) {
+                // arg-max and max in ONE reduction: the low six bits of the masked |df| are replaced by
+                // 63 - lane, so the largest key is unique, belongs to the lowest lane among (near-)equal
+                // values as dlib's strict '>' scan would pick, and differs from the true maximum by
+                // < 2^-46 relative -- inside what this family's FMA dot product already differs by.
+                // (an infinite |df| -- possible only where the screen did not run -- would turn into a NaN
+                // under the tag and drop out of the maximum: it competes as the largest finite number)
+                const T cf = (!MASK && tabs(cs) == (T)__builtin_inf()) ? (T)1.7976931348623157e308 : cs;
+                const T key = pack_key_abs(cf, 63 - lane);
+                const T mk = wave_max<N>(key);
+                go_mask = __ballot(!(unpack_key(mk) < eps_v));                   // mpc.h:310-311 (all lanes alike)
+                upd_mask = __ballot(key == mk);
+            } else {
+                const T c = tabs(cs);
+                const T mx = wave_max<N>(c);
+                go_mask = __ballot(!(mx < eps_v));
+                const unsigned long long hit = __ballot(c == mx);
+                upd_mask = hit & (0ull - hit);                                  // lowest index wins
+            }
+            last_upd = upd_mask & go_mask & qdnz_mask;
+            u = lane_select(last_upd, nu, u);
+            iter += go_mask != 0ull ? 1u : 0u;
+        };
+        auto pg_step = [&]() {
+            const T df = gradient_of(u);
+            const T cs = masked(u, df);
+            const T v_new = clamp3(tfma(-inv_lambda, df, u), lo, hi);            // fused, like the dot product above
+            const T u_new = clamp3(tfma(beta, v_new - v, v_new), lo, hi);
+            go_mask = __ballot(tabs(cs) >= eps);                                 // mpc.h:310-311: 0 = stop
+            const unsigned long long go_all = any_to_all(go_mask);
+            v = lane_select(go_all, v_new, v);
+            u = lane_select(go_all, u_new, u);
+            iter += go_mask != 0ull ? 1u : 0u;
         };
         // ---- coordinate descent on the arg-max (mpc.h:319-335)
         const uint32_t cd_end = kn.smo_iters < kn.max_iter ? kn.smo_iters : kn.max_iter;
-#pragma unroll 1
-        for (; iter < cd_end; ++iter) {
-            const T df = gradient_of(u);
-            const T c = masked(u, df);
-            T nu = put_in_range(lo, hi, -(df - my_qd * u) * my_rqd);             // mpc.h:325-326, every lane its own
-            asm volatile("" : "+v"(nu));   // computed HERE, beside the reduction (the optimiser would sink it)
-            const T mx = wave_max<N>(c);
-            if (mx < eps) { capped = false; return; }                            // mpc.h:310-311
-            const unsigned long long hit = __ballot(c == mx);
-            const int best = __ffsll((long long)hit) - 1;                        // lowest index wins
-            // mpc.h:322: a zero Q_diag skips the update (the iteration still counts).  Decided per lane
-            // from the lane's own Q_diag -- no cross-lane read, no wave-uniform branch on the path.
-            const bool upd = lane == best && my_qd != (T)0;
-            u = upd ? nu : u;
-            if (iter + 1 == kn.smo_iters && __ballot(upd) != 0ull) v = u;        // mpc.h:330-334 (last CD iteration only)
+        const uint32_t cd_left = cd_end > iter ? cd_end - iter : 0u;
+        for (uint32_t blk = cd_left / kUnrollCd; blk;) {
+#pragma unroll
+            for (int r = 0; r < kUnrollCd; ++r) cd_step();
+            blk = go_mask != 0ull ? blk - 1 : 0u;          // one branch per block: the loop's own
         }
+        for (uint32_t rest = go_mask != 0ull ? cd_left % kUnrollCd : 0u; rest; --rest) cd_step();
+        if (go_mask == 0ull) { capped = false; return; }
+        if (iter == kn.smo_iters && last_upd != 0ull) v = u;   // mpc.h:330-334: the last CD iteration, unless it was skipped
         // ---- accelerated projected gradient (mpc.h:336-345); stop test without a reduction
-#pragma unroll 1
-        for (; iter < kn.max_iter; ++iter) {
-            const T df = gradient_of(u);
-            const T c = masked(u, df);
-            T v_new = clamp3(u - inv_lambda * df, lo, hi);
-            T u_new = clamp3(v_new + beta * (v_new - v), lo, hi);
-            asm volatile("" : "+v"(v_new), "+v"(u_new));   // computed HERE, beside the stop test
-            if (__ballot(c >= eps) == 0ull) { capped = false; return; }          // mpc.h:310-311
-            v = v_new;
-            u = u_new;
+        const uint32_t pg_left = kn.max_iter > iter ? kn.max_iter - iter : 0u;
+        for (uint32_t blk = pg_left / kUnrollPg; blk;) {
+#pragma unroll
+            for (int r = 0; r < kUnrollPg; ++r) pg_step();
+            blk = go_mask != 0ull ? blk - 1 : 0u;
         }
+        for (uint32_t rest = go_mask != 0ull ? pg_left % kUnrollPg : 0u; rest; --rest) pg_step();
+        if (go_mask == 0ull) capped = false;
     };
     if ((Model::kScreen && nonfinite) || badmodel) capped = false;
     else if (mask_ok) run(std::true_type{});
@@ -301,11 +446,18 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_u, T* s_
     }
 }
 
+// kWavesPerBlock instances per workgroup, one per wavefront; they share nothing but the launch.
+// Measured at 4 096 instances, N = 10: 231 / 230 / 225 / 242 us for 1 / 2 / 4 / 8 wavefronts per workgroup.
+#ifndef TPC_WAVES_PER_BLOCK
+#define TPC_WAVES_PER_BLOCK 4
+#endif
+constexpr int kWavesPerBlock = TPC_WAVES_PER_BLOCK;
 template <typename T, int I, int H, class Model, class Args>
-__global__ __launch_bounds__(64) void wave_kernel(Args g, Knobs kn) {
-    __shared__ __attribute__((aligned(16))) T s_u[I * H + 2];
-    __shared__ __attribute__((aligned(16))) T s_w[2 * H];
-    wave_solve<T, I, H, Model, Args>(g, kn, (int64_t)blockIdx.x, s_u, s_w);
+__global__ __launch_bounds__(kWavesPerBlock * kWave) void wave_kernel(Args g, Knobs kn) {
+    __shared__ __attribute__((aligned(16))) T s_w[kWavesPerBlock][2 * H];
+    const int w = threadIdx.x / kWave;
+    const int64_t k = (int64_t)blockIdx.x * kWavesPerBlock + w;
+    if (k < g.n) wave_solve<T, I, H, Model, Args>(g, kn, k, s_w[w]);
 }
 
 }  // namespace tpc

@@ -21,7 +21,8 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
         if (a.n <= 0) return hipSuccess;
         if (a.n > 0x7fffffffll) return hipErrorInvalidValue;
         if (ws.ev) (void)hipEventRecord(ws.ev[0], s);
-        hipLaunchKernelGGL((wave_kernel<T, I, kH, Model, Args>), dim3((unsigned)a.n), dim3(kWave), 0, s, a, k);
+        hipLaunchKernelGGL((wave_kernel<T, I, kH, Model, Args>), dim3((unsigned)((a.n + kWavesPerBlock - 1) / kWavesPerBlock)),
+                           dim3(kWavesPerBlock * kWave), 0, s, a, k);
         const hipError_t e = hipGetLastError();
         if (ws.ev) { (void)hipEventRecord(ws.ev[1], s); (void)hipEventRecord(ws.ev[2], s); }
         return e;

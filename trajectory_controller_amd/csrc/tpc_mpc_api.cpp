@@ -54,7 +54,7 @@ const int32_t* take_hint(tpc_mpc_context* h, int64_t n) {
 // LANE needs enough instances to give every SIMD a full wavefront; below that WAVE's
 // one-wavefront-per-instance launch finishes sooner.  Measured crossovers on MI355X
 // (scripts/crossover.py, fp64, compact form, round 2 kernels; the chip has 65 536 LANE slots):
-// H = 4: between 16 384 and 24 576 instances, H = 10 and H = 20: between 24 576 and 32 768.
+// H = 4 and H = 10: between 24 576 and 32 768 instances, H = 20: between 32 768 and 49 152.
 // The WAVE kernel maps one decision variable to one lane, so it exists for I*H <= 64 only.
 // Returns the kernel family to run, or -1 when WAVE was demanded for a shape it cannot take.
 int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n) {
@@ -63,7 +63,7 @@ int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n) {
     if (algo == TPC_MPC_ALGO_WAVE) return wave_ok ? algo : -1;
     if (algo == TPC_MPC_ALGO_LANE) return algo;
     const int64_t lanes = (int64_t)h->cu_count * 4 * kWave;
-    const int64_t crossover = H <= 5 ? lanes * 9 / 32 : lanes * 7 / 16;
+    const int64_t crossover = lanes * 7 / 16;
     return (n >= crossover || !wave_ok) ? TPC_MPC_ALGO_LANE : TPC_MPC_ALGO_WAVE;
 }
 

@@ -64,7 +64,6 @@ TPC_DEV void sys_store(uint64_t* p, uint64_t x) {
 // every solve: slower than an ordinary launch at N = 20.)
 template <int H>
 __global__ __launch_bounds__(64) void one_shot_kernel(uint64_t* mail, uint64_t start_seq, uint64_t idle_ticks) {
-    __shared__ __attribute__((aligned(16))) double s_u[2 * H + 2];
     __shared__ __attribute__((aligned(16))) double s_w[2 * H];
     __shared__ __attribute__((aligned(16))) uint64_t s_req[kReqWords + 2];   // the request, then front, rear
     const int lane = threadIdx.x;
@@ -97,7 +96,7 @@ __global__ __launch_bounds__(64) void one_shot_kernel(uint64_t* mail, uint64_t s
             kn.eps = rq[kW_Eps];
             kn.max_iter = (uint32_t)s_req[kW_Iters];
             kn.smo_iters = (uint32_t)(s_req[kW_Iters] >> 32);
-            wave_solve<double, 2, H, CompactModel<double>, CompactArgs>(g, kn, 0, s_u, s_w);
+            wave_solve<double, 2, H, CompactModel<double>, CompactArgs>(g, kn, 0, s_w);
         } else {
             s_req[kReqWords] = s_req[kReqWords + 1] = 0x7ff8000000000badull;   // the host never asks this
         }

@@ -167,6 +167,11 @@ TPC_DEV unsigned long long any_to_all(unsigned long long mask) {
 TPC_DEV double pack_key_abs(double x, int tag) {   // of |x|
     return __hiloint2double(__double2hiint(x) & 0x7fffffff, (__double2loint(x) & ~63) | tag);
 }
+TPC_DEV double round_up_key(double x) {   // smallest value with a clear tag that is >= x (x > 0)
+    const unsigned long long b = ((unsigned long long)__double_as_longlong(x) + 63ull) & ~63ull;
+    return __longlong_as_double((long long)b);
+}
+TPC_DEV float round_up_key(float x) { return x; }
 TPC_DEV double unpack_key(double x) { return __hiloint2double(__double2hiint(x), __double2loint(x) & ~63); }
 TPC_DEV float pack_key_abs(float x, int) { return tabs(x); }   // (unused: fp32 keeps the two-step arg-max, six of 23 bits is too much)
 TPC_DEV float unpack_key(float x) { return x; }
@@ -183,6 +188,24 @@ template <int N, typename T> TPC_DEV T wave_max(T x) {
     if constexpr (N > 32) x = raw_max(x, dpp_mov<0x143, 0xc>(x, x));  // row_bcast:31 -> rows 2, 3; lane 63 = wave max
     constexpr int last = N > 32 ? 63 : (N > 16 ? 31 : (N > 8 ? 15 : (N > 4 ? 7 : (N > 2 ? 3 : (N > 1 ? 1 : 0)))));
     return read_lane(x, last);
+}
+
+// max over the lanes 0 .. N-1 of the first 16-lane row (N <= 16; lanes N .. 15 must hold values that cannot
+// win), left in EVERY lane of the group: butterfly exchanges (xor 1, xor 2, half mirror, mirror) instead of
+// shifts, so no broadcast or lane read follows.
+template <int N> TPC_DEV double row_max_all(double x) {
+    static_assert(N <= 16, "one row");
+    auto step = [&](auto ctrl) {
+        constexpr int c = decltype(ctrl)::value;
+        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), c, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), c, 0xf, 0xf, false);
+        x = raw_max(x, __hiloint2double(hi, lo));
+    };
+    if constexpr (N > 1) step(std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    if constexpr (N > 2) step(std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    if constexpr (N > 4) step(std::integral_constant<int, 0x141>{});   // row_half_mirror
+    if constexpr (N > 8) step(std::integral_constant<int, 0x140>{});   // row_mirror
+    return x;
 }
 
 template <typename T, int I, int H, class Args> struct WaveIO;
@@ -365,19 +388,28 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w) {
         // no longer changes, so the following iterations reproduce the same verdict and do nothing; the
         // loops look at the verdict once per block of kUnroll iterations (a few idle iterations at the end
         // of a solve against a branch in every one).
-        const unsigned long long qdnz_mask = __ballot(my_qd != (T)0);
-        unsigned long long last_upd = 0ull, go_mask = ~0ull;
-        T eps_v = eps;
-        asm volatile("" : "+v"(eps_v));   // a VGPR copy: the reduced maximum arrives in SGPRs, and a VALU compare takes one scalar operand
+        const bool qd_nz = my_qd != (T)0;
+        const T my_rqd0 = qd_nz ? my_rqd : (T)0;
+        unsigned long long go_mask = ~0ull;
+        bool go_lane = true, last_take = false;
+        int cnt = 0;                          // iterations this lane has seen counted (all lanes alike)
+        // eps rounded up to the key grid (a multiple of 64 ulp): key >= eps_up  <=>  key with its tag cleared >= eps
+        const T eps_up = round_up_key(eps);
         auto cd_step = [&]() {
             const T df = gradient_of(u);
             const T cs = masked(u, df);
-            // mpc.h:325-326, every lane its own (speculatively: only the winner's is used).  mpc.h:322: a zero
-            // Q_diag skips the update (the iteration still counts) -- such a lane is masked out of the winners
-            const T nu_arg = -(df - my_qd * u) * my_rqd;
-            T nu = MASK ? tmax(tmin(nu_arg, hi), lo) : put_in_range(lo, hi, nu_arg);   // (same value unless NaN, which MASK excludes)
+            // mpc.h:325-326, every lane its own (speculatively: only the winner's is used): -(df - Qd*u)/Qd is
+            // the Newton step u - df/Qd.  Where the screen ran it is ONE fused multiply-add with the lane's
+            // reciprocal -- which is 0 for a zero Q_diag, so that lane "updates" to the value it has
+            // (mpc.h:322: the update is skipped, the iteration still counts); elsewhere dlib's expression
+            // and an explicit select (a warm start may lie outside the bounds, where clamp(u) != u).
+            T nu;
+            if constexpr (MASK) nu = tmax(tmin(tfma(-my_rqd0, df, u), hi), lo);
+            else {
+                nu = put_in_range(lo, hi, -(df - my_qd * u) * my_rqd);
+                nu = qd_nz ? nu : u;
+            }
             asm volatile("" : "+v"(nu));   // computed HERE, beside the reduction (the optimiser would sink it behind the winner's mask)
-            unsigned long long upd_mask;
             if constexpr (sizeof(T) == 8) {
                 // arg-max and max in ONE reduction: the low six bits of the masked |df| are replaced by
                 // 63 - lane, so the largest key is unique, belongs to the lowest lane among (near-)equal
@@ -387,19 +419,28 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w) {
                 // under the tag and drop out of the maximum: it competes as the largest finite number)
                 const T cf = (!MASK && tabs(cs) == (T)__builtin_inf()) ? (T)1.7976931348623157e308 : cs;
                 const T key = pack_key_abs(cf, 63 - lane);
-                const T mk = wave_max<N>(key);
-                go_mask = __ballot(!(unpack_key(mk) < eps_v));                   // mpc.h:310-311 (all lanes alike)
-                upd_mask = __ballot(key == mk);
+                // The winner and the verdict without leaving the vector unit (every hop VALU -> SALU -> VALU
+                // costs ~20 cycles of a chain that has nothing else to do): the maximum reaches every lane
+                // (butterfly for one row; a lane read otherwise), and "this lane holds it AND it is >= eps" is
+                // ONE compare against max(maximum, eps rounded up to the key grid).
+                T mk;
+                if constexpr (N <= 16) mk = row_max_all<N>(key);
+                else mk = wave_max<N>(key);
+                const T thr = raw_max(mk, eps_up);
+                const bool take = key >= thr;
+                go_lane = mk >= eps_up;                                          // mpc.h:310-311 (all lanes alike)
+                last_take = take;
+                u = take ? nu : u;
             } else {
                 const T c = tabs(cs);
                 const T mx = wave_max<N>(c);
-                go_mask = __ballot(!(mx < eps_v));
+                go_lane = !(mx < eps);
                 const unsigned long long hit = __ballot(c == mx);
-                upd_mask = hit & (0ull - hit);                                  // lowest index wins
+                const bool take = go_lane && lane == __ffsll((long long)hit) - 1;   // lowest index wins
+                last_take = take;
+                u = take ? nu : u;
             }
-            last_upd = upd_mask & go_mask & qdnz_mask;
-            u = lane_select(last_upd, nu, u);
-            iter += go_mask != 0ull ? 1u : 0u;
+            cnt += go_lane ? 1 : 0;
         };
         auto pg_step = [&]() {
             const T df = gradient_of(u);
@@ -418,11 +459,14 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w) {
         for (uint32_t blk = cd_left / kUnrollCd; blk;) {
 #pragma unroll
             for (int r = 0; r < kUnrollCd; ++r) cd_step();
+            go_mask = __ballot(go_lane);
             blk = go_mask != 0ull ? blk - 1 : 0u;          // one branch per block: the loop's own
         }
         for (uint32_t rest = go_mask != 0ull ? cd_left % kUnrollCd : 0u; rest; --rest) cd_step();
+        go_mask = __ballot(go_lane);
+        iter += (uint32_t)__builtin_amdgcn_readfirstlane(cnt);
         if (go_mask == 0ull) { capped = false; return; }
-        if (iter == kn.smo_iters && last_upd != 0ull) v = u;   // mpc.h:330-334: the last CD iteration, unless it was skipped
+        if (iter == kn.smo_iters && __ballot(last_take && qd_nz) != 0ull) v = u;   // mpc.h:330-334: the last CD iteration, unless it was skipped
         // ---- accelerated projected gradient (mpc.h:336-345); stop test without a reduction
         const uint32_t pg_left = kn.max_iter > iter ? kn.max_iter - iter : 0u;
         for (uint32_t blk = pg_left / kUnrollPg; blk;) {

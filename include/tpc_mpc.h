@@ -129,8 +129,8 @@ const char* tpc_mpc_build_info(void);
  * A=[1,Tv;0,1], B=[0,Tv;Tv/l,-Tv/l], C=0, Q, R from `p`, a fresh controller, one target
  * (delta_y, delta_phi) for all steps, x0 = 0, cold start, and returns u0.  `v` is the speed AFTER
  * the module's velocity lookup (src/...follower.cpp:323).  One instance on the GPU (WAVE kernel),
- * served by a resident wavefront that takes requests through pinned host memory (see
- * tpc_mpc_set_resident), so the call costs no kernel launch and no synchronisation call. */
+ * served by a resident wavefront that takes requests through a mailbox (see tpc_mpc_set_resident),
+ * so the call costs no kernel launch and no synchronisation call. */
 int tpc_mpc_solve_one(tpc_mpc_handle h, const tpc_mpc_params* p, double v, double delta_y,
                       double delta_phi, double* steering_front, double* steering_rear);
 
@@ -140,7 +140,10 @@ int tpc_mpc_solve_one(tpc_mpc_handle h, const tpc_mpc_params* p, double v, doubl
  * started again by the next call; tpc_mpc_destroy stops it.  While it is resident a device-wide
  * synchronisation elsewhere in the process (hipDeviceSynchronize, hipFree) waits for it, i.e. up to
  * the idle timeout.  idle_timeout_us <= 0 turns the resident mode off: every solve_one is then one
- * kernel launch. */
+ * kernel launch.
+ * Where the CPU can write device memory (hipDeviceAttributeIsLargeBar) the request is written into
+ * device memory through the BAR, otherwise into pinned host memory; the environment variable
+ * TPC_MPC_MAILBOX=host, read when a handle first uses solve_one, forces the latter. */
 int tpc_mpc_set_resident(tpc_mpc_handle h, int64_t idle_timeout_us);
 
 /* The same computation for n independent instances in one launch.  Arrays are `p->dtype`,

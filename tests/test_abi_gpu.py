@@ -459,6 +459,31 @@ def test_solve_one_resident_vs_oracle(torch_cuda, oracle, H):
         assert abs(f - e2f[1]) <= 1e-9 and abs(r - e2r[1]) <= 1e-9
 
 
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_solve_one_request_lines_placement(torch_cuda, oracle, monkeypatch, where):
+    """The resident wave takes its requests from device memory the CPU writes through the BAR (where the
+    part has a large BAR) or from the pinned block (TPC_MPC_MAILBOX=host, the fallback): same answers, also
+    across a horizon swap, an idle timeout and two handles alive at once."""
+    from trajectory_controller_amd.synth import compact_inputs
+    if where == "host":
+        monkeypatch.setenv("TPC_MPC_MAILBOX", "host")
+    else:
+        monkeypatch.delenv("TPC_MPC_MAILBOX", raising=False)
+    ref = {}
+    for H in (4, 10):
+        v, dy, dphi = compact_inputs(H, 24, first=991 + H)
+        ref[H] = (v, dy, dphi) + tuple(oracle.solve_compact(H, v, dy, dphi)[:2])
+    with _solver(4, "auto") as s, _solver(10, "auto") as t:      # the placement is chosen per handle, at its first solve
+        for rep in range(2):
+            for k in range(24):
+                for slv, H in ((s, 4), (t, 10), (s, 10)):        # s swaps its resident wave between two horizons
+                    v, dy, dphi, of, orr = ref[H]
+                    f, r = slv.solve_one(v[k], dy[k], dphi[k], horizon=H) if slv is s else slv.solve_one(v[k], dy[k], dphi[k])
+                    assert abs(f - of[k]) <= 1e-9 and abs(r - orr[k]) <= 1e-9, (where, H, k)
+            s.set_resident(1000)
+            time.sleep(0.03)                                     # s's wave has left: the next request restarts it
+
+
 def test_solve_one_latency_and_coexistence(torch_cuda):
     """Latency of the resident path at the reference's real size (H = 4), printed; and a batch solve on
     the same device while the resident wave is up (they must not disturb each other)."""

@@ -28,6 +28,17 @@ struct CompactArgs {
     double q[2], r[2], lo[2], hi[2];
 };
 
+// One compact instance whose inputs are already in registers (the resident solve_one wavefront,
+// tpc_mpc_one.hip): no input arrays; the two outputs are stored system-wide into out[0], out[1].
+struct OneArgs {
+    double v, dy, dphi;
+    double step, wheelbase;
+    double q[2], r[2], lo[2], hi[2];
+    uint64_t* out;                         // front, rear (8-byte stores visible to the host)
+    static constexpr int32_t* iters = nullptr;
+    static constexpr uint32_t* flags = nullptr;
+};
+
 // General batch: SoA with leading dimension ld, component c of instance k at base[c*ld + k].
 struct GeneralArgs {
     int64_t n, ld;

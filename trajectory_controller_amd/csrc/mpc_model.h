@@ -261,6 +261,16 @@ struct CompactModel {
         q0 = (T)g.q[0]; q1 = (T)g.q[1]; r0 = (T)g.r[0]; r1 = (T)g.r[1];
         l0 = (T)g.lo[0]; l1 = (T)g.lo[1]; h0 = (T)g.hi[0]; h1 = (T)g.hi[1];
     }
+    TPC_DEV void load(const OneArgs& g, int64_t) {
+        const T vk = (T)g.v;
+        const T step = (T)g.step;
+        a = step * vk;
+        c = step * vk / (T)g.wheelbase;
+        ty = (T)g.dy;
+        tphi = (T)g.dphi;
+        q0 = (T)g.q[0]; q1 = (T)g.q[1]; r0 = (T)g.r[0]; r1 = (T)g.r[1];
+        l0 = (T)g.lo[0]; l1 = (T)g.lo[1]; h0 = (T)g.hi[0]; h1 = (T)g.hi[1];
+    }
     // Any non-finite v, dy or dphi makes every gradient component NaN in dlib, which then returns
     // the untouched start point at iteration 0 (mpc.h:298-311); the shortcuts below assume finite
     // a, c, so such instances are screened to exactly that result.

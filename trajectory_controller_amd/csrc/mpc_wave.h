@@ -208,6 +208,28 @@ template <int N> TPC_DEV double row_max_all(double x) {
     return x;
 }
 
+// sum over the lanes 0 .. N-1 (the other lanes must hold 0), left in every lane of the rows in use:
+// butterfly exchanges inside a row, row swaps across rows.
+template <int N, typename T> TPC_DEV T wave_sum_all(T x) {
+    auto step = [&](auto ctrl) {
+        constexpr int c = decltype(ctrl)::value;
+        if constexpr (sizeof(T) == 8) {
+            const int lo = __builtin_amdgcn_mov_dpp(__double2loint((double)x), c, 0xf, 0xf, false);
+            const int hi = __builtin_amdgcn_mov_dpp(__double2hiint((double)x), c, 0xf, 0xf, false);
+            x = x + (T)__hiloint2double(hi, lo);
+        } else {
+            x = x + (T)__int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int((float)x), c, 0xf, 0xf, false));
+        }
+    };
+    if constexpr (N > 1) step(std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    if constexpr (N > 2) step(std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    if constexpr (N > 4) step(std::integral_constant<int, 0x141>{});   // row_half_mirror
+    if constexpr (N > 8) step(std::integral_constant<int, 0x140>{});   // row_mirror
+    if constexpr (N > 16) { const Swapped<T> p = swap_rows16(x, x); x = p.a + p.b; }
+    if constexpr (N > 32) { const Swapped<T> p = swap_halves(x, x); x = p.a + p.b; }
+    return x;
+}
+
 template <typename T, int I, int H, class Args> struct WaveIO;
 template <typename T, int I, int H> struct WaveIO<T, I, H, CompactArgs> {
     static TPC_DEV T init_u(const CompactArgs&, int64_t, int, int) { return (T)0; }
@@ -217,6 +239,14 @@ template <typename T, int I, int H> struct WaveIO<T, I, H, CompactArgs> {
             if (qj == 0) ((T*)g.front)[k] = u; else ((T*)g.rear)[k] = u;
         }
         if (g.iters && (threadIdx.x & 63) == 0) g.iters[k] = (int32_t)it;
+    }
+};
+template <int I, int H> struct WaveIO<double, I, H, OneArgs> {
+    static TPC_DEV double init_u(const OneArgs&, int64_t, int, int) { return 0.0; }
+    static TPC_DEV double init_v(const OneArgs&, int64_t, int, int) { return 0.0; }
+    static TPC_DEV void write(const OneArgs& g, int64_t, bool active, int qi, int qj, double u, double, uint32_t) {
+        if (active && qi == 0)
+            __hip_atomic_store(g.out + qj, (uint64_t)__double_as_longlong(u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 };
 template <typename T, int I, int H> struct WaveIO<T, I, H, GeneralArgs> {
@@ -242,8 +272,13 @@ template <typename T, int I, int H> struct WaveIO<T, I, H, GeneralArgs> {
 // (mpc.h:275-283) applied to the unit vector e_(qi,qj) with MM = 0.  B*e is a column of B at step qi
 // and zero elsewhere, so no control vector is materialised; the arithmetic is the generic one
 // (x*1 = x, x + 0 = x exactly).  row[2*i + j] = Hd[(i,j)][(qi,qj)].
+// The lane's own diagonal entry before R is added is dlib's Q_diag of its variable: trans(B)*T_c*B with
+// T_c = sum_k trans(A^k)*Q*A^k is exactly what the recurrence accumulates at (q, q) -- and the diagonal
+// entries, R included, sum to dlib's lambda (its trace bound, mpc.h:116-123).  So the constructor's own
+// O(H) matrix recurrence is not run at all; the values differ from dlib's by rounding only (a different
+// association), like everything else in this family.
 template <typename T, int I, int H, class Model>
-TPC_DEV void hessian_row(const Model& m, bool active, int qi, int qj, T* row) {
+TPC_DEV void hessian_row(const Model& m, bool active, int qi, int qj, T* row, T& own_qdiag) {
     const T bq0 = active ? (qj == 0 ? m.B(0, 0) : m.B(0, I - 1)) : (T)0;
     const T bq1 = active ? (qj == 0 ? m.B(1, 0) : m.B(1, I - 1)) : (T)0;
     T m0 = (T)0, m1 = (T)0;
@@ -265,8 +300,10 @@ TPC_DEV void hessian_row(const Model& m, bool active, int qi, int qj, T* row) {
         }
 #pragma unroll
         for (int j = 0; j < I; ++j) {
-            const T diag = (active && i == qi && j == qj) ? m.R(j) : (T)0;
-            row[2 * i + j] = (m.B(0, j) * n0 + m.B(1, j) * n1) + diag;
+            const bool own = active && i == qi && j == qj;
+            const T btn = m.B(0, j) * n0 + m.B(1, j) * n1;
+            if (own) own_qdiag = btn;          // Hd[q][q] without R: dlib's Q_diag (mpc.h:118-121)
+            row[2 * i + j] = btn + (own ? m.R(j) : (T)0);
         }
     }
 }
@@ -289,16 +326,24 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w) {
 
     // ---- prologue: this lane's Hessian row, Q_diag, linear-term element, lambda
     T row[2 * H];
-    hessian_row<T, I, H>(m, active, qi, qj, row);
+    T my_qd = (T)0, my_g = (T)0;
+    hessian_row<T, I, H>(m, active, qi, qj, row, my_qd);
     T kq[N];   // the entries of the row in variable order (for I = 1 every second slot of `row` is unused)
 #pragma unroll
     for (int q = 0; q < N; ++q) kq[q] = row[2 * (q / I) + (q % I)];
-    T my_qd = (T)0, my_g = (T)0;
-    const T lambda = ctor_lambda_qdiag<T, I, H>(m, [&](int i, int j, T val) { if (2 * i + j == slot) my_qd = val; });
-    // every lane computes the same linear term; its 2H intermediates are identical in all lanes,
-    // so they are parked in one small LDS vector instead of 2H registers per lane
-    linear_term_fn<T, I, H>(m, [&](int q, T val) { s_w[q] = val; }, [&](int q) { return s_w[q]; },
-                            [&](int q, T val) { if (q == slot) my_g = val; });
+    const T lambda = wave_sum_all<N>(active ? my_qd + m.R(qj) : (T)0);   // trace of the Hessian
+    // every lane computes the same linear term.  The compact model needs no intermediates (its own
+    // linear_term: one target for all steps); a short general horizon keeps them in registers; a long
+    // one parks them -- identical in all lanes -- in one small LDS vector instead of 2H registers per lane
+    auto take_g = [&](int q, T val) { if (q == slot) my_g = val; };
+    if constexpr (std::is_same<Model, CompactModel<T>>::value) {
+        linear_term<T, I, H>(m, (T*)nullptr, take_g);
+    } else if constexpr (H <= 10) {
+        T w[2 * H];
+        linear_term<T, I, H>(m, w, take_g);
+    } else {
+        linear_term_fn<T, I, H>(m, [&](int q, T val) { s_w[q] = val; }, [&](int q) { return s_w[q]; }, take_g);
+    }
     if (!active) my_g = (T)0;   // an idle lane shadows variable 0 through the prologue; from here on it is all zeros
     const T lo = m.lo(qj), hi = m.hi(qj);
     const T eps = (T)kn.eps;
@@ -360,7 +405,13 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w) {
         return a0 + a1;
     };
 
-    constexpr int kUnrollCd = 5, kUnrollPg = 8;
+#ifndef TPC_WAVE_UNROLL_CD
+#define TPC_WAVE_UNROLL_CD 5
+#endif
+#ifndef TPC_WAVE_UNROLL_PG
+#define TPC_WAVE_UNROLL_PG 8
+#endif
+    constexpr int kUnrollCd = TPC_WAVE_UNROLL_CD, kUnrollPg = TPC_WAVE_UNROLL_PG;
     uint32_t iter = 0;
     bool capped = true;
     // Two loops, one per phase; both kinds of step are computed SPECULATIVELY beside the stop test they do

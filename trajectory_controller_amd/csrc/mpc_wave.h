@@ -268,17 +268,19 @@ template <typename T, int I, int H> struct WaveIO<T, I, H, GeneralArgs> {
     }
 };
 
-// Row `slot` (= column, the Hessian is symmetric) of Hd = K'QK + R: dlib's gradient recurrences
+// Row `slot` (= column, the Hessian is symmetric) of K'QK, i.e. of the Hessian Hd = K'QK + R WITHOUT its R
+// (the diagonal's R*u is added where the gradient is formed: with R inside the row the compiler kept the
+// row and the R-free values both alive, 60 registers at N = 40): dlib's gradient recurrences
 // (mpc.h:275-283) applied to the unit vector e_(qi,qj) with MM = 0.  B*e is a column of B at step qi
 // and zero elsewhere, so no control vector is materialised; the arithmetic is the generic one
-// (x*1 = x, x + 0 = x exactly).  row[2*i + j] = Hd[(i,j)][(qi,qj)].
-// The lane's own diagonal entry before R is added is dlib's Q_diag of its variable: trans(B)*T_c*B with
+// (x*1 = x, x + 0 = x exactly).  row[2*i + j] = (K'QK)[(i,j)][(qi,qj)].
+// The lane's own diagonal entry is dlib's Q_diag of its variable: trans(B)*T_c*B with
 // T_c = sum_k trans(A^k)*Q*A^k is exactly what the recurrence accumulates at (q, q) -- and the diagonal
 // entries, R included, sum to dlib's lambda (its trace bound, mpc.h:116-123).  So the constructor's own
 // O(H) matrix recurrence is not run at all; the values differ from dlib's by rounding only (a different
 // association), like everything else in this family.
 template <typename T, int I, int H, class Model>
-TPC_DEV void hessian_row(const Model& m, bool active, int qi, int qj, T* row, T& own_qdiag) {
+TPC_DEV void hessian_row(const Model& m, bool active, int qi, int qj, T* row) {
     const T bq0 = active ? (qj == 0 ? m.B(0, 0) : m.B(0, I - 1)) : (T)0;
     const T bq1 = active ? (qj == 0 ? m.B(1, 0) : m.B(1, I - 1)) : (T)0;
     T m0 = (T)0, m1 = (T)0;
@@ -300,12 +302,29 @@ TPC_DEV void hessian_row(const Model& m, bool active, int qi, int qj, T* row, T&
         }
 #pragma unroll
         for (int j = 0; j < I; ++j) {
-            const bool own = active && i == qi && j == qj;
             const T btn = m.B(0, j) * n0 + m.B(1, j) * n1;
-            if (own) own_qdiag = btn;          // Hd[q][q] without R: dlib's Q_diag (mpc.h:118-121)
-            row[2 * i + j] = btn + (own ? m.R(j) : (T)0);
+            row[2 * i + j] = btn;
         }
     }
+}
+
+// a[idx] for a per-lane idx < LEN with the array in registers: a binary tree of selects on the bits of idx
+// (LEN - 1 selects under log2(LEN) lane masks; a chain of "idx == k ? a[k]" needs LEN masks, and keeping 2H of
+// them alive cost the N = 40 kernel 60 registers)
+template <typename T, int LEN> TPC_DEV T pick_own(const T* a, int idx) {
+    T lvl[LEN];
+#pragma unroll
+    for (int k = 0; k < LEN; ++k) lvl[k] = a[k];
+    int n = LEN;
+#pragma unroll
+    for (int bit = 0; (1 << bit) < LEN; ++bit) {
+        const bool odd = (idx >> bit) & 1;
+        const int half = (n + 1) / 2;
+#pragma unroll
+        for (int k = 0; k < half; ++k) lvl[k] = (2 * k + 1 < n) ? (odd ? lvl[2 * k + 1] : lvl[2 * k]) : lvl[2 * k];
+        n = half;
+    }
+    return lvl[0];
 }
 
 // One instance solved by the calling wavefront (all 64 lanes must call it together).
@@ -327,11 +346,18 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w) {
     // ---- prologue: this lane's Hessian row, Q_diag, linear-term element, lambda
     T row[2 * H];
     T my_qd = (T)0, my_g = (T)0;
-    hessian_row<T, I, H>(m, active, qi, qj, row, my_qd);
-    T kq[N];   // the entries of the row in variable order (for I = 1 every second slot of `row` is unused)
+    hessian_row<T, I, H>(m, active, qi, qj, row);
+    my_qd = active ? pick_own<T, 2 * H>(row, slot) : (T)0;   // dlib's Q_diag of this lane's variable (mpc.h:118-121)
+    // the entries of the row in variable order: the row itself for two inputs, every second slot of it for one
+    T kq_one[I == 2 ? 1 : N];
+    const T* kq = row;
+    if constexpr (I != 2) {
 #pragma unroll
-    for (int q = 0; q < N; ++q) kq[q] = row[2 * (q / I) + (q % I)];
-    const T lambda = wave_sum_all<N>(active ? my_qd + m.R(qj) : (T)0);   // trace of the Hessian
+        for (int q = 0; q < N; ++q) kq_one[q] = row[2 * (q / I) + (q % I)];
+        kq = kq_one;
+    }
+    const T my_r = active ? m.R(qj) : (T)0;
+    const T lambda = wave_sum_all<N>(my_qd + my_r);   // trace of the Hessian (idle lanes hold 0 + 0)
     // every lane computes the same linear term.  The compact model needs no intermediates (its own
     // linear_term: one target for all steps); a short general horizon keeps them in registers; a long
     // one parks them -- identical in all lanes -- in one small LDS vector instead of 2H registers per lane
@@ -386,7 +412,7 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w) {
     auto gradient_of = [&](T uu) -> T {
         // two accumulators: with a dependent v_fmac every second instruction the chain never waits
         // (8.6 cycles of latency against 2 x 4.8 of issue), and the linear term seeds one of them
-        T a0 = my_g, a1 = (T)0;
+        T a0 = my_g, a1 = my_r * uu;   // (the Hessian's R, on the diagonal)
         T x[4] = {uu, uu, uu, uu};
         if constexpr (N > 16) {
             const Swapped<T> p = swap_rows16(uu, uu);        // p.a = rows (0,0,2,2), p.b = rows (1,1,3,3)
@@ -547,8 +573,18 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w) {
 #define TPC_WAVES_PER_BLOCK 4
 #endif
 constexpr int kWavesPerBlock = TPC_WAVES_PER_BLOCK;
+// Registers: the row of N doubles, the controls and a few temporaries stay live through the loops, and the
+// set-up before them takes more if left alone (the scheduler interleaves its recurrences as far as the
+// 512-register file lets it: 181 registers at N = 40, two wavefronts per SIMD).  The occupancy that the
+// loops themselves allow is asked for explicitly; what the set-up then spills is a few dozen scratch
+// accesses per instance, none inside a loop.
+template <typename T, int I, int H> constexpr int wave_min_waves() {
+    const int dwords = I * H * (int)(sizeof(T) / 4);          // the row
+    return dwords <= 40 ? 5 : (dwords <= 80 ? 3 : 2);
+}
 template <typename T, int I, int H, class Model, class Args>
-__global__ __launch_bounds__(kWavesPerBlock * kWave) void wave_kernel(Args g, Knobs kn) {
+__global__ __launch_bounds__(kWavesPerBlock * kWave) __attribute__((amdgpu_waves_per_eu(wave_min_waves<T, I, H>())))
+void wave_kernel(Args g, Knobs kn) {
     __shared__ __attribute__((aligned(16))) T s_w[kWavesPerBlock][2 * H];
     const int w = threadIdx.x / kWave;
     const int64_t k = (int64_t)blockIdx.x * kWavesPerBlock + w;

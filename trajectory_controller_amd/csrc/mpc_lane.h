@@ -468,6 +468,31 @@ template <typename T, int H> struct FusedBig { static constexpr bool value = siz
 // per wave): four waves per CU.
 template <typename T, int H> struct FusedCkpt { static constexpr bool value = sizeof(T) == 8 && H == 40; };
 
+// fp32 only: v_med3_f32 is dlib's three-argument clamp in ONE instruction, and v_max3_f32 folds two
+// stop-test terms into the running maximum in one -- for operands that cannot be NaN (med3 returns the
+// minimum then, the clamp the upper bound), i.e. in the build the model's screen admits.  min / max / med3 /
+// max3 issue at the 4-cycle rate where plain fp32 multiplies and adds issue at 2 (scripts/ubench_pk.hip), so
+// they were 38 % of the fp32 iteration's time for 27 % of its instructions.  (fp64 has no med3.)
+TPC_DEV float med3(float x, float lo, float hi) {
+    float r;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
+    return r;
+}
+TPC_DEV float med3_neglo(float x, float neg_lo, float hi) {   // clamp of x to [-neg_lo, hi]
+    float r;
+    asm("v_med3_f32 %0, %1, -%2, %3" : "=v"(r) : "v"(x), "v"(neg_lo), "v"(hi));
+    return r;
+}
+TPC_DEV float max3_abs(float acc, float a, float b) {        // max(acc, |a|, |b|)
+    float r;
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(acc), "v"(a), "v"(b));
+    return r;
+}
+template <bool NONAN, typename T> TPC_DEV T clamp3_fast(T val, T lo, T hi) {
+    if constexpr (NONAN && sizeof(T) == 4) return (T)med3((float)val, (float)lo, (float)hi);
+    else return clamp3(val, lo, hi);
+}
+
 template <typename T, int I, int H, class Model, class Args, bool FAST>
 __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::value)) void lane_pg_fused_kernel(Args g, Knobs kn, const T* __restrict__ recs,
                                                               const uint32_t* __restrict__ order,
@@ -710,7 +735,7 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
             } else {
                 if constexpr (i < H - 1) m.bwd(n0, n1, w_get(2 * i), w_get(2 * i + 1));   // mpc.h:280-281
             }
-            T vn[2];
+            T vn[2], st[2];
             static_for<I>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 constexpr int q = 2 * i + j;
@@ -729,14 +754,21 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
                     // NaN for a screened instance, and controls never leave [lo, hi] (lo < 0 < hi).
                     const T g_lo = tfma(uu, huge, nlo_h[j]);
                     const T g_hi = tfma(uu, -huge, hi_h[j]);
-                    acc[(i * I + j) % NA] = tmax(acc[(i * I + j) % NA], tabs(tmax(tmin(dd, g_lo), -g_hi)));
+                    if constexpr (sizeof(T) == 4) {
+                        // one med3 per variable, one max3 per horizon step (both variables at once)
+                        st[j] = (T)med3_neglo((float)dd, (float)g_hi, (float)g_lo);
+                        if constexpr (j == I - 1)
+                            acc[i % NA] = (T)max3_abs((float)acc[i % NA], (float)st[0], (float)st[I - 1]);
+                    } else {
+                        acc[(i * I + j) % NA] = tmax(acc[(i * I + j) % NA], tabs(tmax(tmin(dd, g_lo), -g_hi)));
+                    }
                 } else {
                     const T up = (uu <= m.lo(j)) ? (T)0 : dd;                   // mpc.h:298-299
                     const T dn = (uu >= m.hi(j)) ? (T)0 : -dd;
                     acc[(i * I + j) % NA] = tmax(acc[(i * I + j) % NA], tmax(up, dn));
                 }
-                if constexpr (!MOVED) vn[j] = clamp3(uu - inv_lambda * dd, m.lo(j), m.hi(j));   // mpc.h:342
-                u[q] = clamp3(vn[j] + beta * (vn[j] - pv[cur][j]), m.lo(j), m.hi(j));   // mpc.h:343
+                if constexpr (!MOVED) vn[j] = clamp3_fast<FAST>(uu - inv_lambda * dd, m.lo(j), m.hi(j));   // mpc.h:342
+                u[q] = clamp3_fast<FAST>(vn[j] + beta * (vn[j] - pv[cur][j]), m.lo(j), m.hi(j));   // mpc.h:343
 #ifndef TPC_NO_UPIN
                 asm volatile("" : "+v"(u[q]));   // keep the update in its step (LLVM would sink it)
 #endif

@@ -21,6 +21,8 @@ H = 20.  It is not the default because the HIP events that time each kernel then
 its workgroups wait for CUs and stop agreeing with rocprofv3's dispatch timestamps.  "kernel_ms" is
 the average over the timed region of the library's events around each kernel (last solve of each
 handle), "kernel_ms_serial" the same measured right after the timed region with one batch in flight.
+A one-GPU run with the default one batch in flight also times the same K steps with two in flight and
+reports that figure under "pipelined" (value, ms_per_step, alu_frac), next to `value`.
 
 `value` is measured in fp64, the only dtype that meets the 1e-6 parity target (SURVEY.md section 0
 fact 3); the fp32 rate of the same workload is reported beside it under "fp32" with its error
@@ -62,6 +64,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-fp32", action="store_true")
     ap.add_argument("--inflight", type=int, default=1, help="batches kept in flight (handle + stream each)")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the two-batches-in-flight leg")
     return ap.parse_args()
 
 
@@ -329,6 +332,33 @@ def main():
             out["cpu_baseline"] = cb
             out["max_abs_du_vs_dlib"] = float(max(np.abs(gf - cf).max(), np.abs(gr - cr).max()))
             out["gpu_over_cpu"] = value / cb["value"]
+        if world == 1 and slots == 1 and not a.no_pipelined:
+            # the same K steps with two batches in flight (two handles, two streams): the next batch's
+            # coordinate-descent kernel and queue sort run while the previous batch's last long instances
+            # finish.  Reported beside `value`, which stays the one-batch-at-a-time figure whose kernel
+            # durations agree with the rocprofv3 summaries under profiles/.
+            s2 = MpcSolver(horizon=H, device=local_rank, dtype=a.dtype, algo=a.algo)
+            s2.reserve(n)
+            pair = [(solver, streams[0], fronts[0], rears[0]),
+                    (s2, torch.cuda.Stream(dev), torch.empty_like(tv), torch.empty_like(tv))]
+
+            def pstep(k):
+                sv, st, fo, ro = pair[k % 2]
+                with torch.cuda.stream(st):
+                    sv.solve_batch_compact(tv, ty, tp, out=(fo, ro), want_flags=False)
+            for k in range(4):
+                pstep(k)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(a.steps):
+                pstep(k)
+            torch.cuda.synchronize()
+            dp = time.perf_counter() - t1
+            same = bool(torch.equal(pair[1][2], fronts[0]) and torch.equal(pair[1][3], rears[0]))
+            out["pipelined"] = {"value": n * a.steps / dp, "unit": "solves/s", "batches_in_flight": 2,
+                                "ms_per_step": dp / a.steps * 1e3, "outputs_identical_to_serial": same,
+                                "alu_frac": alg_flops / (dp / a.steps) / 1e12 / peak_tf}
+            s2.close()
         if not a.no_fp32 and a.dtype == "f64":
             s32 = MpcSolver(horizon=H, device=local_rank, dtype="f32", algo=a.algo)
             v32, y32, p32 = tv.float(), ty.float(), tp.float()

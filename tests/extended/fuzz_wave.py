@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised differential run on the GPU box: WAVE fp64 (both mask forms, DPP and LDS exchange, every
-horizon it exists for) against the CPU oracle with random weights, bounds, step size, wheelbase, eps
+"""Randomised differential run on the GPU box: WAVE fp64 (both mask forms, one to four 16-lane rows of
+variables, every horizon it exists for) against the CPU oracle with random weights, bounds, step size, wheelbase, eps
 and iteration caps.  The WAVE family is not bit-exact (different summation order, FMA, a reciprocal
 instead of a division), so this counts what matters for it: instances whose ITERATION COUNT differs
 from dlib's (a decision flipped somewhere) and the largest |du| among the others.

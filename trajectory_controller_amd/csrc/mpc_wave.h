@@ -1,20 +1,25 @@
 // WAVE kernel: one 64-lane wavefront per MPC instance (the layout BASELINE.json's north_star
 // describes).  Lane q owns decision variable q = i*I + j (i = horizon step, j = input).
 //
-//   prologue  every lane runs dlib's O(H) gradient recurrence on the unit vector e_q: that is
-//             column q of the dense Hessian Hd = K'QK + R, kept in the lane's VGPRs as "its row"
-//             (Hd is symmetric).  lambda, Q_diag and the linear term MM are computed redundantly by
-//             all lanes; each keeps its own element.
-//   loop      controls are exchanged through a 2H-entry LDS vector (one ds_write per lane, then
-//             broadcast ds_reads); df_q = Hd[q,:].u + MM_q is a register dot product.
-//             Coordinate-descent iterations (iter < smo_iters) need the arg-max: DPP wavefront
-//             max + ballot, lowest index wins like dlib's strict '>' scan (mpc.h:292-308).
-//             Projected-gradient iterations need only "is any free |df| >= eps": one compare and a
-//             ballot, no reduction at all.
+//   set-up    every lane runs dlib's O(H) gradient recurrence on the unit vector e_q: that is column q
+//             of K'QK, kept in the lane's VGPRs as "its row" (the Hessian Hd = K'QK + R is symmetric; the
+//             R*u of the diagonal is added where the gradient is formed).  The lane's own diagonal entry
+//             is dlib's Q_diag of its variable and the diagonal entries, R included, sum to dlib's lambda
+//             (one wavefront sum), so the constructor's matrix recurrence is not run.  The linear term MM
+//             is computed redundantly by all lanes; each keeps its own element.
+//   loops     df_q = Hd[q,:].u + MM_q: one v_fmac_f64 per variable whose first operand is read through DPP
+//             (row_newbcast: the control of lane K of the 16-lane row), after v_permlane16/32_swap has
+//             given every row a copy of the other rows' controls -- no LDS, no wait.
+//             Coordinate-descent iterations (iter < smo_iters) need the arg-max: the masked |df| with its
+//             six lowest bits replaced by 63 - lane is a key whose wavefront maximum (butterfly DPP
+//             exchanges) names value and winner at once, lowest index first like dlib's strict '>' scan
+//             (mpc.h:292-308).  Projected-gradient iterations need only "is any free |df| >= eps": one
+//             compare and a ballot.  No branch inside an iteration: a step is applied under its own stop
+//             verdict as a select, and the loops look at the verdict once per block of iterations.
 //
 // Not bit-identical to dlib (the dot product sums in a different order; fused multiply-adds are
 // used), but it takes dlib's decisions on dlib's quantities, so iteration counts agree and the
-// outputs differ by ~1e-11 relative in fp64 (tests/test_parity_gpu.py).
+// outputs differ by ~1e-14 on the reference workload in fp64 (tests/test_parity_gpu.py).
 // Iteration counts are wave-uniform: no divergence, no refill.  Supports I*H <= 64.
 #pragma once
 

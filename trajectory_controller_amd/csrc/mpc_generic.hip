@@ -190,10 +190,7 @@ __global__ __launch_bounds__(64) void lane_generic_kernel(Args g, Knobs kn, int 
     if (nonfinite) f |= 0x1u;
     if (badmodel) f |= 0x4u;
     if (capped) f |= 0x2u;
-    const unsigned long long any = __ballot(f != 0u);
-    if (g.flags && any != 0ull) {   // one atomic per wavefront and flag pattern is plenty
-        if (f != 0u) atomicOr(g.flags, f);
-    }
+    raise_flags(g.flags, f);
 }
 
 template <typename T, int I, class Model, class Args>

@@ -256,14 +256,14 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args 
     // (every instance when max_iter <= smo_iters, under 1 % of the synthetic workload otherwise) is
     // complete: its outputs go out here, and the PG kernel's queue
     // ends where bins 0..127 begin (the scan leaves that position in the histogram, mpc_sort.hip).
+    uint32_t f = 0;
     if (publish_finished && finished) {
         LaneIO<T, I, H, Args>::write(g, k, u, [&](int) { return (T)0; }, iter);
-        uint32_t f = 0;
         if (nonfinite) f |= 0x1u;
         if (badmodel) f |= 0x4u;
         if (!stopped) f |= 0x2u;          // ran into max_iter inside this phase
-        if (g.flags && f) atomicOr(g.flags, f);
     }
+    raise_flags(g.flags, f);              // (every lane of the wavefront gets here)
     keys[k] = key;
     key_rank[k] = atomicAdd(&key_hist[key >> 16], 1u);   // counting sort: histogram + rank in bin (mpc_sort.hip)
 }
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(64, 1) void lane_pg_kernel(Args g, Knobs kn, const 
             }
         }
     }
-    if (g.flags && flags) atomicOr(g.flags, flags);
+    raise_flags(g.flags, flags);
     if (stats && lane == 0) {
         atomicAdd(&stats[0], (unsigned long long)wave_iters);   // wave-iterations executed
         atomicAdd(&stats[1], (unsigned long long)refills);      // refill blocks executed
@@ -819,7 +819,7 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
             }
         }
     }
-    if (g.flags && flags) atomicOr(g.flags, flags);
+    raise_flags(g.flags, flags);
     if (stats && (lane & (kWave - 1)) == 0) {
         atomicAdd(&stats[0], (unsigned long long)wave_iters);
         atomicAdd(&stats[1], (unsigned long long)refills);

@@ -563,12 +563,12 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w) {
     else if (mask_ok) run(std::true_type{});
     else run(std::false_type{});
     WaveIO<T, I, H, Args>::write(g, k, active, qi, qj, u, v, iter);
-    if (g.flags && lane == 0) {
+    if (g.flags) {   // (all lanes alike)
         uint32_t f = 0;
         if (nonfinite) f |= 0x1u;
         if (badmodel) f |= 0x4u;
         if (capped) f |= 0x2u;
-        if (f) atomicOr(g.flags, f);
+        raise_flags(g.flags, f);
     }
 }
 

@@ -63,8 +63,8 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
  *   LANE : one lane per instance, dlib's O(H) recurrences unrolled in registers, 64 instances
  *          per wavefront with dynamic refill of finished lanes.  Bit-identical to the reference
  *          arithmetic in fp64; highest throughput on large batches.
- *   AUTO : WAVE below a measured crossover (about 29 000 instances on a 256-CU part), LANE from
- *          there up. */
+ *   AUTO : WAVE below a measured crossover (about 29 000 instances on a 256-CU part, 32 768 from
+ *          N = 20), LANE from there up. */
 typedef enum tpc_mpc_algo { TPC_MPC_ALGO_AUTO = 0, TPC_MPC_ALGO_WAVE = 1, TPC_MPC_ALGO_LANE = 2 } tpc_mpc_algo;
 
 /* Non-fatal per-call flags, OR-ed into *flags_out (may be NULL). */
@@ -294,7 +294,8 @@ int tpc_mpc_reserve(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n, int me
 
 /* EXPERIMENTAL; no reference counterpart (one controller solves one problem per cycle there).  Instances of a
  * batch need between a few and several thousand iterations (mpc.h:271, :310), and the batch
- * finishes when its slowest lane does, so the LANE kernels start the instances expected to run
+ * finishes when its slowest lane does, so the LANE kernels -- and the WAVE kernels when a batch has
+ * more instances than wavefronts fit the chip (N >= 10) -- start the instances expected to run
  * longest first.  Their own estimate is dlib's lambda (mpc.h:116-123) with a correction where it
  * is uninformative.  A caller that knows the iteration counts better passes them here: hint[k] =
  * expected iteration count of instance k (e.g. the `iters` output of an earlier solve of the SAME

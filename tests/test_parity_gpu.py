@@ -745,6 +745,36 @@ def test_wave_mask_forms_vs_oracle(torch_cuda, oracle, I):
     run(g)
 
 
+@pytest.mark.parametrize("H", [10, 20, 30])
+def test_wave_queue_vs_oracle(torch_cuda, oracle, H):
+    """More instances than the WAVE family's persistent grid holds (two wavefronts per SIMD): they are taken
+    from a longest-first queue, ordered by lambda or by the caller's work hint.  The order must not change a
+    result: iteration counts equal the oracle's, outputs within the family's tolerance, with and without a
+    hint, compact and general form, and a batch that fits the grid (no queue) agrees on its share."""
+    from trajectory_controller_amd.synth import compact_inputs, general_inputs
+    n = 5000 if H < 30 else 3000
+    v, dy, dphi = compact_inputs(H, n, first=31000 + H)
+    of, orr, oit = oracle.solve_compact(H, v, dy, dphi, nthreads=8)
+    with _solver(H, "wave") as s:
+        f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+        assert np.array_equal(it, oit)
+        assert max(np.abs(f - of).max(), np.abs(r - orr).max()) <= WAVE_ATOL
+        s.set_work_hint(np.ascontiguousarray(oit[::-1].astype(np.int32)))    # a deliberately bad order
+        f2, r2, it2 = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+        assert np.array_equal(it2, oit) and np.array_equal(f2, f) and np.array_equal(r2, r)
+        s.set_work_hint(None)
+        f3, r3, it3 = s.solve_batch_compact(v[:700], dy[:700], dphi[:700], want_iters=True)   # fits the grid
+        assert np.array_equal(it3, oit[:700]) and np.array_equal(f3, f[:700]) and np.array_equal(r3, r[:700])
+        for I in (1, 2):
+            if I * H > 64:
+                continue
+            g = general_inputs(H, 2600, I=I, first=52000 + H)
+            u0, _, git0 = oracle.solve_general(I, H, *[g[k] for k in GEN_NAMES], nthreads=8)
+            gu0, git = s.solve_batch_general(*[_soa(g[k]) for k in GEN_NAMES], inputs=I, want_iters=True)
+            assert np.array_equal(git, git0), I
+            assert np.abs(gu0.T - u0).max() <= WAVE_ATOL, I
+
+
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("H", [1, 2, 3, 7, 8, 15, 25, 33, 64])
 def test_generic_horizon_vs_oracle(torch_cuda, oracle, oracle32, H, dtype):

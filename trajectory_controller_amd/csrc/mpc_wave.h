@@ -67,16 +67,6 @@ template <int CTRL> TPC_DEV float dpp_shr0(float x) {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xf, 0xf, true));
 }
 
-// value of lane K of the caller's 16-lane row, in every lane of that row (DPP row_newbcast)
-template <int K> TPC_DEV double row_bcast(double x) {
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0x150 + K, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0x150 + K, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-template <int K> TPC_DEV float row_bcast(float x) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x150 + K, 0xf, 0xf, false));
-}
-
 // a0 += sum over even q, a1 += sum over odd q, of (x of lane q of the caller's 16-lane row) * k[q], q < CNT:
 // v_fmac with a DPP row_newbcast first operand -- the broadcast and the multiply-add are one instruction.
 // One asm block per row of controls: inline asm is opaque to the compiler's hazard recogniser, which
@@ -178,8 +168,7 @@ TPC_DEV double round_up_key(double x) {   // smallest value with a clear tag tha
 }
 TPC_DEV float round_up_key(float x) { return x; }
 TPC_DEV double unpack_key(double x) { return __hiloint2double(__double2hiint(x), __double2loint(x) & ~63); }
-TPC_DEV float pack_key_abs(float x, int) { return tabs(x); }   // (unused: fp32 keeps the two-step arg-max, six of 23 bits is too much)
-TPC_DEV float unpack_key(float x) { return x; }
+// (fp32 keeps the two-step arg-max: six of its 23 mantissa bits is too much to give to the tag)
 
 // max over lanes 0 .. N-1 (the other lanes hold 0), returned wave-uniform.  x >= 0; a NaN lane
 // is ignored (v_max returns the other operand).  Only as many DPP steps as N needs: the reduction is
@@ -594,6 +583,110 @@ void wave_kernel(Args g, Knobs kn) {
     const int w = threadIdx.x / kWave;
     const int64_t k = (int64_t)blockIdx.x * kWavesPerBlock + w;
     if (k < g.n) wave_solve<T, I, H, Model, Args>(g, kn, k, s_w[w]);
+}
+
+
+// ---- work queue (batches with more instances than the persistent grid holds) -----------------------------
+// Iteration counts differ ~30x between instances, a SIMD runs the wavefronts it was given and nothing else,
+// and with every instance resident at once a launch lasts as long as its unluckiest SIMD: 1.8x the mean at
+// 4 096 instances.  From N = 10 up the grid is therefore kQueueWorkgroupsPerCu workgroups of four persistent
+// wavefronts per CU (two per SIMD), each taking instances from an atomic ticket over a queue ordered
+// longest-first -- by lambda, dlib's own Hessian trace bound (the step is 1/lambda: large lambda, many small
+// steps; Spearman 0.89 / 0.97 with the iteration count at N = 10 / 20), or by the caller's work hint.
+// Measured (kernel time, 4 096 / 16 384 instances): N = 10: 226 -> 215 / 609 -> 602 us, N = 20: 1 266 -> 909 /
+// 3 455 -> 2 575 us, N = 30: 3 849 -> 2 488 / 11 256 -> 7 164 us.  At N = 4 and 5 an instance is too short for the
+// queue to pay (45 -> 92 us): those keep one launch slot per instance.
+constexpr int kQueueWorkgroupsPerCu = 2;
+constexpr int kQueueMinHorizon = 10;
+constexpr int kOrderThreads = 1024, kOrderBins = 2048, kOrderPerThread = 32;
+constexpr int64_t kQueueMaxInstances = (int64_t)kOrderThreads * kOrderPerThread;   // larger batches: plain launch
+
+// One workgroup: a key per instance (kept in registers) -> counting sort over kOrderBins linear bins of the
+// key range -> order[] (descending), ticket = first queue position nobody starts on.  Positions inside a bin
+// come from atomics and are not reproducible; they decide which wavefront solves which instance, never a result.
+template <typename T, int I, int H, class Model, class Args>
+__global__ __launch_bounds__(kOrderThreads) void wave_order_kernel(Args g, uint32_t* __restrict__ order,
+                                                                   uint32_t* __restrict__ ticket, uint32_t first_ticket) {
+    __shared__ uint32_t bins[kOrderBins];
+    __shared__ uint32_t wave_sum[kOrderThreads / kWave];
+    __shared__ uint32_t kmin, kmax;
+    const int t = threadIdx.x;
+    const int n = (int)g.n;
+    if (t == 0) { kmin = 0xffffffffu; kmax = 0u; *ticket = first_ticket; }
+    for (int b = t; b < kOrderBins; b += kOrderThreads) bins[b] = 0u;
+    uint32_t key[kOrderPerThread];
+    uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+    for (int j = 0; j < kOrderPerThread; ++j) {
+        const int i = j * kOrderThreads + t;
+        key[j] = 0u;
+        if (j * kOrderThreads < n) {
+            if (i < n) {
+                if (g.work_hint) {
+                    const int32_t w = g.work_hint[i];
+                    key[j] = w > 0 ? (uint32_t)w : 0u;
+                } else {
+                    Model m;
+                    m.load(g, i);
+                    float lf;
+                    if constexpr (std::is_same<Model, CompactModel<T>>::value)
+                        lf = (float)tabs(m.a);   // one batch-wide Q, R, T, l: lambda grows with |T v|, which orders the same
+                    else
+                        lf = (float)ctor_lambda_qdiag<T, I, H>(m, [](int, int, T) {});
+                    key[j] = (lf > 0.0f && lf < __builtin_inff()) ? (uint32_t)__float_as_int(lf) : 0u;
+                }
+                lo = key[j] < lo ? key[j] : lo;
+                hi = key[j] > hi ? key[j] : hi;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t l2 = (uint32_t)__shfl_xor((int)lo, off), h2 = (uint32_t)__shfl_xor((int)hi, off);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    __syncthreads();
+    if ((t & 63) == 0) { atomicMin(&kmin, lo); atomicMax(&kmax, hi); }
+    __syncthreads();
+    const uint32_t top = kmax, span = kmax > kmin ? kmax - kmin : 1u;
+    auto bin_of = [&](uint32_t k) { return (uint32_t)(((uint64_t)(top - k) * (kOrderBins - 1)) / span); };
+#pragma unroll
+    for (int j = 0; j < kOrderPerThread; ++j)
+        if (j * kOrderThreads + t < n) atomicAdd(&bins[bin_of(key[j])], 1u);
+    __syncthreads();
+    constexpr int kPer = kOrderBins / kOrderThreads;
+    uint32_t c[kPer], sum = 0;
+    for (int j = 0; j < kPer; ++j) { c[j] = bins[t * kPer + j]; sum += c[j]; }
+    uint32_t incl = sum;
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+        if ((t & 63) >= off) incl += up;
+    }
+    if ((t & 63) == 63) wave_sum[t >> 6] = incl;
+    __syncthreads();
+    uint32_t pos = incl - sum;
+    for (int w = 0; w < (t >> 6); ++w) pos += wave_sum[w];
+    for (int j = 0; j < kPer; ++j) { bins[t * kPer + j] = pos; pos += c[j]; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kOrderPerThread; ++j)
+        if (j * kOrderThreads + t < n) order[atomicAdd(&bins[bin_of(key[j])], 1u)] = (uint32_t)(j * kOrderThreads + t);
+}
+
+// Workgroup b's wavefront w starts on queue position 4 b + w and goes on with order[ticket++] until the queue
+// is empty (the next ticket is fetched before the solve it follows).
+template <typename T, int I, int H, class Model, class Args>
+__global__ __launch_bounds__(kWavesPerBlock * kWave) __attribute__((amdgpu_waves_per_eu(wave_min_waves<T, I, H>())))
+void wave_queue_kernel(Args g, Knobs kn, const uint32_t* __restrict__ order, uint32_t* ticket) {
+    __shared__ __attribute__((aligned(16))) T s_w[kWavesPerBlock][2 * H];
+    const int w = threadIdx.x / kWave;
+    uint32_t t = blockIdx.x * kWavesPerBlock + w;
+    while ((int64_t)t < g.n) {
+        uint32_t next = 0;
+        if ((threadIdx.x & (kWave - 1)) == 0) next = atomicAdd(ticket, 1u);
+        wave_solve<T, I, H, Model, Args>(g, kn, (int64_t)order[t], s_w[w]);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+    }
 }
 
 }  // namespace tpc

@@ -13,6 +13,20 @@ namespace {
 
 constexpr int kH = TPC_WAVE_H;
 
+// compute units of the current device, cached per device ordinal
+int cu_count() {
+    constexpr int kMaxDev = 64;
+    static int cache[kMaxDev] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 256;
+    if (cache[dev] <= 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cache[dev] = cus;
+    }
+    return cache[dev];
+}
+
 template <typename T, int I, class Model, class Args>
 hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
     if constexpr (I * kH > kWave) {
@@ -21,6 +35,14 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
         if (a.n <= 0) return hipSuccess;
         if (a.n > 0x7fffffffll) return hipErrorInvalidValue;
         if (ws.ev) (void)hipEventRecord(ws.ev[0], s);
+        // more instances than the persistent grid holds: wavefronts over a longest-first queue (mpc_wave.h)
+        const int64_t slots = (int64_t)cu_count() * kQueueWorkgroupsPerCu * kWavesPerBlock;
+        if (kH >= kQueueMinHorizon && a.n > slots && a.n <= kQueueMaxInstances && ws.order) {
+            hipLaunchKernelGGL((wave_order_kernel<T, I, kH, Model, Args>), dim3(1), dim3(kOrderThreads), 0, s, a,
+                               ws.order, ws.ticket, (uint32_t)slots);
+            hipLaunchKernelGGL((wave_queue_kernel<T, I, kH, Model, Args>), dim3((unsigned)(slots / kWavesPerBlock)),
+                               dim3(kWavesPerBlock * kWave), 0, s, a, k, (const uint32_t*)ws.order, ws.ticket);
+        } else
         hipLaunchKernelGGL((wave_kernel<T, I, kH, Model, Args>), dim3((unsigned)((a.n + kWavesPerBlock - 1) / kWavesPerBlock)),
                            dim3(kWavesPerBlock * kWave), 0, s, a, k);
         const hipError_t e = hipGetLastError();

@@ -54,7 +54,8 @@ const int32_t* take_hint(tpc_mpc_context* h, int64_t n) {
 // LANE needs enough instances to give every SIMD a full wavefront; below that WAVE's
 // one-wavefront-per-instance launch finishes sooner.  Measured crossovers on MI355X
 // (scripts/crossover.py, fp64, compact form, round 2 kernels; the chip has 65 536 LANE slots):
-// H = 4 and H = 10: between 24 576 and 32 768 instances, H = 20: between 32 768 and 49 152.
+// H = 4 and H = 10: between 24 576 and 32 768 instances; H = 20: WAVE still wins at 32 768, the largest
+// batch its work queue takes (5.4 against 6.9 ms), and loses without the queue beyond.
 // The WAVE kernel maps one decision variable to one lane, so it exists for I*H <= 64 only.
 // Returns the kernel family to run, or -1 when WAVE was demanded for a shape it cannot take.
 int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n) {
@@ -63,7 +64,7 @@ int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n) {
     if (algo == TPC_MPC_ALGO_WAVE) return wave_ok ? algo : -1;
     if (algo == TPC_MPC_ALGO_LANE) return algo;
     const int64_t lanes = (int64_t)h->cu_count * 4 * kWave;
-    const int64_t crossover = lanes * 7 / 16;
+    const int64_t crossover = H >= 20 ? lanes / 2 + 1 : lanes * 7 / 16;
     return (n >= crossover || !wave_ok) ? TPC_MPC_ALGO_LANE : TPC_MPC_ALGO_WAVE;
 }
 
@@ -122,6 +123,13 @@ int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n,
         int rc = ensure(h, &h->ws_state, &h->ws_bytes, pad256(generic_scratch_bytes(H, dtype, n)));
         if (rc) return rc;
         ws->state = h->ws_state;
+        ws->capacity_bytes = h->ws_bytes;
+    }
+    if (algo == TPC_MPC_ALGO_WAVE) {
+        // order[] of the longest-first queue (mpc_wave.h); batches that fit the chip at once do not use it
+        int rc = ensure(h, &h->ws_state, &h->ws_bytes, pad256(n * 4));
+        if (rc) return rc;
+        ws->order = (uint32_t*)h->ws_state;
         ws->capacity_bytes = h->ws_bytes;
     }
     if (algo == TPC_MPC_ALGO_LANE) {

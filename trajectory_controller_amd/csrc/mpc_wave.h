@@ -567,15 +567,11 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w) {
 #define TPC_WAVES_PER_BLOCK 4
 #endif
 constexpr int kWavesPerBlock = TPC_WAVES_PER_BLOCK;
-// Registers: the row of N doubles, the controls and a few temporaries stay live through the loops, and the
-// set-up before them takes more if left alone (the scheduler interleaves its recurrences as far as the
-// 512-register file lets it: 181 registers at N = 40, two wavefronts per SIMD).  The occupancy that the
-// loops themselves allow is asked for explicitly; what the set-up then spills is a few dozen scratch
-// accesses per instance, none inside a loop.
-template <typename T, int I, int H> constexpr int wave_min_waves() {
-    const int dwords = I * H * (int)(sizeof(T) / 4);          // the row
-    return dwords <= 40 ? 5 : (dwords <= 80 ? 3 : 2);
-}
+// Registers: two wavefronts per SIMD is what the work queue keeps resident and what a batch that fits the
+// chip at once amounts to, so that is the occupancy asked for (256 registers): only the 60-variable kernels'
+// set-up code spills under it (a few dozen scratch accesses per instance, none inside a loop).  Asking for
+// more made the set-up code of the smaller kernels spill too: 20 MB of scratch traffic per 4 096 instances.
+template <typename T, int I, int H> constexpr int wave_min_waves() { return 2; }
 template <typename T, int I, int H, class Model, class Args>
 __global__ __launch_bounds__(kWavesPerBlock * kWave) __attribute__((amdgpu_waves_per_eu(wave_min_waves<T, I, H>())))
 void wave_kernel(Args g, Knobs kn) {

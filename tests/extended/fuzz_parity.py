@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential run on the GPU box: LANE fp64 (both builds of the stop test, every
 horizon) against the CPU oracle with random weights, bounds, step size, wheelbase, eps and
-iteration caps.  Prints one line per parameter set; exits non-zero on any mismatch."""
+iteration caps.  Prints one line per parameter set; exits non-zero on any mismatch.
+DTYPE=f32 in the environment runs the fp32 kernels against the float-typed restatement instead."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -10,7 +11,9 @@ from trajectory_controller_amd import MpcSolver
 from trajectory_controller_amd.synth import compact_inputs
 
 build_oracle()
-orc = Oracle()
+DT = os.environ.get("DTYPE", "f64")
+orc = Oracle(dtype=DT)
+NP, UI = (np.float64, np.uint64) if DT == "f64" else (np.float32, np.uint32)
 rng = np.random.default_rng(int(os.environ.get("SEED", "20261003")))
 sets = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
@@ -33,16 +36,16 @@ for s_i in range(sets):
     v, dy, dphi = compact_inputs(H, m, first=int(rng.integers(0, 1 << 30)))
     scale = float(rng.choice([1.0, 1.0, 0.2, 3.0]))
     dy, dphi = dy * scale, dphi * scale
+    v, dy, dphi = v.astype(NP), dy.astype(NP), dphi.astype(NP)
     if rng.random() < 0.3:
-        v[rng.integers(0, m, 5)] = rng.choice([0.0, 1e-12, 50.0, np.nan, 1e70], 5)
+        v[rng.integers(0, m, 5)] = rng.choice([0.0, 1e-12, 50.0, np.nan, 1e70 if DT == "f64" else 1e8], 5)
     of, orr, oit = orc.solve_compact(H, v, dy, dphi, weights=w, T=T, l=l, lo=lo, hi=hi, eps=eps,
                                      max_iter=cap, smo_iters=smo, nthreads=threads)
-    with MpcSolver(horizon=H, algo="lane", weight_y=w[0], weight_phi=w[1], weight_steering_front=w[2],
+    with MpcSolver(horizon=H, algo="lane", dtype=DT, weight_y=w[0], weight_phi=w[1], weight_steering_front=w[2],
                    weight_steering_rear=w[3], lower=lo, upper=hi, step_size=T, wheelbase=l, eps=eps,
                    max_iter=cap, smo_iters=smo) as s:
         f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
-    same = lambda x, y: np.array_equal(x.view(np.uint64), y.view(np.uint64))
-    mism = int(np.sum((f.view(np.uint64) != of.view(np.uint64)) | (r.view(np.uint64) != orr.view(np.uint64)) | (it != oit)))
+    mism = int(np.sum((f.view(UI) != of.view(UI)) | (r.view(UI) != orr.view(UI)) | (it != oit)))
     bad += mism
     print(f"set {s_i:3d} H={H:2d} n={m:5d} bounds kind {kind} eps {eps:.1e} cap {cap:5d} smo {smo:3d} "
           f"mean iters {oit.mean():7.1f}: mismatching instances {mism}", flush=True)

@@ -38,14 +38,16 @@ for s_i in range(sets):
     dy, dphi = dy * scale, dphi * scale
     v, dy, dphi = v.astype(NP), dy.astype(NP), dphi.astype(NP)
     if rng.random() < 0.3:
-        v[rng.integers(0, m, 5)] = rng.choice([0.0, 1e-12, 50.0, np.nan, 1e70 if DT == "f64" else 1e8], 5)
+        v[rng.integers(0, m, 5)] = rng.choice([0.0, 1e-12, 50.0, np.nan, 1e70 if DT == "f64" else 1e30], 5)
     of, orr, oit = orc.solve_compact(H, v, dy, dphi, weights=w, T=T, l=l, lo=lo, hi=hi, eps=eps,
                                      max_iter=cap, smo_iters=smo, nthreads=threads)
     with MpcSolver(horizon=H, algo="lane", dtype=DT, weight_y=w[0], weight_phi=w[1], weight_steering_front=w[2],
                    weight_steering_rear=w[3], lower=lo, upper=hi, step_size=T, wheelbase=l, eps=eps,
                    max_iter=cap, smo_iters=smo) as s:
         f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
-    mism = int(np.sum((f.view(UI) != of.view(UI)) | (r.view(UI) != orr.view(UI)) | (it != oit)))
+    # bits, except that any NaN equals any NaN (x86 and the GPU disagree on the default NaN's sign bit)
+    diff = lambda x, y: (x.view(UI) != y.view(UI)) & ~(np.isnan(x) & np.isnan(y))
+    mism = int(np.sum(diff(f, of) | diff(r, orr) | (it != oit)))
     bad += mism
     print(f"set {s_i:3d} H={H:2d} n={m:5d} bounds kind {kind} eps {eps:.1e} cap {cap:5d} smo {smo:3d} "
           f"mean iters {oit.mean():7.1f}: mismatching instances {mism}", flush=True)

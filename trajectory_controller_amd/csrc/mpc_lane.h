@@ -466,7 +466,11 @@ template <typename T, int H> struct FusedBig { static constexpr bool value = siz
 // re-computation with the original and keep the value alive).  That is 8 extra flops per second
 // step, and the state shrinks to u (VGPRs) + 80 words of w + v (VGPRs and AGPRs) + MM (LDS, 40 KB
 // per wave): four waves per CU.
-template <typename T, int H> struct FusedCkpt { static constexpr bool value = sizeof(T) == 8 && H == 40; };
+// The same plan pays at H = 30 too (compact model): against FusedBig's all-AGPR w and v it halves w, keeps
+// 16 steps of v in VGPRs instead of 8 and so saves ~320 of the loop's 550 AGPR moves for ~120 recomputed
+// flops: 37.8 -> 35.7 ms per 262 144 instances (KV = 8 / 12 / 16 / 20: 37.3 / 36.1 / 35.7 / 36.8 ms), same bits.
+template <typename T, int H> struct FusedCkpt { static constexpr bool value = sizeof(T) == 8 && (H == 40 || H == 30); };
+template <typename T, int H> struct FusedCkptVRegSteps { static constexpr int value = H == 30 ? 16 : FusedVRegSteps<T, H>::value; };
 
 // fp32 only: v_med3_f32 is dlib's three-argument clamp in ONE instruction, and v_max3_f32 folds two
 // stop-test terms into the running maximum in one -- for operands that cannot be NaN (med3 returns the
@@ -514,11 +518,11 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
     // barrier anywhere): one 40 KB workgroup per SIMD pair is what the CU is known to co-schedule.
     constexpr int BT = kWave * FusedOcc<T, H>::value;
     constexpr bool REGS = FusedInRegs<T, H>::value;
-    constexpr int KV = REGS ? H : FusedVRegSteps<T, H>::value;   // steps of v in VGPRs
     // CK: checkpointed w (see FusedCkpt); compact model only -- the general model's linear term
     // routes 2H intermediates through w at every refill
     constexpr bool CK = FusedCkpt<T, H>::value && std::is_same<Model, CompactModel<T>>::value;
-    constexpr bool BIG = FusedBig<T, H>::value;
+    constexpr bool BIG = FusedBig<T, H>::value && !CK;
+    constexpr int KV = REGS ? H : (CK ? FusedCkptVRegSteps<T, H>::value : FusedVRegSteps<T, H>::value);   // steps of v in VGPRs
     constexpr int KA = REGS ? 0 : ((BIG || CK) ? H - KV : 0);    // next steps of v in AGPRs
     constexpr int VL = H - KV - KA;                              // the rest of v in LDS
     constexpr bool WA = BIG || CK;                               // w in AGPRs

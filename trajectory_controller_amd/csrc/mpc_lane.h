@@ -439,7 +439,10 @@ template <typename T, int H> struct ExitEveryStop { static constexpr bool value 
 // measured per kernel (scripts/ab_many.sh, both forms at every horizon and dtype)
 template <typename T, int H> struct ExitEveryStop { static constexpr bool value = (sizeof(T) == 8 && H == 20) || (sizeof(T) == 4 && H == 30); };
 #endif
-template <typename T, int H> struct FusedInRegs { static constexpr bool value = H * (int)sizeof(T) <= 80; };
+// fp32 at H = 30 / 40 keeps everything in registers as well (240 / 320 of them), at one wave per SIMD: without
+// the LDS round trips of MM and v the kernels run 29.6 -> 26.0 ms (H = 30) and 73.6 -> 67.4 ms (H = 40) per
+// 262 144 instances.
+template <typename T, int H> struct FusedInRegs { static constexpr bool value = H * (int)sizeof(T) <= 80 || sizeof(T) == 4; };
 #ifdef TPC_KV_STEPS   // A/B override: horizon steps of v kept in VGPRs by the LDS/AGPR plans
 template <typename T, int H> struct FusedVRegSteps { static constexpr int value = FusedInRegs<T, H>::value ? 0 : TPC_KV_STEPS; };
 #else
@@ -447,7 +450,7 @@ template <typename T, int H> struct FusedVRegSteps {
     static constexpr int value = sizeof(T) != 8 ? 0 : (H == 20 ? 6 : ((H == 30 || H == 40) ? 8 : 0));
 };
 #endif
-template <typename T, int H> struct FusedOcc { static constexpr int value = FusedInRegs<T, H>::value ? 2 : 1; };
+template <typename T, int H> struct FusedOcc { static constexpr int value = H * (int)sizeof(T) <= 80 ? 2 : 1; };   // 160 state registers: two waves per SIMD
 // fp64, H = 30: u (120 words) fits the VGPRs, but MM and v in LDS take 61 KB per wave and leave two
 // of a CU's four SIMDs without a wave.  The forward-pass array w and all of v go to AGPRs instead
 // (240 of the 256; two v_accvgpr moves per double and direction: 550 of the loop's 2130

@@ -450,6 +450,8 @@ template <typename T, int H> struct FusedVRegSteps {
     static constexpr int value = sizeof(T) != 8 ? 0 : (H == 20 ? 6 : ((H == 30 || H == 40) ? 8 : 0));
 };
 #endif
+// (four waves per SIMD for the short fp32 horizons, whose state would allow it, measured 10-12 % SLOWER:
+// fewer lanes per refill pass and more waves pulling on the one ticket)
 template <typename T, int H> struct FusedOcc { static constexpr int value = H * (int)sizeof(T) <= 80 ? 2 : 1; };   // 160 state registers: two waves per SIMD
 // fp64, H = 30: u (120 words) fits the VGPRs, but MM and v in LDS take 61 KB per wave and leave two
 // of a CU's four SIMDs without a wave.  The forward-pass array w and all of v go to AGPRs instead

@@ -57,14 +57,16 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
 
 /* Kernel family.
  *   WAVE : one 64-lane wavefront per instance; lane j owns decision variable j and its row of the
- *          dense (I*H)x(I*H) Hessian, the controls are exchanged through LDS, reductions by
- *          wavefront DPP/ballot.  Lowest latency; used for small batches and solve_one.  Needs
- *          I*H <= 64.  Agrees with the reference to ~1e-14 (same decisions, different summation).
+ *          dense (I*H)x(I*H) Hessian (two variables per lane where I*H > 64: I = 2, H <= 64), the
+ *          controls are exchanged by DPP / lane swaps, reductions by wavefront DPP/ballot.  Lowest
+ *          latency; used for small and mid-size batches and solve_one.  Needs a specialised horizon
+ *          with I*H <= 64 or I = 2.  Agrees with the reference to ~1e-14 (same decisions, different
+ *          summation).
  *   LANE : one lane per instance, dlib's O(H) recurrences unrolled in registers, 64 instances
  *          per wavefront with dynamic refill of finished lanes.  Bit-identical to the reference
  *          arithmetic in fp64; highest throughput on large batches.
  *   AUTO : WAVE below a measured crossover (about 29 000 instances on a 256-CU part, 32 768 from
- *          N = 20), LANE from there up. */
+ *          N = 20, 15 360 at N = 40 with two inputs), LANE from there up. */
 typedef enum tpc_mpc_algo { TPC_MPC_ALGO_AUTO = 0, TPC_MPC_ALGO_WAVE = 1, TPC_MPC_ALGO_LANE = 2 } tpc_mpc_algo;
 
 /* Non-fatal per-call flags, OR-ed into *flags_out (may be NULL). */
@@ -112,7 +114,7 @@ const char* tpc_mpc_last_error(tpc_mpc_handle h);
 
 /* dlib::mpc<2,I,H> is a template: any horizon compiles.  Here every horizon 1 <= H <= 64 is accepted;
  * the ones this function lists (writes up to `cap`, returns how many exist) have kernels specialised
- * at compile time (LANE, and WAVE where I*H <= 64), every other one runs a generic kernel with H as a
+ * at compile time (LANE and WAVE), every other one runs a generic kernel with H as a
  * run-time value -- the same arithmetic, the same results (fp64: bit for bit), several times slower. */
 int tpc_mpc_supported_horizons(int* out, int cap);
 int tpc_mpc_abi_version(void);
@@ -135,7 +137,7 @@ int tpc_mpc_solve_one(tpc_mpc_handle h, const tpc_mpc_params* p, double v, doubl
                       double delta_phi, double* steering_front, double* steering_rear);
 
 /* No reference counterpart.  tpc_mpc_solve_one keeps one wavefront resident on the GPU between
- * calls (fp64, horizons with 2*N <= 64, algo AUTO or WAVE; other requests take an ordinary launch).
+ * calls (fp64, the specialised horizons, algo AUTO or WAVE; other requests take an ordinary launch).
  * The wavefront leaves by itself `idle_timeout_us` after its last request (default 20 000) and is
  * started again by the next call; tpc_mpc_destroy stops it.  While it is resident a device-wide
  * synchronisation elsewhere in the process (hipDeviceSynchronize, hipFree) waits for it, i.e. up to

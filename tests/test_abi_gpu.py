@@ -433,7 +433,7 @@ def test_follow_batch_horizon(torch_cuda, oracle):
 
 @pytest.mark.parametrize("H", [4, 5, 10, 20, 30, 40])
 def test_solve_one_resident_vs_oracle(torch_cuda, oracle, H):
-    """tpc_mpc_solve_one through the resident wavefront (H <= 30) or an ordinary launch (H = 40),
+    """tpc_mpc_solve_one through the resident wavefront (every specialised horizon; two variables per lane at H = 40),
     a few dozen different requests in a row, against the oracle; then the same with the resident mode
     off, after an idle timeout (the wave has left and must be started again), and with changed knobs."""
     from trajectory_controller_amd.synth import compact_inputs

@@ -73,44 +73,68 @@ template <int CTRL> TPC_DEV float dpp_shr0(float x) {
 // otherwise pads every pair of separate asms with a nop; a VGPR written by the VALU needs two wait
 // states before a DPP read, so the block opens with them (x may come straight out of an ALU op).
 // Two accumulators: alternate v_fmacs depend on each other at distance 2, ~2 x 4.8 cycles of issue
-// against 8.6 of latency.
-template <int CNT> TPC_DEV void fmac_row(double& a0, double& a1, double x, const double* k) {
+// against 8.6 of latency.  S: stride of the entries in k (2 where a lane's row interleaves two inputs).
+template <int CNT, int S = 1> TPC_DEV void fmac_row(double& a0, double& a1, double x, const double* k) {
     static_assert(CNT >= 1 && CNT <= 16, "one 16-lane row");
-    if constexpr (CNT == 1) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]));
-    else if constexpr (CNT == 2) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]));
-    else if constexpr (CNT == 3) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]));
-    else if constexpr (CNT == 4) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]));
-    else if constexpr (CNT == 5) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]));
-    else if constexpr (CNT == 6) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]));
-    else if constexpr (CNT == 7) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]));
-    else if constexpr (CNT == 8) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]));
-    else if constexpr (CNT == 9) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]));
-    else if constexpr (CNT == 10) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]));
-    else if constexpr (CNT == 11) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]));
-    else if constexpr (CNT == 12) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]));
-    else if constexpr (CNT == 13) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]), "v"(k[12]));
-    else if constexpr (CNT == 14) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]), "v"(k[12]), "v"(k[13]));
-    else if constexpr (CNT == 15) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]), "v"(k[12]), "v"(k[13]), "v"(k[14]));
-    else if constexpr (CNT == 16) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]), "v"(k[12]), "v"(k[13]), "v"(k[14]), "v"(k[15]));
+    if constexpr (CNT == 1) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]));
+    else if constexpr (CNT == 2) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]));
+    else if constexpr (CNT == 3) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]));
+    else if constexpr (CNT == 4) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]));
+    else if constexpr (CNT == 5) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]));
+    else if constexpr (CNT == 6) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]));
+    else if constexpr (CNT == 7) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]));
+    else if constexpr (CNT == 8) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]));
+    else if constexpr (CNT == 9) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]));
+    else if constexpr (CNT == 10) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]));
+    else if constexpr (CNT == 11) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]));
+    else if constexpr (CNT == 12) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]), "v"(k[S * 11]));
+    else if constexpr (CNT == 13) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]), "v"(k[S * 11]), "v"(k[S * 12]));
+    else if constexpr (CNT == 14) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]), "v"(k[S * 11]), "v"(k[S * 12]), "v"(k[S * 13]));
+    else if constexpr (CNT == 15) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]), "v"(k[S * 11]), "v"(k[S * 12]), "v"(k[S * 13]), "v"(k[S * 14]));
+    else if constexpr (CNT == 16) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]), "v"(k[S * 11]), "v"(k[S * 12]), "v"(k[S * 13]), "v"(k[S * 14]), "v"(k[S * 15]));
 }
-template <int CNT> TPC_DEV void fmac_row(float& a0, float& a1, float x, const float* k) {
+template <int CNT, int S = 1> TPC_DEV void fmac_row(float& a0, float& a1, float x, const float* k) {
     static_assert(CNT >= 1 && CNT <= 16, "one 16-lane row");
-    if constexpr (CNT == 1) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]));
-    else if constexpr (CNT == 2) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]));
-    else if constexpr (CNT == 3) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]));
-    else if constexpr (CNT == 4) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]));
-    else if constexpr (CNT == 5) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]));
-    else if constexpr (CNT == 6) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]));
-    else if constexpr (CNT == 7) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]));
-    else if constexpr (CNT == 8) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]));
-    else if constexpr (CNT == 9) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]));
-    else if constexpr (CNT == 10) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]));
-    else if constexpr (CNT == 11) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]));
-    else if constexpr (CNT == 12) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]));
-    else if constexpr (CNT == 13) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]), "v"(k[12]));
-    else if constexpr (CNT == 14) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]), "v"(k[12]), "v"(k[13]));
-    else if constexpr (CNT == 15) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]), "v"(k[12]), "v"(k[13]), "v"(k[14]));
-    else if constexpr (CNT == 16) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]), "v"(k[12]), "v"(k[13]), "v"(k[14]), "v"(k[15]));
+    if constexpr (CNT == 1) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]));
+    else if constexpr (CNT == 2) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]));
+    else if constexpr (CNT == 3) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]));
+    else if constexpr (CNT == 4) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]));
+    else if constexpr (CNT == 5) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]));
+    else if constexpr (CNT == 6) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]));
+    else if constexpr (CNT == 7) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]));
+    else if constexpr (CNT == 8) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]));
+    else if constexpr (CNT == 9) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]));
+    else if constexpr (CNT == 10) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]));
+    else if constexpr (CNT == 11) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]));
+    else if constexpr (CNT == 12) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]), "v"(k[S * 11]));
+    else if constexpr (CNT == 13) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]), "v"(k[S * 11]), "v"(k[S * 12]));
+    else if constexpr (CNT == 14) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]), "v"(k[S * 11]), "v"(k[S * 12]), "v"(k[S * 13]));
+    else if constexpr (CNT == 15) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]), "v"(k[S * 11]), "v"(k[S * 12]), "v"(k[S * 13]), "v"(k[S * 14]));
+    else if constexpr (CNT == 16) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]), "v"(k[S * 11]), "v"(k[S * 12]), "v"(k[S * 13]), "v"(k[S * 14]), "v"(k[S * 15]));
+}
+
+// ... up to eight entries of a row starting at lane OFF (the broadcast lane is an immediate operand here)
+template <int CNT, int OFF, int S> TPC_DEV void fmac_row8(double& a0, double& a1, double x, const double* k) {
+    static_assert(CNT >= 1 && CNT <= 8 && OFF + CNT <= 16, "part of one 16-lane row");
+    if constexpr (CNT == 1) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%c4 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "n"(OFF + 0));
+    else if constexpr (CNT == 2) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%c5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%c6 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "n"(OFF + 0), "n"(OFF + 1));
+    else if constexpr (CNT == 3) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%c6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%c7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:%c8 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2));
+    else if constexpr (CNT == 4) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%c7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%c8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:%c9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:%c10 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3));
+    else if constexpr (CNT == 5) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%c8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%c9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:%c10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:%c11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:%c12 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3), "n"(OFF + 4));
+    else if constexpr (CNT == 6) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%c9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%c10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:%c11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:%c12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:%c13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:%c14 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3), "n"(OFF + 4), "n"(OFF + 5));
+    else if constexpr (CNT == 7) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%c10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%c11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:%c12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:%c13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:%c14 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:%c15 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:%c16 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3), "n"(OFF + 4), "n"(OFF + 5), "n"(OFF + 6));
+    else if constexpr (CNT == 8) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%c11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%c12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:%c13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:%c14 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:%c15 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:%c16 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:%c17 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:%c18 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3), "n"(OFF + 4), "n"(OFF + 5), "n"(OFF + 6), "n"(OFF + 7));
+}
+template <int CNT, int OFF, int S> TPC_DEV void fmac_row8(float& a0, float& a1, float x, const float* k) {
+    static_assert(CNT >= 1 && CNT <= 8 && OFF + CNT <= 16, "part of one 16-lane row");
+    if constexpr (CNT == 1) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:%c4 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "n"(OFF + 0));
+    else if constexpr (CNT == 2) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:%c5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:%c6 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "n"(OFF + 0), "n"(OFF + 1));
+    else if constexpr (CNT == 3) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:%c6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:%c7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:%c8 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2));
+    else if constexpr (CNT == 4) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:%c7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:%c8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:%c9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:%c10 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3));
+    else if constexpr (CNT == 5) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:%c8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:%c9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:%c10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:%c11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:%c12 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3), "n"(OFF + 4));
+    else if constexpr (CNT == 6) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:%c9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:%c10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:%c11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:%c12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:%c13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:%c14 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3), "n"(OFF + 4), "n"(OFF + 5));
+    else if constexpr (CNT == 7) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:%c10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:%c11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:%c12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:%c13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:%c14 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:%c15 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:%c16 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3), "n"(OFF + 4), "n"(OFF + 5), "n"(OFF + 6));
+    else if constexpr (CNT == 8) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:%c11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:%c12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:%c13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:%c14 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:%c15 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:%c16 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:%c17 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:%c18 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3), "n"(OFF + 4), "n"(OFF + 5), "n"(OFF + 6), "n"(OFF + 7));
 }
 
 // v_permlane16_swap: (a, b) -> a' = rows (a0, b0, a2, b2), b' = rows (a1, b1, a3, b3);
@@ -567,18 +591,263 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w) {
 #define TPC_WAVES_PER_BLOCK 4
 #endif
 constexpr int kWavesPerBlock = TPC_WAVES_PER_BLOCK;
+// ---- two decision variables per lane ------------------------------------------------------------------------
+// Horizons whose I*H exceeds the wavefront (N = 40 with two inputs: 80 variables).  Lane i owns BOTH inputs of
+// horizon step i: two Hessian rows (4H doubles: 320 registers at H = 40, one wavefront per SIMD), two controls,
+// two of everything per-variable; the gradient is four v_fmac rows per source row (destination input x source
+// input).  dlib scans the variables step by step, input 0 before input 1 (mpc.h:292-308), so the arg-max is the
+// lane's own better variable (input 1 only if strictly larger) and then the same tagged-key maximum over lanes.
+// Same arithmetic, verdicts and loop structure as wave_solve; 0.5 us per iteration against 5.1 us of a LANE lane.
+template <typename T, int H> constexpr bool wave2_row_in_lds() { return 4 * H * (int)sizeof(T) > 960; }   // two rows past 240 registers
+template <typename T, int H, class Model, class Args>
+TPC_DEV void wave2_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s_row1) {
+    constexpr int I = 2, NL = H;
+    // fp64 at H = 40: two rows are 320 registers, VALU operands must be architectural VGPRs (256) -- the second
+    // row lives in LDS as [step][lane][2] (one ds_read_b128 per source step and iteration)
+    constexpr bool R1L = wave2_row_in_lds<T, H>();
+    static_assert(NL <= kWave && NL > 16, "one horizon step per lane, more than one row of lanes");
+    const int lane = threadIdx.x & (kWave - 1);
+    const bool active = lane < NL;
+    const int qi = active ? lane : 0;
+
+    Model m;
+    m.load(g, k);
+    const bool nonfinite = m.nonfinite();
+    const bool badmodel = m.invalid();
+
+    T row[R1L ? 1 : 2][2 * H];
+    T my_qd[2], my_g[2] = {(T)0, (T)0}, my_r[2];
+    if constexpr (R1L) {
+        T tmp[2 * H];
+        hessian_row<T, I, H>(m, active, qi, 1, tmp);
+        my_qd[1] = active ? pick_own<T, 2 * H>(tmp, 2 * qi + 1) : (T)0;
+#pragma unroll
+        for (int l = 0; l < H; ++l) { s_row1[(l * kWave + lane) * 2] = tmp[2 * l]; s_row1[(l * kWave + lane) * 2 + 1] = tmp[2 * l + 1]; }
+        hessian_row<T, I, H>(m, active, qi, 0, row[0]);
+        my_qd[0] = active ? pick_own<T, 2 * H>(row[0], 2 * qi) : (T)0;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            hessian_row<T, I, H>(m, active, qi, e, row[e]);
+            my_qd[e] = active ? pick_own<T, 2 * H>(row[e], 2 * qi + e) : (T)0;
+        }
+    }
+    my_r[0] = active ? m.R(0) : (T)0;
+    my_r[1] = active ? m.R(1) : (T)0;
+    const T lambda = wave_sum_all<NL>((my_qd[0] + my_r[0]) + (my_qd[1] + my_r[1]));
+    auto take_g = [&](int q, T val) { if (q == 2 * qi) my_g[0] = val; if (q == 2 * qi + 1) my_g[1] = val; };
+    if constexpr (std::is_same<Model, CompactModel<T>>::value) linear_term<T, I, H>(m, (T*)nullptr, take_g);
+    else linear_term_fn<T, I, H>(m, [&](int q, T val) { s_w[q] = val; }, [&](int q) { return s_w[q]; }, take_g);
+    if (!active) my_g[0] = my_g[1] = (T)0;
+    const T lo[2] = {m.lo(0), m.lo(1)}, hi[2] = {m.hi(0), m.hi(1)};
+    const T eps = (T)kn.eps;
+    const T my_rqd[2] = {(T)1 / my_qd[0], (T)1 / my_qd[1]};
+    const T inv_lambda = (T)1.0 / lambda;
+    const T sq = tsqrt(lambda);
+    const T beta = (sq - (T)1) / (sq + (T)1);
+
+    T u[2], v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        u[e] = active ? WaveIO<T, I, H, Args>::init_u(g, k, qi, e) : (T)0;
+        v[e] = active ? WaveIO<T, I, H, Args>::init_v(g, k, qi, e) : (T)0;
+    }
+    bool mask_ok = false;
+    if constexpr (Model::kFastStop) {
+        const T mm_max = wave_max<NL>(active ? tmax(tabs(my_g[0]), tabs(my_g[1])) : (T)0);
+        const bool start_inside = u[0] >= lo[0] && u[0] <= hi[0] && u[1] >= lo[1] && u[1] <= hi[1];
+        const bool term_nan = my_g[0] != my_g[0] || my_g[1] != my_g[1];
+        mask_ok = m.fast_stop_ok(mm_max, eps, lambda, H) && __ballot(active && (!start_inside || term_nan)) == 0ull;
+    }
+    constexpr T kHuge = (T)(sizeof(T) == 8 ? 0x1p600 : 0x1p100);
+    const T nlo_h[2] = {-(lo[0] * kHuge), -(lo[1] * kHuge)}, hi_h[2] = {hi[0] * kHuge, hi[1] * kHuge};
+    T huge_r = kHuge;
+    asm volatile("" : "+v"(huge_r));
+
+    // df[e] = sum over source steps l and source inputs e2 of row[e][2 l + e2] * u[e2] of lane l, + R u + g
+    auto gradient_of = [&](const T* uu, T* df) {
+        T x[2][4];
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+            const Swapped<T> p = swap_rows16(uu[e2], uu[e2]);
+            x[e2][0] = p.a; x[e2][1] = p.b; x[e2][2] = p.a; x[e2][3] = p.b;
+            if constexpr (NL > 32) {
+                const Swapped<T> ev = swap_halves(p.a, p.a);
+                const Swapped<T> od = swap_halves(p.b, p.b);
+                x[e2][0] = ev.a; x[e2][2] = ev.b; x[e2][1] = od.a; x[e2][3] = od.b;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < (R1L ? 1 : 2); ++e) {
+            T a0 = my_g[e], a1 = my_r[e] * uu[e];
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                static_for_w<(NL + 15) / 16>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    constexpr int cnt = NL - 16 * r < 16 ? NL - 16 * r : 16;
+                    fmac_row<cnt, 2>(a0, a1, x[e2][r], row[e] + 32 * r + e2);
+                });
+            }
+            df[e] = a0 + a1;
+        }
+        if constexpr (R1L) {
+            T a0 = my_g[1], a1 = my_r[1] * uu[1];
+            static_for_w<(NL + 7) / 8>([&](auto cc) {          // eight source steps at a time
+                constexpr int c8 = decltype(cc)::value;
+                constexpr int cnt = NL - 8 * c8 < 8 ? NL - 8 * c8 : 8;
+                T tmp[16];
+#pragma unroll
+                for (int l = 0; l < cnt; ++l) {
+                    tmp[2 * l] = s_row1[((8 * c8 + l) * kWave + lane) * 2];
+                    tmp[2 * l + 1] = s_row1[((8 * c8 + l) * kWave + lane) * 2 + 1];
+                }
+                fmac_row8<cnt, (8 * c8) % 16, 2>(a0, a1, x[0][(8 * c8) / 16], tmp);
+                fmac_row8<cnt, (8 * c8) % 16, 2>(a0, a1, x[1][(8 * c8) / 16], tmp + 1);
+            });
+            df[1] = a0 + a1;
+        }
+    };
+
+    constexpr int kUnrollCd = 5, kUnrollPg = 4;
+    uint32_t iter = 0;
+    bool capped = true;
+    auto run = [&](auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        auto masked = [&](int e, T uu, T df) -> T {
+            if constexpr (MASK) {
+                const T g_lo = tfma(uu, huge_r, nlo_h[e]), g_hi = tfma(uu, -huge_r, hi_h[e]);
+                return tmax(tmin(df, g_lo), -g_hi);
+            } else {
+                const bool blocked = (uu <= lo[e] && df > (T)0) || (uu >= hi[e] && df < (T)0);   // mpc.h:298-299
+                return (active && !blocked) ? df : (T)0;
+            }
+        };
+        const bool qd_nz[2] = {my_qd[0] != (T)0, my_qd[1] != (T)0};
+        const T my_rqd0[2] = {qd_nz[0] ? my_rqd[0] : (T)0, qd_nz[1] ? my_rqd[1] : (T)0};
+        unsigned long long go_mask = ~0ull;
+        bool go_lane = true, last_take = false;
+        int cnt = 0;
+        const T eps_up = round_up_key(eps);
+        auto cd_step = [&]() {
+            T df[2], c[2], nu[2];
+            gradient_of(u, df);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const T cs = masked(e, u[e], df[e]);
+                c[e] = tabs(cs);
+                if constexpr (!MASK && sizeof(T) == 8) c[e] = c[e] == (T)__builtin_inf() ? (T)1.7976931348623157e308 : c[e];
+                if constexpr (MASK) nu[e] = tmax(tmin(tfma(-my_rqd0[e], df[e], u[e]), hi[e]), lo[e]);
+                else {
+                    nu[e] = put_in_range(lo[e], hi[e], -(df[e] - my_qd[e] * u[e]) * my_rqd[e]);
+                    nu[e] = qd_nz[e] ? nu[e] : u[e];
+                }
+                asm volatile("" : "+v"(nu[e]));
+            }
+            const bool second = c[1] > c[0];              // input 1 only if strictly larger (NaN never wins)
+            const T cbest = second ? c[1] : c[0];
+            bool take_lane;
+            if constexpr (sizeof(T) == 8) {
+                const T key = pack_key_abs(cbest, 63 - lane);
+                const T mk = wave_max<NL>(key);
+                const T thr = raw_max(mk, eps_up);
+                take_lane = key >= thr;
+                go_lane = mk >= eps_up;                                          // mpc.h:310-311
+            } else {
+                const T mx = wave_max<NL>(cbest == cbest ? cbest : (T)0);
+                go_lane = !(mx < eps);
+                const unsigned long long hit = __ballot(cbest == mx);
+                take_lane = go_lane && lane == __ffsll((long long)hit) - 1;
+            }
+            last_take = take_lane && (second ? qd_nz[1] : qd_nz[0]);
+            u[0] = (take_lane && !second) ? nu[0] : u[0];
+            u[1] = (take_lane && second) ? nu[1] : u[1];
+            cnt += go_lane ? 1 : 0;
+        };
+        auto pg_step = [&]() {
+            T df[2], v_new[2], u_new[2];
+            gradient_of(u, df);
+            bool above = false;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const T cs = masked(e, u[e], df[e]);
+                above = above || tabs(cs) >= eps;
+                v_new[e] = clamp3(tfma(-inv_lambda, df[e], u[e]), lo[e], hi[e]);
+                u_new[e] = clamp3(tfma(beta, v_new[e] - v[e], v_new[e]), lo[e], hi[e]);
+            }
+            go_mask = __ballot(above);                                           // mpc.h:310-311: 0 = stop
+            const unsigned long long go_all = any_to_all(go_mask);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                v[e] = lane_select(go_all, v_new[e], v[e]);
+                u[e] = lane_select(go_all, u_new[e], u[e]);
+            }
+            iter += go_mask != 0ull ? 1u : 0u;
+        };
+        const uint32_t cd_end = kn.smo_iters < kn.max_iter ? kn.smo_iters : kn.max_iter;
+        const uint32_t cd_left = cd_end > iter ? cd_end - iter : 0u;
+        for (uint32_t blk = cd_left / kUnrollCd; blk;) {
+#pragma unroll
+            for (int r = 0; r < kUnrollCd; ++r) cd_step();
+            go_mask = __ballot(go_lane);
+            blk = go_mask != 0ull ? blk - 1 : 0u;
+        }
+        for (uint32_t rest = go_mask != 0ull ? cd_left % kUnrollCd : 0u; rest; --rest) cd_step();
+        go_mask = __ballot(go_lane);
+        iter += (uint32_t)__builtin_amdgcn_readfirstlane(cnt);
+        if (go_mask == 0ull) { capped = false; return; }
+        if (iter == kn.smo_iters && __ballot(last_take) != 0ull) { v[0] = u[0]; v[1] = u[1]; }   // mpc.h:330-334
+        const uint32_t pg_left = kn.max_iter > iter ? kn.max_iter - iter : 0u;
+        for (uint32_t blk = pg_left / kUnrollPg; blk;) {
+#pragma unroll
+            for (int r = 0; r < kUnrollPg; ++r) pg_step();
+            blk = go_mask != 0ull ? blk - 1 : 0u;
+        }
+        for (uint32_t rest = go_mask != 0ull ? pg_left % kUnrollPg : 0u; rest; --rest) pg_step();
+        if (go_mask == 0ull) capped = false;
+    };
+    if ((Model::kScreen && nonfinite) || badmodel) capped = false;
+    else if (mask_ok) run(std::true_type{});
+    else run(std::false_type{});
+#pragma unroll
+    for (int e = 0; e < 2; ++e) WaveIO<T, I, H, Args>::write(g, k, active, qi, e, u[e], v[e], iter);
+    if (g.flags) {
+        uint32_t f = 0;
+        if (nonfinite) f |= 0x1u;
+        if (badmodel) f |= 0x4u;
+        if (capped) f |= 0x2u;
+        raise_flags(g.flags, f);
+    }
+}
+
+// one instance by the calling wavefront, whichever layout its size needs
+template <int I, int H> constexpr bool wave_two_per_lane() { return I * H > kWave; }
+// LDS a wavefront needs beside s_w (T elements): the second Hessian row of the two-per-lane fp64 kernels
+template <typename T, int I, int H> constexpr int wave_row_lds() {
+    if constexpr (I * H > kWave) return wave2_row_in_lds<T, H>() ? 2 * H * kWave : 1;
+    else return 1;
+}
+// (one where a wavefront parks a Hessian row in LDS: 40 KB each, and a workgroup's static LDS ends at 64 KB)
+template <typename T, int I, int H> constexpr int waves_per_block() { return wave_row_lds<T, I, H>() > 1 ? 1 : kWavesPerBlock; }
+template <typename T, int I, int H, class Model, class Args>
+TPC_DEV void wave_solve_any(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s_row1) {
+    if constexpr (I * H <= kWave) wave_solve<T, I, H, Model, Args>(g, kn, k, s_w);
+    else wave2_solve<T, H, Model, Args>(g, kn, k, s_w, s_row1);
+}
+
 // Registers: two wavefronts per SIMD is what the work queue keeps resident and what a batch that fits the
 // chip at once amounts to, so that is the occupancy asked for (256 registers): only the 60-variable kernels'
 // set-up code spills under it (a few dozen scratch accesses per instance, none inside a loop).  Asking for
 // more made the set-up code of the smaller kernels spill too: 20 MB of scratch traffic per 4 096 instances.
-template <typename T, int I, int H> constexpr int wave_min_waves() { return 2; }
+template <typename T, int I, int H> constexpr int wave_min_waves() { return wave_two_per_lane<I, H>() ? 1 : 2; }
 template <typename T, int I, int H, class Model, class Args>
-__global__ __launch_bounds__(kWavesPerBlock * kWave) __attribute__((amdgpu_waves_per_eu(wave_min_waves<T, I, H>())))
+__global__ __launch_bounds__((waves_per_block<T, I, H>() * kWave)) __attribute__((amdgpu_waves_per_eu(wave_min_waves<T, I, H>())))
 void wave_kernel(Args g, Knobs kn) {
-    __shared__ __attribute__((aligned(16))) T s_w[kWavesPerBlock][2 * H];
+    constexpr int WPB = waves_per_block<T, I, H>();
+    __shared__ __attribute__((aligned(16))) T s_w[WPB][2 * H];
+    __shared__ __attribute__((aligned(16))) T s_row1[WPB][wave_row_lds<T, I, H>()];
     const int w = threadIdx.x / kWave;
-    const int64_t k = (int64_t)blockIdx.x * kWavesPerBlock + w;
-    if (k < g.n) wave_solve<T, I, H, Model, Args>(g, kn, k, s_w[w]);
+    const int64_t k = (int64_t)blockIdx.x * WPB + w;
+    if (k < g.n) wave_solve_any<T, I, H, Model, Args>(g, kn, k, s_w[w], s_row1[w]);
 }
 
 
@@ -592,7 +861,8 @@ void wave_kernel(Args g, Knobs kn) {
 // Measured (kernel time, 4 096 / 16 384 instances): N = 10: 226 -> 215 / 609 -> 602 us, N = 20: 1 266 -> 909 /
 // 3 455 -> 2 575 us, N = 30: 3 849 -> 2 488 / 11 256 -> 7 164 us.  At N = 4 and 5 an instance is too short for the
 // queue to pay (45 -> 92 us): those keep one launch slot per instance.
-constexpr int kQueueWorkgroupsPerCu = 2;
+constexpr int kQueueWorkgroupsPerCu = 2;   // (one where a lane holds two variables: 380 registers per lane)
+template <int I, int H> constexpr int queue_waves_per_cu() { return (wave_two_per_lane<I, H>() ? 1 : kQueueWorkgroupsPerCu) * kWavesPerBlock; }
 constexpr int kQueueMinHorizon = 10;
 constexpr int kOrderThreads = 1024, kOrderBins = 2048, kOrderPerThread = 32;
 constexpr int64_t kQueueMaxInstances = (int64_t)kOrderThreads * kOrderPerThread;   // larger batches: plain launch
@@ -672,15 +942,17 @@ __global__ __launch_bounds__(kOrderThreads) void wave_order_kernel(Args g, uint3
 // Workgroup b's wavefront w starts on queue position 4 b + w and goes on with order[ticket++] until the queue
 // is empty (the next ticket is fetched before the solve it follows).
 template <typename T, int I, int H, class Model, class Args>
-__global__ __launch_bounds__(kWavesPerBlock * kWave) __attribute__((amdgpu_waves_per_eu(wave_min_waves<T, I, H>())))
+__global__ __launch_bounds__((waves_per_block<T, I, H>() * kWave)) __attribute__((amdgpu_waves_per_eu(wave_min_waves<T, I, H>())))
 void wave_queue_kernel(Args g, Knobs kn, const uint32_t* __restrict__ order, uint32_t* ticket) {
-    __shared__ __attribute__((aligned(16))) T s_w[kWavesPerBlock][2 * H];
+    constexpr int WPB = waves_per_block<T, I, H>();
+    __shared__ __attribute__((aligned(16))) T s_w[WPB][2 * H];
+    __shared__ __attribute__((aligned(16))) T s_row1[WPB][wave_row_lds<T, I, H>()];
     const int w = threadIdx.x / kWave;
-    uint32_t t = blockIdx.x * kWavesPerBlock + w;
+    uint32_t t = blockIdx.x * WPB + w;
     while ((int64_t)t < g.n) {
         uint32_t next = 0;
         if ((threadIdx.x & (kWave - 1)) == 0) next = atomicAdd(ticket, 1u);
-        wave_solve<T, I, H, Model, Args>(g, kn, (int64_t)order[t], s_w[w]);
+        wave_solve_any<T, I, H, Model, Args>(g, kn, (int64_t)order[t], s_w[w], s_row1[w]);
         t = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
     }
 }

@@ -29,22 +29,23 @@ int cu_count() {
 
 template <typename T, int I, class Model, class Args>
 hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
-    if constexpr (I * kH > kWave) {
+    if constexpr (I * kH > 2 * kWave || (I * kH > kWave && I != 2)) {
         return hipErrorNotSupported;
     } else {
         if (a.n <= 0) return hipSuccess;
         if (a.n > 0x7fffffffll) return hipErrorInvalidValue;
         if (ws.ev) (void)hipEventRecord(ws.ev[0], s);
         // more instances than the persistent grid holds: wavefronts over a longest-first queue (mpc_wave.h)
-        const int64_t slots = (int64_t)cu_count() * kQueueWorkgroupsPerCu * kWavesPerBlock;
+        constexpr int wpb = waves_per_block<T, I, kH>();
+        const int64_t slots = (int64_t)cu_count() * queue_waves_per_cu<I, kH>();
         if (kH >= kQueueMinHorizon && a.n > slots && a.n <= kQueueMaxInstances && ws.order) {
             hipLaunchKernelGGL((wave_order_kernel<T, I, kH, Model, Args>), dim3(1), dim3(kOrderThreads), 0, s, a,
                                ws.order, ws.ticket, (uint32_t)slots);
-            hipLaunchKernelGGL((wave_queue_kernel<T, I, kH, Model, Args>), dim3((unsigned)(slots / kWavesPerBlock)),
-                               dim3(kWavesPerBlock * kWave), 0, s, a, k, (const uint32_t*)ws.order, ws.ticket);
+            hipLaunchKernelGGL((wave_queue_kernel<T, I, kH, Model, Args>), dim3((unsigned)(slots / wpb)),
+                               dim3(wpb * kWave), 0, s, a, k, (const uint32_t*)ws.order, ws.ticket);
         } else
-        hipLaunchKernelGGL((wave_kernel<T, I, kH, Model, Args>), dim3((unsigned)((a.n + kWavesPerBlock - 1) / kWavesPerBlock)),
-                           dim3(kWavesPerBlock * kWave), 0, s, a, k);
+        hipLaunchKernelGGL((wave_kernel<T, I, kH, Model, Args>), dim3((unsigned)((a.n + wpb - 1) / wpb)),
+                           dim3(wpb * kWave), 0, s, a, k);
         const hipError_t e = hipGetLastError();
         if (ws.ev) { (void)hipEventRecord(ws.ev[1], s); (void)hipEventRecord(ws.ev[2], s); }
         return e;

@@ -60,11 +60,13 @@ const int32_t* take_hint(tpc_mpc_context* h, int64_t n) {
 // Returns the kernel family to run, or -1 when WAVE was demanded for a shape it cannot take.
 int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n) {
     if (!horizon_specialised(H)) return algo == TPC_MPC_ALGO_WAVE ? -1 : kAlgoGeneric;
-    const bool wave_ok = I * H <= kWave;
+    const bool wave_ok = I * H <= kWave || (I == 2 && H <= kWave);   // (two variables per lane past 64)
     if (algo == TPC_MPC_ALGO_WAVE) return wave_ok ? algo : -1;
     if (algo == TPC_MPC_ALGO_LANE) return algo;
     const int64_t lanes = (int64_t)h->cu_count * 4 * kWave;
-    const int64_t crossover = H >= 20 ? lanes / 2 + 1 : lanes * 7 / 16;
+    // (N = 40 with two inputs: the two-variables-per-lane WAVE kernel against a LANE pass that lasts as long
+    // as its slowest instance, 50 ms whatever the batch: 38.8 against 49.8 ms at 12 288, 51.3 against 49.8 at 16 384)
+    const int64_t crossover = I * H > kWave ? lanes * 15 / 64 : (H >= 20 ? lanes / 2 + 1 : lanes * 7 / 16);
     return (n >= crossover || !wave_ok) ? TPC_MPC_ALGO_LANE : TPC_MPC_ALGO_WAVE;
 }
 

@@ -25,8 +25,8 @@
 // a request (default 20 ms: longer than the cycle of a 50 Hz control loop, short enough that a
 // device-wide synchronisation elsewhere in the process -- which has to wait for every running
 // kernel -- is not held up noticeably), and after a fixed number of polls whatever the clocks say.
-// The host notices (`alive` word) and starts a new one with the next request.  Horizons the WAVE
-// kernel cannot take (2*H > 64), fp32 and TPC_MPC_ALGO_LANE go through an ordinary launch.
+// The host notices (`alive` word) and starts a new one with the next request.  Horizons without a
+// specialised kernel, fp32 and TPC_MPC_ALGO_LANE go through an ordinary launch.
 #include "tpc_mpc_context.h"
 
 #include <chrono>
@@ -70,6 +70,7 @@ TPC_DEV void sys_store(uint64_t* p, uint64_t x) {
 template <int H>
 __global__ __launch_bounds__(64) void one_shot_kernel(const uint64_t* req, uint64_t* mail, uint64_t start_seq, uint64_t idle_ticks) {
     __shared__ __attribute__((aligned(16))) double s_w[2 * H];
+    __shared__ __attribute__((aligned(16))) double s_row1[wave_row_lds<double, 2, H>()];   // (N = 40: a Hessian row, mpc_wave.h)
     const int lane = threadIdx.x;
     uint64_t seen = start_seq;
     uint64_t idle_since = wall_clock64();   // 100 MHz
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(64) void one_shot_kernel(const uint64_t* req, uint6
             const uint64_t its = field(kW_Iters);
             kn.max_iter = (uint32_t)its;
             kn.smo_iters = (uint32_t)(its >> 32);
-            wave_solve<double, 2, H, CompactModel<double>, OneArgs>(g, kn, 0, s_w);
+            wave_solve_any<double, 2, H, CompactModel<double>, OneArgs>(g, kn, 0, s_w, s_row1);
         } else if (lane < 2) {
             sys_store(mail + kW_Front + lane, 0x7ff8000000000badull);   // the host never asks this
         }
@@ -150,7 +151,7 @@ int start_kernel(tpc_mpc_context* h, OneShot* o, int horizon, uint64_t start_seq
     const uint64_t ticks = o->idle_us * 100ull;
     switch (horizon) {
 #define X(hh) case hh: hipLaunchKernelGGL(one_shot_kernel<hh>, dim3(1), dim3(kWave), 0, o->stream, req, dev, start_seq, ticks); break;
-        X(4) X(5) X(10) X(20) X(30)
+        X(4) X(5) X(10) X(20) X(30) X(40)
 #undef X
         default: m[kW_Alive] = 0; return fail(h, TPC_MPC_ERR_BAD_HORIZON, "no resident kernel for horizon %d", horizon);
     }
@@ -280,7 +281,7 @@ int one_shot_solve(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double
     OneShot* o = h->one;
     const int H = p->horizon;   // resident kernels exist for the specialised horizons the WAVE layout can take
     const bool resident_ok = !o->disabled && p->dtype == TPC_MPC_F64 && p->algo != TPC_MPC_ALGO_LANE &&
-                             (H == 4 || H == 5 || H == 10 || H == 20 || H == 30);
+                             (H == 4 || H == 5 || H == 10 || H == 20 || H == 30 || H == 40);
     if (!resident_ok) return launch_path(h, p, v, dy, dphi, front, rear);
     if (!o->stream) HIP_TRY(h, hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking));
     volatile uint64_t* m = mailbox(h);

@@ -19,10 +19,10 @@ sets = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 threads = int(os.environ.get("THREADS", "16"))
 flips = total = 0
-worst = 0.0
+worst = worst_cut = 0.0
 for s_i in range(sets):
-    H = (4, 5, 10, 20, 30)[s_i % 5]
-    m = n if H <= 20 else n // 3
+    H = (4, 5, 10, 20, 30, 40)[s_i % 6]
+    m = n if H <= 20 else (n // 3 if H == 30 else n // 8)
     w = (10 ** rng.uniform(-1, 2), 10 ** rng.uniform(-1, 2), 10 ** rng.uniform(-4, 1), 10 ** rng.uniform(-2, 1.5))
     kind = rng.integers(0, 4)
     if kind == 0:   lo, hi = (-0.384, -0.384), (0.384, 0.384)
@@ -42,10 +42,19 @@ for s_i in range(sets):
     same = it == oit
     err = np.maximum(np.abs(f - of), np.abs(r - orr))
     flips += int((~same).sum()); total += m
-    if same.any():
-        worst = max(worst, float(err[same].max()))
+    # an instance cut off by the iteration cap has not converged: its iteration is still moving, and a
+    # 10 000-step run of an ill-conditioned one amplifies rounding differences exponentially (the error
+    # grows smoothly with the cap: 8e-14 / 4e-12 / 3e-8 / 3e-5 at 100 / 1 000 / 4 000 / 7 000 steps of one
+    # N = 40 set) -- reported apart from the converged ones, which are what the tolerance is about
+    done = same & (oit < cap)
+    cut = same & (oit >= cap)
+    if done.any():
+        worst = max(worst, float(err[done].max()))
+    if cut.any():
+        worst_cut = max(worst_cut, float(err[cut].max()))
     print(f"set {s_i:3d} H={H:2d} n={m:5d} bounds kind {kind} eps {eps:.1e} cap {cap:5d} smo {smo:3d}: "
-          f"iteration counts differ on {int((~same).sum())}, max|du| elsewhere {err[same].max() if same.any() else 0:.2e}", flush=True)
+          f"iteration counts differ on {int((~same).sum())}, max|du| converged {err[done].max() if done.any() else 0:.2e}"
+          f", cut off by the cap ({int(cut.sum())}) {err[cut].max() if cut.any() else 0:.2e}", flush=True)
 print(f"{sets} parameter sets, {total} instances: iteration counts differ on {flips} ({flips / total:.2e}); "
-      f"max |du| among the rest {worst:.2e}")
+      f"max |du| among the converged rest {worst:.2e}, among those cut off by the cap {worst_cut:.2e}")
 sys.exit(1 if worst > 1e-7 or flips > 1e-4 * total else 0)

@@ -66,7 +66,7 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
  *          per wavefront with dynamic refill of finished lanes.  Bit-identical to the reference
  *          arithmetic in fp64; highest throughput on large batches.
  *   AUTO : WAVE below a measured crossover (about 29 000 instances on a 256-CU part, 32 768 from
- *          N = 20, 15 360 at N = 40 with two inputs), LANE from there up. */
+ *          N = 20, 19 456 at N = 40 with two inputs), LANE from there up. */
 typedef enum tpc_mpc_algo { TPC_MPC_ALGO_AUTO = 0, TPC_MPC_ALGO_WAVE = 1, TPC_MPC_ALGO_LANE = 2 } tpc_mpc_algo;
 
 /* Non-fatal per-call flags, OR-ed into *flags_out (may be NULL). */

@@ -677,34 +677,41 @@ TPC_DEV void wave2_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s
                 x[e2][0] = ev.a; x[e2][2] = ev.b; x[e2][1] = od.a; x[e2][3] = od.b;
             }
         }
+        if constexpr (!R1L) {
 #pragma unroll
-        for (int e = 0; e < (R1L ? 1 : 2); ++e) {
-            T a0 = my_g[e], a1 = my_r[e] * uu[e];
+            for (int e = 0; e < 2; ++e) {
+                T a0 = my_g[e], a1 = my_r[e] * uu[e];
 #pragma unroll
-            for (int e2 = 0; e2 < 2; ++e2) {
-                static_for_w<(NL + 15) / 16>([&](auto rc) {
-                    constexpr int r = decltype(rc)::value;
-                    constexpr int cnt = NL - 16 * r < 16 ? NL - 16 * r : 16;
-                    fmac_row<cnt, 2>(a0, a1, x[e2][r], row[e] + 32 * r + e2);
-                });
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    static_for_w<(NL + 15) / 16>([&](auto rc) {
+                        constexpr int r = decltype(rc)::value;
+                        constexpr int cnt = NL - 16 * r < 16 ? NL - 16 * r : 16;
+                        fmac_row<cnt, 2>(a0, a1, x[e2][r], row[e] + 32 * r + e2);
+                    });
+                }
+                df[e] = a0 + a1;
             }
-            df[e] = a0 + a1;
-        }
-        if constexpr (R1L) {
-            T a0 = my_g[1], a1 = my_r[1] * uu[1];
-            static_for_w<(NL + 7) / 8>([&](auto cc) {          // eight source steps at a time
+        } else {
+            // eight source steps at a time: the LDS reads of the second row's entries go out first and the first
+            // row's sixteen multiply-adds for the same steps run under their latency
+            T a0 = my_g[0], a1 = my_r[0] * uu[0], b0 = my_g[1], b1 = my_r[1] * uu[1];
+            static_for_w<(NL + 7) / 8>([&](auto cc) {
                 constexpr int c8 = decltype(cc)::value;
                 constexpr int cnt = NL - 8 * c8 < 8 ? NL - 8 * c8 : 8;
+                constexpr int off = (8 * c8) % 16, r = (8 * c8) / 16;
                 T tmp[16];
 #pragma unroll
                 for (int l = 0; l < cnt; ++l) {
                     tmp[2 * l] = s_row1[((8 * c8 + l) * kWave + lane) * 2];
                     tmp[2 * l + 1] = s_row1[((8 * c8 + l) * kWave + lane) * 2 + 1];
                 }
-                fmac_row8<cnt, (8 * c8) % 16, 2>(a0, a1, x[0][(8 * c8) / 16], tmp);
-                fmac_row8<cnt, (8 * c8) % 16, 2>(a0, a1, x[1][(8 * c8) / 16], tmp + 1);
+                fmac_row8<cnt, off, 2>(a0, a1, x[0][r], row[0] + 16 * c8);
+                fmac_row8<cnt, off, 2>(a0, a1, x[1][r], row[0] + 16 * c8 + 1);
+                fmac_row8<cnt, off, 2>(b0, b1, x[0][r], tmp);
+                fmac_row8<cnt, off, 2>(b0, b1, x[1][r], tmp + 1);
             });
-            df[1] = a0 + a1;
+            df[0] = a0 + a1;
+            df[1] = b0 + b1;
         }
     };
 

@@ -65,8 +65,8 @@ int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n) {
     if (algo == TPC_MPC_ALGO_LANE) return algo;
     const int64_t lanes = (int64_t)h->cu_count * 4 * kWave;
     // (N = 40 with two inputs: the two-variables-per-lane WAVE kernel against a LANE pass that lasts as long
-    // as its slowest instance, 50 ms whatever the batch: 38.8 against 49.8 ms at 12 288, 51.3 against 49.8 at 16 384)
-    const int64_t crossover = I * H > kWave ? lanes * 15 / 64 : (H >= 20 ? lanes / 2 + 1 : lanes * 7 / 16);
+    // as its slowest instance, 50 ms whatever the batch: 42.0 against 50.0 ms at 16 384, 62.4 against 49.9 at 24 576)
+    const int64_t crossover = I * H > kWave ? lanes * 19 / 64 : (H >= 20 ? lanes / 2 + 1 : lanes * 7 / 16);
     return (n >= crossover || !wave_ok) ? TPC_MPC_ALGO_LANE : TPC_MPC_ALGO_WAVE;
 }
 

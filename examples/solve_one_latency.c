@@ -45,8 +45,10 @@ int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 2000;
     tpc_mpc_handle h;
     if (tpc_mpc_create(0, &h) != TPC_MPC_OK) { fprintf(stderr, "tpc_mpc_create: %s\n", tpc_mpc_last_error(NULL)); return 3; }
-    const int hs[] = {4, 10, 20};
-    for (int k = 0; k < 3; ++k) {
+    const int hs[] = {4, 10, 20, 30, 40};
+    for (int k = 0; k < 5; ++k) {
+        const int reps_all = reps;
+        const int reps = hs[k] >= 30 ? (reps_all + 9) / 10 : reps_all;   /* milliseconds per call up there */
         tpc_mpc_params p;
         tpc_mpc_default_params(&p, hs[k]);
         tpc_mpc_set_resident(h, 20000);

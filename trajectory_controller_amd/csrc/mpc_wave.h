@@ -20,7 +20,8 @@
 // Not bit-identical to dlib (the dot product sums in a different order; fused multiply-adds are
 // used), but it takes dlib's decisions on dlib's quantities, so iteration counts agree and the
 // outputs differ by ~1e-14 on the reference workload in fp64 (tests/test_parity_gpu.py).
-// Iteration counts are wave-uniform: no divergence, no refill.  Supports I*H <= 64.
+// Iteration counts are wave-uniform: no divergence, no refill.  Supports I*H <= 64 with one variable per lane
+// (wave_solve) and two inputs up to H = 64 with two per lane (wave2_solve).
 #pragma once
 
 #include <type_traits>
@@ -597,7 +598,8 @@ constexpr int kWavesPerBlock = TPC_WAVES_PER_BLOCK;
 // two of everything per-variable; the gradient is four v_fmac rows per source row (destination input x source
 // input).  dlib scans the variables step by step, input 0 before input 1 (mpc.h:292-308), so the arg-max is the
 // lane's own better variable (input 1 only if strictly larger) and then the same tagged-key maximum over lanes.
-// Same arithmetic, verdicts and loop structure as wave_solve; 0.5 us per iteration against 5.1 us of a LANE lane.
+// Same arithmetic, verdicts and loop structure as wave_solve; 0.5-0.7 us per iteration (fp32 / fp64 at H = 40)
+// against 5.1 us of a LANE lane.
 template <typename T, int H> constexpr bool wave2_row_in_lds() { return 4 * H * (int)sizeof(T) > 960; }   // two rows past 240 registers
 template <typename T, int H, class Model, class Args>
 TPC_DEV void wave2_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s_row1) {
@@ -617,6 +619,16 @@ TPC_DEV void wave2_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s
 
     T row[R1L ? 1 : 2][2 * H];
     T my_qd[2], my_g[2] = {(T)0, (T)0}, my_r[2];
+    // the linear term first: its intermediates (identical in all lanes) are parked in LDS, and where the second
+    // Hessian row goes to LDS they borrow its place before it is written (40 KB per wavefront is a quarter of the
+    // CU's LDS exactly: a vector of its own beside it would cost the CU its fourth wavefront)
+    {
+        T* lt = R1L ? s_row1 : s_w;
+        auto take_g = [&](int q, T val) { if (q == 2 * qi) my_g[0] = val; if (q == 2 * qi + 1) my_g[1] = val; };
+        if constexpr (std::is_same<Model, CompactModel<T>>::value) linear_term<T, I, H>(m, (T*)nullptr, take_g);
+        else linear_term_fn<T, I, H>(m, [&](int q, T val) { lt[q] = val; }, [&](int q) { return lt[q]; }, take_g);
+        if (!active) my_g[0] = my_g[1] = (T)0;
+    }
     if constexpr (R1L) {
         T tmp[2 * H];
         hessian_row<T, I, H>(m, active, qi, 1, tmp);
@@ -635,10 +647,6 @@ TPC_DEV void wave2_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s
     my_r[0] = active ? m.R(0) : (T)0;
     my_r[1] = active ? m.R(1) : (T)0;
     const T lambda = wave_sum_all<NL>((my_qd[0] + my_r[0]) + (my_qd[1] + my_r[1]));
-    auto take_g = [&](int q, T val) { if (q == 2 * qi) my_g[0] = val; if (q == 2 * qi + 1) my_g[1] = val; };
-    if constexpr (std::is_same<Model, CompactModel<T>>::value) linear_term<T, I, H>(m, (T*)nullptr, take_g);
-    else linear_term_fn<T, I, H>(m, [&](int q, T val) { s_w[q] = val; }, [&](int q) { return s_w[q]; }, take_g);
-    if (!active) my_g[0] = my_g[1] = (T)0;
     const T lo[2] = {m.lo(0), m.lo(1)}, hi[2] = {m.hi(0), m.hi(1)};
     const T eps = (T)kn.eps;
     const T my_rqd[2] = {(T)1 / my_qd[0], (T)1 / my_qd[1]};
@@ -833,6 +841,8 @@ template <typename T, int I, int H> constexpr int wave_row_lds() {
     if constexpr (I * H > kWave) return wave2_row_in_lds<T, H>() ? 2 * H * kWave : 1;
     else return 1;
 }
+// LDS for the linear term's intermediates (T elements): none of its own where the row's place is borrowed
+template <typename T, int I, int H> constexpr int wave_lt_lds() { return wave_row_lds<T, I, H>() > 1 ? 1 : 2 * H; }
 // (one where a wavefront parks a Hessian row in LDS: 40 KB each, and a workgroup's static LDS ends at 64 KB)
 template <typename T, int I, int H> constexpr int waves_per_block() { return wave_row_lds<T, I, H>() > 1 ? 1 : kWavesPerBlock; }
 template <typename T, int I, int H, class Model, class Args>
@@ -850,7 +860,7 @@ template <typename T, int I, int H, class Model, class Args>
 __global__ __launch_bounds__((waves_per_block<T, I, H>() * kWave)) __attribute__((amdgpu_waves_per_eu(wave_min_waves<T, I, H>())))
 void wave_kernel(Args g, Knobs kn) {
     constexpr int WPB = waves_per_block<T, I, H>();
-    __shared__ __attribute__((aligned(16))) T s_w[WPB][2 * H];
+    __shared__ __attribute__((aligned(16))) T s_w[WPB][wave_lt_lds<T, I, H>()];
     __shared__ __attribute__((aligned(16))) T s_row1[WPB][wave_row_lds<T, I, H>()];
     const int w = threadIdx.x / kWave;
     const int64_t k = (int64_t)blockIdx.x * WPB + w;
@@ -952,7 +962,7 @@ template <typename T, int I, int H, class Model, class Args>
 __global__ __launch_bounds__((waves_per_block<T, I, H>() * kWave)) __attribute__((amdgpu_waves_per_eu(wave_min_waves<T, I, H>())))
 void wave_queue_kernel(Args g, Knobs kn, const uint32_t* __restrict__ order, uint32_t* ticket) {
     constexpr int WPB = waves_per_block<T, I, H>();
-    __shared__ __attribute__((aligned(16))) T s_w[WPB][2 * H];
+    __shared__ __attribute__((aligned(16))) T s_w[WPB][wave_lt_lds<T, I, H>()];
     __shared__ __attribute__((aligned(16))) T s_row1[WPB][wave_row_lds<T, I, H>()];
     const int w = threadIdx.x / kWave;
     uint32_t t = blockIdx.x * WPB + w;

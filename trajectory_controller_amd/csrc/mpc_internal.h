@@ -55,7 +55,7 @@ struct GeneralArgs {
 // phase to the projected-gradient phase, and the work-queue ticket).
 struct Workspace {
     void* state;        // per-instance records, LaneRec<T,H>::kLen elements each
-    uint32_t* ticket;   // 1 word
+    uint32_t* ticket;   // LANE: 1 word; WAVE queue: kQueueTickets words, kQueueTicketStride apart
     unsigned long long* stats;   // [3]: PG wave-iterations, refill blocks, exact-stop-test flag (zeroed per launch)
     int64_t capacity_bytes;
     // longest-first queue (mpc_sort.hip): keys written by the CD kernel, ordered into order[]
@@ -66,6 +66,13 @@ struct Workspace {
     // (ev[0] .. ev[1] first kernel, ev[1] .. ev[2] second kernel); null when profiling is off
     hipEvent_t* ev;
 };
+
+// WAVE work queue (mpc_wave.h): the dynamic part of the queue is dealt out through kQueueTickets counters on
+// cache lines of their own -- returning atomics on one address complete at ~30 M/s on this chip, whatever the
+// number of wavefronts asking
+constexpr int kQueueTickets = 16;
+constexpr int kQueueTicketStride = 64;   // in words: 256 B
+constexpr int64_t kQueueTicketBytes = (int64_t)kQueueTickets * kQueueTicketStride * 4;
 
 // mpc_generic.hip: the any-horizon fallback (run-time H, per-instance arrays in a global workspace)
 constexpr int kAlgoGeneric = 3;   // internal kernel-family code next to TPC_MPC_ALGO_WAVE / _LANE

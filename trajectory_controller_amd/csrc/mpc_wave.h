@@ -346,10 +346,15 @@ template <typename T, int LEN> TPC_DEV T pick_own(const T* a, int idx) {
     return lvl[0];
 }
 
+struct NoHook { TPC_DEV void operator()() const {} };
+
 // One instance solved by the calling wavefront (all 64 lanes must call it together).
 // s_w: 2*H values of LDS private to the wavefront, 16-byte aligned.
-template <typename T, int I, int H, class Model, class Args>
-TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w) {
+// before_loops(): called once, after the set-up has consumed everything it loads and before the iteration loops --
+// the place for a memory operation whose result is wanted after the solve (the work queue's next ticket: the
+// wait counter is in-order, so issued any earlier it is waited for together with the model's own loads).
+template <typename T, int I, int H, class Model, class Args, class Hook = NoHook>
+TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, Hook before_loops = Hook{}) {
     constexpr int N = I * H;
     static_assert(N <= kWave, "WAVE kernel: one variable per lane");
     const int lane = threadIdx.x & (kWave - 1);
@@ -573,6 +578,7 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w) {
         for (uint32_t rest = go_mask != 0ull ? pg_left % kUnrollPg : 0u; rest; --rest) pg_step();
         if (go_mask == 0ull) capped = false;
     };
+    before_loops();
     if ((Model::kScreen && nonfinite) || badmodel) capped = false;
     else if (mask_ok) run(std::true_type{});
     else run(std::false_type{});
@@ -601,8 +607,8 @@ constexpr int kWavesPerBlock = TPC_WAVES_PER_BLOCK;
 // Same arithmetic, verdicts and loop structure as wave_solve; 0.5-0.7 us per iteration (fp32 / fp64 at H = 40)
 // against 5.1 us of a LANE lane.
 template <typename T, int H> constexpr bool wave2_row_in_lds() { return 4 * H * (int)sizeof(T) > 960; }   // two rows past 240 registers
-template <typename T, int H, class Model, class Args>
-TPC_DEV void wave2_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s_row1) {
+template <typename T, int H, class Model, class Args, class Hook = NoHook>
+TPC_DEV void wave2_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s_row1, Hook before_loops = Hook{}) {
     constexpr int I = 2, NL = H;
     // fp64 at H = 40: two rows are 320 registers, VALU operands must be architectural VGPRs (256) -- the second
     // row lives in LDS as [step][lane][2] (one ds_read_b128 per source step and iteration)
@@ -723,7 +729,17 @@ TPC_DEV void wave2_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s
         }
     };
 
-    constexpr int kUnrollCd = 5, kUnrollPg = 4;
+    // (blocks of 4, not 5, coordinate-descent steps: with 5 the work-queue kernel's fp64 build ran out of AGPRs and
+    // kept half of one Hessian entry in scratch, reloaded inside the loops -- and that build returned wrong controls
+    // for one instance in nine while the scratch-free builds of the same source agree with dlib to 1e-13.  The
+    // cause was not found; tests/test_build_artifacts.py refuses a two-per-lane kernel that uses scratch.)
+#ifndef TPC_WAVE2_UNROLL_CD
+#define TPC_WAVE2_UNROLL_CD 4
+#endif
+#ifndef TPC_WAVE2_UNROLL_PG
+#define TPC_WAVE2_UNROLL_PG 4
+#endif
+    constexpr int kUnrollCd = TPC_WAVE2_UNROLL_CD, kUnrollPg = TPC_WAVE2_UNROLL_PG;
     uint32_t iter = 0;
     bool capped = true;
     auto run = [&](auto mask_tag) {
@@ -820,6 +836,7 @@ TPC_DEV void wave2_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s
         for (uint32_t rest = go_mask != 0ull ? pg_left % kUnrollPg : 0u; rest; --rest) pg_step();
         if (go_mask == 0ull) capped = false;
     };
+    before_loops();
     if ((Model::kScreen && nonfinite) || badmodel) capped = false;
     else if (mask_ok) run(std::true_type{});
     else run(std::false_type{});
@@ -845,10 +862,10 @@ template <typename T, int I, int H> constexpr int wave_row_lds() {
 template <typename T, int I, int H> constexpr int wave_lt_lds() { return wave_row_lds<T, I, H>() > 1 ? 1 : 2 * H; }
 // (one where a wavefront parks a Hessian row in LDS: 40 KB each, and a workgroup's static LDS ends at 64 KB)
 template <typename T, int I, int H> constexpr int waves_per_block() { return wave_row_lds<T, I, H>() > 1 ? 1 : kWavesPerBlock; }
-template <typename T, int I, int H, class Model, class Args>
-TPC_DEV void wave_solve_any(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s_row1) {
-    if constexpr (I * H <= kWave) wave_solve<T, I, H, Model, Args>(g, kn, k, s_w);
-    else wave2_solve<T, H, Model, Args>(g, kn, k, s_w, s_row1);
+template <typename T, int I, int H, class Model, class Args, class Hook = NoHook>
+TPC_DEV void wave_solve_any(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s_row1, Hook before_loops = Hook{}) {
+    if constexpr (I * H <= kWave) wave_solve<T, I, H, Model, Args, Hook>(g, kn, k, s_w, before_loops);
+    else wave2_solve<T, H, Model, Args, Hook>(g, kn, k, s_w, s_row1, before_loops);
 }
 
 // Registers: two wavefronts per SIMD is what the work queue keeps resident and what a batch that fits the
@@ -880,22 +897,26 @@ void wave_kernel(Args g, Knobs kn) {
 // queue to pay (45 -> 92 us): those keep one launch slot per instance.
 constexpr int kQueueWorkgroupsPerCu = 2;   // (one where a lane holds two variables: 380 registers per lane)
 template <int I, int H> constexpr int queue_waves_per_cu() { return (wave_two_per_lane<I, H>() ? 1 : kQueueWorkgroupsPerCu) * kWavesPerBlock; }
-constexpr int kQueueMinHorizon = 10;
+#ifndef TPC_QUEUE_MIN_H
+#define TPC_QUEUE_MIN_H 10
+#endif
+constexpr int kQueueMinHorizon = TPC_QUEUE_MIN_H;
 constexpr int kOrderThreads = 1024, kOrderBins = 2048, kOrderPerThread = 32;
 constexpr int64_t kQueueMaxInstances = (int64_t)kOrderThreads * kOrderPerThread;   // larger batches: plain launch
 
 // One workgroup: a key per instance (kept in registers) -> counting sort over kOrderBins linear bins of the
-// key range -> order[] (descending), ticket = first queue position nobody starts on.  Positions inside a bin
+// key range -> order[] (descending); the queue's ticket counters are zeroed here.  Positions inside a bin
 // come from atomics and are not reproducible; they decide which wavefront solves which instance, never a result.
 template <typename T, int I, int H, class Model, class Args>
 __global__ __launch_bounds__(kOrderThreads) void wave_order_kernel(Args g, uint32_t* __restrict__ order,
-                                                                   uint32_t* __restrict__ ticket, uint32_t first_ticket) {
+                                                                   uint32_t* __restrict__ tickets) {
     __shared__ uint32_t bins[kOrderBins];
     __shared__ uint32_t wave_sum[kOrderThreads / kWave];
     __shared__ uint32_t kmin, kmax;
     const int t = threadIdx.x;
     const int n = (int)g.n;
-    if (t == 0) { kmin = 0xffffffffu; kmax = 0u; *ticket = first_ticket; }
+    if (t == 0) { kmin = 0xffffffffu; kmax = 0u; }
+    if (t < kQueueTickets) tickets[t * kQueueTicketStride] = 0u;
     for (int b = t; b < kOrderBins; b += kOrderThreads) bins[b] = 0u;
     uint32_t key[kOrderPerThread];
     uint32_t lo = 0xffffffffu, hi = 0u;
@@ -956,21 +977,39 @@ __global__ __launch_bounds__(kOrderThreads) void wave_order_kernel(Args g, uint3
         if (j * kOrderThreads + t < n) order[atomicAdd(&bins[bin_of(key[j])], 1u)] = (uint32_t)(j * kOrderThreads + t);
 }
 
-// Workgroup b's wavefront w starts on queue position 4 b + w and goes on with order[ticket++] until the queue
-// is empty (the next ticket is fetched before the solve it follows).
+// W persistent wavefronts over the queue.  The first two rounds are static: wavefront w takes position w, then
+// position 2W-1-w -- the longest instance is paired with the shortest of the second round, and so on inwards.
+// What lies beyond 2W is dealt out dynamically, through kQueueTickets counters instead of one: returning atomics
+// on ONE address complete at about one per 30-38 ns on this chip whatever the number of waves asking (measured:
+// 32 768 empty solves with one ticket each took 1.1 ms, and so did 32 768 real N = 10 solves), which capped the
+// queue at ~30 M instances/s and opened every launch with a 2W-deep burst.  Counter j (wavefronts w = j mod
+// kQueueTickets) hands out positions 2W + j, 2W + j + kQueueTickets, ...: the sub-queues interleave, so each
+// is longest-first with the same mix and they run dry within an instance or two of each other.  A wavefront
+// asks for its next position when the set-up of the current instance is done, just before its iteration loops
+// (see wave_solve: any earlier and the in-order wait counter makes the set-up's own loads wait for the ticket).
 template <typename T, int I, int H, class Model, class Args>
 __global__ __launch_bounds__((waves_per_block<T, I, H>() * kWave)) __attribute__((amdgpu_waves_per_eu(wave_min_waves<T, I, H>())))
-void wave_queue_kernel(Args g, Knobs kn, const uint32_t* __restrict__ order, uint32_t* ticket) {
+void wave_queue_kernel(Args g, Knobs kn, const uint32_t* __restrict__ order, uint32_t* tickets) {
     constexpr int WPB = waves_per_block<T, I, H>();
     __shared__ __attribute__((aligned(16))) T s_w[WPB][wave_lt_lds<T, I, H>()];
     __shared__ __attribute__((aligned(16))) T s_row1[WPB][wave_row_lds<T, I, H>()];
     const int w = threadIdx.x / kWave;
-    uint32_t t = blockIdx.x * WPB + w;
-    while ((int64_t)t < g.n) {
-        uint32_t next = 0;
-        if ((threadIdx.x & (kWave - 1)) == 0) next = atomicAdd(ticket, 1u);
-        wave_solve_any<T, I, H, Model, Args>(g, kn, (int64_t)order[t], s_w[w], s_row1[w]);
-        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+    const uint32_t n = (uint32_t)g.n;
+    const uint32_t waves = gridDim.x * WPB, wid = blockIdx.x * WPB + w;
+    const uint32_t sub = wid % kQueueTickets;
+    uint32_t* my_ticket = tickets + sub * kQueueTicketStride;
+    uint32_t t = wid;
+    bool first = true;
+    while (t < n) {
+        const bool dynamic = !first && 2u * waves < n;
+        uint32_t drawn = 0;   // (turned into a position only after the solve: its first use is where the wait goes)
+        auto ask = [&]() {
+            if (dynamic && (threadIdx.x & (kWave - 1)) == 0) drawn = atomicAdd(my_ticket, 1u);
+        };
+        wave_solve_any<T, I, H, Model, Args>(g, kn, (int64_t)order[t], s_w[w], s_row1[w], ask);
+        const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)drawn);
+        t = first ? 2u * waves - 1u - wid : (dynamic ? 2u * waves + d * kQueueTickets + sub : n);
+        first = false;
     }
 }
 

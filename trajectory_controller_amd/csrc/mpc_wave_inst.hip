@@ -38,14 +38,23 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
         // more instances than the persistent grid holds: wavefronts over a longest-first queue (mpc_wave.h)
         constexpr int wpb = waves_per_block<T, I, kH>();
         const int64_t slots = (int64_t)cu_count() * queue_waves_per_cu<I, kH>();
-        if (kH >= kQueueMinHorizon && a.n > slots && a.n <= kQueueMaxInstances && ws.order) {
-            hipLaunchKernelGGL((wave_order_kernel<T, I, kH, Model, Args>), dim3(1), dim3(kOrderThreads), 0, s, a,
-                               ws.order, ws.ticket, (uint32_t)slots);
-            hipLaunchKernelGGL((wave_queue_kernel<T, I, kH, Model, Args>), dim3((unsigned)(slots / wpb)),
-                               dim3(wpb * kWave), 0, s, a, k, (const uint32_t*)ws.order, ws.ticket);
-        } else
-        hipLaunchKernelGGL((wave_kernel<T, I, kH, Model, Args>), dim3((unsigned)((a.n + wpb - 1) / wpb)),
-                           dim3(wpb * kWave), 0, s, a, k);
+        // (not for the general form with two variables per lane: its fp64 queue kernel -- the model's registers on
+        // top of two Hessian rows -- spills into scratch inside the loops; the plain launch below does not)
+        constexpr bool queue_ok = kH >= kQueueMinHorizon &&
+                                  !(wave_two_per_lane<I, kH>() && !std::is_same<Model, CompactModel<T>>::value);
+        bool queued = false;
+        if constexpr (queue_ok) {
+            if (a.n > slots && a.n <= kQueueMaxInstances && ws.order) {
+                hipLaunchKernelGGL((wave_order_kernel<T, I, kH, Model, Args>), dim3(1), dim3(kOrderThreads), 0, s, a,
+                                   ws.order, ws.ticket);
+                hipLaunchKernelGGL((wave_queue_kernel<T, I, kH, Model, Args>), dim3((unsigned)(slots / wpb)),
+                                   dim3(wpb * kWave), 0, s, a, k, (const uint32_t*)ws.order, ws.ticket);
+                queued = true;
+            }
+        }
+        if (!queued)
+            hipLaunchKernelGGL((wave_kernel<T, I, kH, Model, Args>), dim3((unsigned)((a.n + wpb - 1) / wpb)),
+                               dim3(wpb * kWave), 0, s, a, k);
         const hipError_t e = hipGetLastError();
         if (ws.ev) { (void)hipEventRecord(ws.ev[1], s); (void)hipEventRecord(ws.ev[2], s); }
         return e;

@@ -129,9 +129,11 @@ int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n,
     }
     if (algo == TPC_MPC_ALGO_WAVE) {
         // order[] of the longest-first queue (mpc_wave.h); batches that fit the chip at once do not use it
-        int rc = ensure(h, &h->ws_state, &h->ws_bytes, pad256(n * 4));
+        // + its ticket words, one cache line each (kQueueTickets x 256 B)
+        int rc = ensure(h, &h->ws_state, &h->ws_bytes, pad256(n * 4) + kQueueTicketBytes);
         if (rc) return rc;
         ws->order = (uint32_t*)h->ws_state;
+        ws->ticket = (uint32_t*)((char*)h->ws_state + pad256(n * 4));
         ws->capacity_bytes = h->ws_bytes;
     }
     if (algo == TPC_MPC_ALGO_LANE) {

@@ -765,6 +765,25 @@ def test_wave_queue_vs_oracle(torch_cuda, oracle, H):
             assert np.abs(gu0.T - u0).max() <= WAVE_ATOL, I
 
 
+def test_wave_queue_boundaries(torch_cuda, oracle):
+    """Batch sizes at every seam of the WAVE work queue (W persistent wavefronts = 8 per CU): the first size that
+    uses it, the end of the two static rounds (2W), the first dynamic positions and the seams between the 16
+    ticket counters they are dealt from, and the largest batch the queue takes.  Every instance must be solved
+    exactly once: iteration counts equal the oracle's and outputs within the family's tolerance."""
+    import torch
+    from trajectory_controller_amd.synth import compact_inputs
+    H = 10
+    W = 8 * torch.cuda.get_device_properties(0).multi_processor_count
+    sizes = sorted({W + 1, 2 * W - 1, 2 * W, 2 * W + 1, 2 * W + 15, 2 * W + 16, 2 * W + 17, 2 * W + 1000, 32767, 32768} - {0})
+    v, dy, dphi = compact_inputs(H, max(sizes), first=77000)
+    of, orr, oit = oracle.solve_compact(H, v, dy, dphi, nthreads=8)
+    with _solver(H, "wave") as s:
+        for n in sizes:
+            f, r, it = s.solve_batch_compact(v[:n], dy[:n], dphi[:n], want_iters=True)
+            assert np.array_equal(it, oit[:n]), n
+            assert max(np.abs(f - of[:n]).max(), np.abs(r - orr[:n]).max()) <= WAVE_ATOL, n
+
+
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("H", [1, 2, 3, 7, 8, 15, 25, 33, 64])
 def test_generic_horizon_vs_oracle(torch_cuda, oracle, oracle32, H, dtype):

@@ -872,7 +872,10 @@ TPC_DEV void wave_solve_any(const Args& g, const Knobs& kn, int64_t k, T* s_w, T
 // chip at once amounts to, so that is the occupancy asked for (256 registers): only the 60-variable kernels'
 // set-up code spills under it (a few dozen scratch accesses per instance, none inside a loop).  Asking for
 // more made the set-up code of the smaller kernels spill too: 20 MB of scratch traffic per 4 096 instances.
-template <typename T, int I, int H> constexpr int wave_min_waves() { return wave_two_per_lane<I, H>() ? 1 : 2; }
+#ifndef TPC_WAVE_MIN_WAVES
+#define TPC_WAVE_MIN_WAVES 2
+#endif
+template <typename T, int I, int H> constexpr int wave_min_waves() { return wave_two_per_lane<I, H>() ? 1 : TPC_WAVE_MIN_WAVES; }
 template <typename T, int I, int H, class Model, class Args>
 __global__ __launch_bounds__((waves_per_block<T, I, H>() * kWave)) __attribute__((amdgpu_waves_per_eu(wave_min_waves<T, I, H>())))
 void wave_kernel(Args g, Knobs kn) {
@@ -895,7 +898,10 @@ void wave_kernel(Args g, Knobs kn) {
 // Measured (kernel time, 4 096 / 16 384 instances): N = 10: 226 -> 215 / 609 -> 602 us, N = 20: 1 266 -> 909 /
 // 3 455 -> 2 575 us, N = 30: 3 849 -> 2 488 / 11 256 -> 7 164 us.  At N = 4 and 5 an instance is too short for the
 // queue to pay (45 -> 92 us): those keep one launch slot per instance.
-constexpr int kQueueWorkgroupsPerCu = 2;   // (one where a lane holds two variables: 380 registers per lane)
+#ifndef TPC_QUEUE_WG_PER_CU
+#define TPC_QUEUE_WG_PER_CU 2
+#endif
+constexpr int kQueueWorkgroupsPerCu = TPC_QUEUE_WG_PER_CU;   // (one where a lane holds two variables: 380 registers per lane)
 template <int I, int H> constexpr int queue_waves_per_cu() { return (wave_two_per_lane<I, H>() ? 1 : kQueueWorkgroupsPerCu) * kWavesPerBlock; }
 #ifndef TPC_QUEUE_MIN_H
 #define TPC_QUEUE_MIN_H 10

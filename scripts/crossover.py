@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from trajectory_controller_amd import MpcSolver
 from trajectory_controller_amd.synth import compact_inputs
-for H in (4, 10, 20):
+for H in [int(a) for a in sys.argv[1:]] or [4, 10, 20]:
     for n in (2048, 4096, 8192, 12288, 16384, 24576, 32768, 49152, 65536):
         v, dy, dphi = (torch.from_numpy(a).cuda() for a in compact_inputs(H, n))
         row = []

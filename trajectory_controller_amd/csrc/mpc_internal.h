@@ -73,6 +73,7 @@ struct Workspace {
 constexpr int kQueueTickets = 16;
 constexpr int kQueueTicketStride = 64;   // in words: 256 B
 constexpr int64_t kQueueTicketBytes = (int64_t)kQueueTickets * kQueueTicketStride * 4;
+constexpr int64_t kWaveQueueMaxInstances = 32768;   // what one wave_order_kernel workgroup sorts (mpc_wave.h)
 
 // mpc_generic.hip: the any-horizon fallback (run-time H, per-instance arrays in a global workspace)
 constexpr int kAlgoGeneric = 3;   // internal kernel-family code next to TPC_MPC_ALGO_WAVE / _LANE

@@ -253,11 +253,12 @@ template <typename T, int I, int H, class Args> struct WaveIO;
 template <typename T, int I, int H> struct WaveIO<T, I, H, CompactArgs> {
     static TPC_DEV T init_u(const CompactArgs&, int64_t, int, int) { return (T)0; }
     static TPC_DEV T init_v(const CompactArgs&, int64_t, int, int) { return (T)0; }
-    static TPC_DEV void write(const CompactArgs& g, int64_t k, bool active, int qi, int qj, T u, T, uint32_t it) {
+    static TPC_DEV void write(const CompactArgs& g, int64_t k, bool active, int qi, int qj, T u, T, uint32_t it,
+                              bool reporter = (threadIdx.x & 63) == 0) {
         if (active && qi == 0) {
             if (qj == 0) ((T*)g.front)[k] = u; else ((T*)g.rear)[k] = u;
         }
-        if (g.iters && (threadIdx.x & 63) == 0) g.iters[k] = (int32_t)it;
+        if (g.iters && reporter) g.iters[k] = (int32_t)it;
     }
 };
 template <int I, int H> struct WaveIO<double, I, H, OneArgs> {
@@ -277,13 +278,14 @@ template <typename T, int I, int H> struct WaveIO<T, I, H, GeneralArgs> {
     static TPC_DEV T init_v(const GeneralArgs& g, int64_t k, int qi, int qj) {
         return g.v ? ((const T*)g.v)[(int64_t)(qi * I + qj) * g.ld + k] : (T)0;
     }
-    static TPC_DEV void write(const GeneralArgs& g, int64_t k, bool active, int qi, int qj, T u, T v, uint32_t it) {
+    static TPC_DEV void write(const GeneralArgs& g, int64_t k, bool active, int qi, int qj, T u, T v, uint32_t it,
+                              bool reporter = (threadIdx.x & 63) == 0) {
         if (active) {
             if (qi == 0) ((T*)g.u0)[(int64_t)qj * g.ld + k] = u;
             if (g.controls) ((T*)g.controls)[(int64_t)(qi * I + qj) * g.ld + k] = u;
             if (g.v) ((T*)g.v)[(int64_t)(qi * I + qj) * g.ld + k] = v;
         }
-        if (g.iters && (threadIdx.x & 63) == 0) g.iters[k] = (int32_t)it;
+        if (g.iters && reporter) g.iters[k] = (int32_t)it;
     }
 };
 
@@ -587,6 +589,225 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, Hook 
         uint32_t f = 0;
         if (nonfinite) f |= 0x1u;
         if (badmodel) f |= 0x4u;
+        if (capped) f |= 0x2u;
+        raise_flags(g.flags, f);
+    }
+}
+
+// ---- two instances per wavefront ----------------------------------------------------------------------------
+// One wavefront's instruction issue fills a SIMD (one instruction per 4 cycles), so past two wavefronts per SIMD a
+// WAVE batch runs at the instruction rate of one instance per SIMD -- with 20 of 64 lanes in use at N = 10.  Up to
+// 32 variables an instance fits one half of the wavefront (two 16-lane rows), and everything the iteration moves
+// between lanes already stays inside a half: the DPP row broadcast, v_permlane16_swap (rows 0<->1, 2<->3), the
+// butterfly sums.  wave_pair_solve runs instance k0 in lanes 0..31 and k1 in lanes 32..63 through the same
+// instructions: same arithmetic per instance as wave_solve (the row-local and half-local reductions associate
+// exactly as the one-instance ones do for N <= 32), every verdict per half.  The two instances stop at different
+// iterations; the one that stopped keeps its state (a stopped state reproduces its stop verdict), so the pair costs
+// max(iterations) -- the work queue hands out neighbours of the longest-first order, which are alike.
+// k1 < 0: no second instance.  fp64 only (the fp32 arg-max is a two-step wavefront reduction).
+TPC_DEV unsigned long long halves_any_to_all(unsigned long long mask) {   // per 32-lane half: any bit set -> all ones
+    unsigned lo, hi;
+    asm("s_cmp_lg_u32 %1, 0\n\ts_cselect_b32 %0, -1, 0" : "=s"(lo) : "s"((unsigned)mask) : "scc");
+    asm("s_cmp_lg_u32 %1, 0\n\ts_cselect_b32 %0, -1, 0" : "=s"(hi) : "s"((unsigned)(mask >> 32)) : "scc");
+    return ((unsigned long long)hi << 32) | lo;
+}
+TPC_DEV uint32_t add_lane_bit(uint32_t x, unsigned long long mask) {   // x + (bit of this lane in mask): one v_addc
+    uint32_t r;
+    unsigned long long carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r), "=s"(carry_out) : "v"(x), "s"(mask));
+    return r;
+}
+// max over the lanes of the caller's 32-lane half, left in every lane of it (x >= 0; lanes past N hold 0)
+template <int N> TPC_DEV double half_max_all(double x) {
+    if constexpr (N <= 16) return row_max_all<N>(x);
+    else {
+        x = row_max_all<16>(x);
+        const Swapped<double> p = swap_rows16(x, x);
+        return raw_max(p.a, p.b);
+    }
+}
+
+template <typename T, int I, int H, class Model, class Args, class Hook = NoHook>
+TPC_DEV void wave_pair_solve(const Args& g, const Knobs& kn, int64_t k0, int64_t k1, T* s_w, Hook before_loops = Hook{}) {
+    static_assert(sizeof(T) == 8, "fp64 only");
+    constexpr int N = I * H, L = kWave / 2;
+    static_assert(N <= L, "one instance per 32-lane half");
+    const int lane = threadIdx.x & (kWave - 1);
+    const int half = lane / L, ll = lane % L;
+    const bool present = half == 0 || k1 >= 0;
+    const int64_t k = (half == 0 || k1 < 0) ? k0 : k1;      // (a missing second instance shadows the first: valid addresses)
+    const bool owns = ll < N && present;                     // this lane holds a variable of an instance
+    const int qi = owns ? ll / I : 0, qj = owns ? ll % I : 0;
+    const int slot = 2 * qi + qj;
+    T* lt = s_w + half * 2 * H;
+
+    Model m;
+    m.load(g, k);
+    const bool nonfinite = m.nonfinite();
+    const bool badmodel = m.invalid();
+    const bool alive = present && !((Model::kScreen && nonfinite) || badmodel);   // the half iterates
+    const bool active = owns && alive;
+    const unsigned long long alive_mask = __ballot(alive);
+
+    T row[2 * H];
+    T my_qd = (T)0, my_g = (T)0;
+    hessian_row<T, I, H>(m, active, qi, qj, row);
+    if (!active) {   // a half that does not iterate (or an idle lane) must not feed NaNs of a broken model into its verdicts
+#pragma unroll
+        for (int q = 0; q < 2 * H; ++q) row[q] = (T)0;
+    }
+    my_qd = active ? pick_own<T, 2 * H>(row, slot) : (T)0;
+    T kq_one[I == 2 ? 1 : N];
+    const T* kq = row;
+    if constexpr (I != 2) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) kq_one[q] = row[2 * (q / I) + (q % I)];
+        kq = kq_one;
+    }
+    const T my_r = active ? m.R(qj) : (T)0;
+    const T lambda = wave_sum_all<N>(my_qd + my_r);   // (N <= 32: the butterfly stays inside the half)
+    auto take_g = [&](int q, T val) { if (q == slot) my_g = val; };
+    if constexpr (std::is_same<Model, CompactModel<T>>::value) {
+        linear_term<T, I, H>(m, (T*)nullptr, take_g);
+    } else if constexpr (H <= 10) {
+        T w[2 * H];
+        linear_term<T, I, H>(m, w, take_g);
+    } else {
+        linear_term_fn<T, I, H>(m, [&](int q, T val) { lt[q] = val; }, [&](int q) { return lt[q]; }, take_g);
+    }
+    if (!active) my_g = (T)0;
+    const T lo = m.lo(qj), hi = m.hi(qj);
+    const T eps = (T)kn.eps;
+    const T my_rqd = (T)1 / my_qd;
+    const T inv_lambda = (T)1.0 / lambda;
+    const T sq = tsqrt(lambda);
+    const T beta = (sq - (T)1) / (sq + (T)1);
+
+    T u = owns ? WaveIO<T, I, H, Args>::init_u(g, k, qi, qj) : (T)0;
+    T v = owns ? WaveIO<T, I, H, Args>::init_v(g, k, qi, qj) : (T)0;
+
+    bool mask_ok = false;
+    if constexpr (Model::kFastStop) {
+        const T mm_max = half_max_all<N>(active ? tabs(my_g) : (T)0);
+        const bool start_inside = u >= lo && u <= hi;
+        const bool term_nan = my_g != my_g;
+        const bool fine = m.fast_stop_ok(mm_max, eps, lambda, H) && start_inside && !term_nan;
+        mask_ok = __ballot(active && !fine) == 0ull;     // one code path for the wavefront: both halves must qualify
+    }
+    constexpr T kHuge = (T)0x1p600;
+    const T nlo_h = -(lo * kHuge), hi_h = hi * kHuge;
+    T huge_r = kHuge;
+    asm volatile("" : "+v"(huge_r));
+
+    auto gradient_of = [&](T uu) -> T {
+        T a0 = my_g, a1 = my_r * uu;
+        T x[2] = {uu, uu};
+        if constexpr (N > 16) {
+            const Swapped<T> p = swap_rows16(uu, uu);   // rows (0,0,2,2) and (1,1,3,3): each half sees its own two rows
+            x[0] = p.a; x[1] = p.b;
+        }
+        static_for_w<(N + 15) / 16>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            constexpr int cnt = N - 16 * r < 16 ? N - 16 * r : 16;
+            fmac_row<cnt>(a0, a1, x[r], kq + 16 * r);
+        });
+        return a0 + a1;
+    };
+
+    constexpr int kUnrollCd = TPC_WAVE_UNROLL_CD, kUnrollPg = TPC_WAVE_UNROLL_PG;
+    uint32_t iter_l = 0;              // iterations of this lane's instance (alike within a half)
+    unsigned long long still = 0ull;  // halves that were still going when the loops ended (= ran into the cap)
+    auto run = [&](auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        auto masked = [&](T uu, T df) -> T {
+            if constexpr (MASK) {
+                const T g_lo = tfma(uu, huge_r, nlo_h), g_hi = tfma(uu, -huge_r, hi_h);
+                return tmax(tmin(df, g_lo), -g_hi);
+            } else {
+                const bool blocked = (uu <= lo && df > (T)0) || (uu >= hi && df < (T)0);   // mpc.h:298-299
+                return (active && !blocked) ? df : (T)0;
+            }
+        };
+        const bool qd_nz = my_qd != (T)0;
+        const T my_rqd0 = qd_nz ? my_rqd : (T)0;
+        unsigned long long go_mask = alive_mask;
+        unsigned long long pg_alive = alive_mask;   // halves that enter the projected-gradient phase (a half that stopped
+                                                    // during coordinate descent is finished: wave_solve returns there)
+        bool go_lane = alive, last_take = false;
+        uint32_t cnt = 0;
+        const T eps_up = round_up_key(eps);
+        auto cd_step = [&]() {
+            const T df = gradient_of(u);
+            const T cs = masked(u, df);
+            T nu;
+            if constexpr (MASK) nu = tmax(tmin(tfma(-my_rqd0, df, u), hi), lo);
+            else {
+                nu = put_in_range(lo, hi, -(df - my_qd * u) * my_rqd);
+                nu = qd_nz ? nu : u;
+            }
+            asm volatile("" : "+v"(nu));
+            const T cf = (!MASK && tabs(cs) == (T)__builtin_inf()) ? (T)1.7976931348623157e308 : cs;
+            const T key = pack_key_abs(cf, 63 - lane);      // (the tag orders the lanes of a half like those of a wavefront)
+            const T mk = half_max_all<N>(key);
+            const T thr = raw_max(mk, eps_up);
+            const bool take = alive && key >= thr;
+            go_lane = alive && mk >= eps_up;                // mpc.h:310-311 (all lanes of a half alike)
+            last_take = take;
+            u = take ? nu : u;
+            cnt += go_lane ? 1u : 0u;
+        };
+        auto pg_step = [&]() {
+            const T df = gradient_of(u);
+            const T cs = masked(u, df);
+            const T v_new = clamp3(tfma(-inv_lambda, df, u), lo, hi);
+            const T u_new = clamp3(tfma(beta, v_new - v, v_new), lo, hi);
+            go_mask = __ballot(tabs(cs) >= eps) & pg_alive;                      // mpc.h:310-311, per half below
+            const unsigned long long go_all = halves_any_to_all(go_mask);
+            v = lane_select(go_all, v_new, v);
+            u = lane_select(go_all, u_new, u);
+            iter_l = add_lane_bit(iter_l, go_all);
+            still = go_all;
+        };
+        // ---- coordinate descent (mpc.h:319-335); the iteration index is common to both halves
+        const uint32_t cd_end = kn.smo_iters < kn.max_iter ? kn.smo_iters : kn.max_iter;
+        for (uint32_t blk = cd_end / kUnrollCd; blk;) {
+#pragma unroll
+            for (int r = 0; r < kUnrollCd; ++r) cd_step();
+            go_mask = __ballot(go_lane);
+            blk = go_mask != 0ull ? blk - 1 : 0u;
+        }
+        for (uint32_t rest = go_mask != 0ull ? cd_end % kUnrollCd : 0u; rest; --rest) cd_step();
+        go_mask = __ballot(go_lane);
+        iter_l = cnt;
+        still = halves_any_to_all(go_mask);
+        if (go_mask == 0ull) return;
+        {   // mpc.h:330-334, per half: the last CD iteration seeds v unless it was skipped
+            const unsigned long long seeded = halves_any_to_all(__ballot(last_take && qd_nz));
+            const bool mine = ((seeded >> lane) & 1ull) != 0ull;
+            if (mine && iter_l == kn.smo_iters) v = u;
+        }
+        // ---- accelerated projected gradient (mpc.h:336-345)
+        const uint32_t pg_left = kn.max_iter > cd_end ? kn.max_iter - cd_end : 0u;
+        pg_alive = still & alive_mask;
+        go_mask = pg_alive;
+        for (uint32_t blk = pg_left / kUnrollPg; blk;) {
+#pragma unroll
+            for (int r = 0; r < kUnrollPg; ++r) pg_step();
+            blk = go_mask != 0ull ? blk - 1 : 0u;
+        }
+        for (uint32_t rest = go_mask != 0ull ? pg_left % kUnrollPg : 0u; rest; --rest) pg_step();
+    };
+    before_loops();
+    if (alive_mask != 0ull) {
+        if (mask_ok) run(std::true_type{});
+        else run(std::false_type{});
+    }
+    WaveIO<T, I, H, Args>::write(g, k, owns, qi, qj, u, v, iter_l, ll == 0 && present);
+    if (g.flags) {
+        const bool capped = ((still >> lane) & 1ull) != 0ull;
+        uint32_t f = 0;
+        if (present && nonfinite) f |= 0x1u;
+        if (present && badmodel) f |= 0x4u;
         if (capped) f |= 0x2u;
         raise_flags(g.flags, f);
     }
@@ -909,6 +1130,7 @@ template <int I, int H> constexpr int queue_waves_per_cu() { return (wave_two_pe
 constexpr int kQueueMinHorizon = TPC_QUEUE_MIN_H;
 constexpr int kOrderThreads = 1024, kOrderBins = 2048, kOrderPerThread = 32;
 constexpr int64_t kQueueMaxInstances = (int64_t)kOrderThreads * kOrderPerThread;   // larger batches: plain launch
+static_assert(kQueueMaxInstances == kWaveQueueMaxInstances, "tpc_mpc_api.cpp's AUTO rule counts on it");
 
 // One workgroup: a key per instance (kept in registers) -> counting sort over kOrderBins linear bins of the
 // key range -> order[] (descending); the queue's ticket counters are zeroed here.  Positions inside a bin
@@ -981,6 +1203,34 @@ __global__ __launch_bounds__(kOrderThreads) void wave_order_kernel(Args g, uint3
 #pragma unroll
     for (int j = 0; j < kOrderPerThread; ++j)
         if (j * kOrderThreads + t < n) order[atomicAdd(&bins[bin_of(key[j])], 1u)] = (uint32_t)(j * kOrderThreads + t);
+}
+
+// The same queue walked in pairs: position p stands for the instances order[2p] and order[2p + 1] -- neighbours of
+// the longest-first order, i.e. alike in length -- solved by one wavefront (wave_pair_solve).
+template <typename T, int I, int H, class Model, class Args>
+__global__ __launch_bounds__((kWavesPerBlock * kWave)) __attribute__((amdgpu_waves_per_eu(2)))
+void wave_pair_queue_kernel(Args g, Knobs kn, const uint32_t* __restrict__ order, uint32_t* tickets) {
+    __shared__ __attribute__((aligned(16))) T s_w[kWavesPerBlock][4 * H];
+    const int w = threadIdx.x / kWave;
+    const uint32_t n = (uint32_t)g.n, pairs = (n + 1u) / 2u;
+    const uint32_t waves = gridDim.x * kWavesPerBlock, wid = blockIdx.x * kWavesPerBlock + w;
+    const uint32_t sub = wid % kQueueTickets;
+    uint32_t* my_ticket = tickets + sub * kQueueTicketStride;
+    uint32_t t = wid;
+    bool first = true;
+    while (t < pairs) {
+        const bool dynamic = !first && 2u * waves < pairs;
+        uint32_t drawn = 0;
+        auto ask = [&]() {
+            if (dynamic && (threadIdx.x & (kWave - 1)) == 0) drawn = atomicAdd(my_ticket, 1u);
+        };
+        const int64_t k0 = (int64_t)order[2u * t];
+        const int64_t k1 = 2u * t + 1u < n ? (int64_t)order[2u * t + 1u] : (int64_t)-1;
+        wave_pair_solve<T, I, H, Model, Args>(g, kn, k0, k1, s_w[w], ask);
+        const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)drawn);
+        t = first ? 2u * waves - 1u - wid : (dynamic ? 2u * waves + d * kQueueTickets + sub : pairs);
+        first = false;
+    }
 }
 
 // W persistent wavefronts over the queue.  The first two rounds are static: wavefront w takes position w, then

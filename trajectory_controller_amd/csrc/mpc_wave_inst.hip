@@ -43,7 +43,21 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
         constexpr bool queue_ok = kH >= kQueueMinHorizon &&
                                   !(wave_two_per_lane<I, kH>() && !std::is_same<Model, CompactModel<T>>::value);
         bool queued = false;
-        if constexpr (queue_ok) {
+        // fp64, at most 32 variables: two instances per wavefront over the same queue (mpc_wave.h, wave_pair_solve)
+        // (at every horizon: paired, even N = 4 and 5 are long enough for the queue to pay -- 280 -> 239 us for
+        // 32 768 instances at N = 5, 207 -> 195 at N = 4)
+        constexpr bool pair_ok = sizeof(T) == 8 && I * kH <= kWave / 2;
+        if constexpr (pair_ok) {
+            // from more than one wavefront per SIMD on: 2 048 instances at N = 10 take 141 us one per wavefront (two
+            // wavefronts sharing every SIMD) and ~120 us as 1 024 pairs of neighbours in the queue order
+            if (a.n > slots / kQueueWorkgroupsPerCu && a.n <= kQueueMaxInstances && ws.order) {
+                hipLaunchKernelGGL((wave_order_kernel<T, I, kH, Model, Args>), dim3(1), dim3(kOrderThreads), 0, s, a,
+                                   ws.order, ws.ticket);
+                hipLaunchKernelGGL((wave_pair_queue_kernel<T, I, kH, Model, Args>), dim3((unsigned)(slots / kWavesPerBlock)),
+                                   dim3(kWavesPerBlock * kWave), 0, s, a, k, (const uint32_t*)ws.order, ws.ticket);
+                queued = true;
+            }
+        } else if constexpr (queue_ok) {
             if (a.n > slots && a.n <= kQueueMaxInstances && ws.order) {
                 hipLaunchKernelGGL((wave_order_kernel<T, I, kH, Model, Args>), dim3(1), dim3(kOrderThreads), 0, s, a,
                                    ws.order, ws.ticket);

@@ -54,11 +54,11 @@ const int32_t* take_hint(tpc_mpc_context* h, int64_t n) {
 // LANE needs enough instances to give every SIMD a full wavefront; below that WAVE's
 // one-wavefront-per-instance launch finishes sooner.  Measured crossovers on MI355X
 // (scripts/crossover.py, fp64, compact form, round 2 kernels; the chip has 65 536 LANE slots):
-// H = 4 and H = 10: between 24 576 and 32 768 instances; H = 20: WAVE still wins at 32 768, the largest
-// batch its work queue takes (5.4 against 6.9 ms), and loses without the queue beyond.
+// fp32 at H = 4 and H = 10 (one instance per wavefront): between 24 576 and 32 768 instances; H = 20: WAVE still
+// wins at 32 768, the largest batch its work queue takes (5.4 against 6.9 ms), and loses without the queue beyond.
 // The WAVE kernel maps one decision variable to one lane, so it exists for I*H <= 64 only.
 // Returns the kernel family to run, or -1 when WAVE was demanded for a shape it cannot take.
-int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n) {
+int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n, int dtype) {
     if (!horizon_specialised(H)) return algo == TPC_MPC_ALGO_WAVE ? -1 : kAlgoGeneric;
     const bool wave_ok = I * H <= kWave || (I == 2 && H <= kWave);   // (two variables per lane past 64)
     if (algo == TPC_MPC_ALGO_WAVE) return wave_ok ? algo : -1;
@@ -66,7 +66,12 @@ int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n) {
     const int64_t lanes = (int64_t)h->cu_count * 4 * kWave;
     // (N = 40 with two inputs: the two-variables-per-lane WAVE kernel against a LANE pass that lasts as long
     // as its slowest instance, 50 ms whatever the batch: 42.0 against 50.0 ms at 16 384, 62.4 against 49.9 at 24 576)
-    const int64_t crossover = I * H > kWave ? lanes * 19 / 64 : (H >= 20 ? lanes / 2 + 1 : lanes * 7 / 16);
+    // (fp64 with at most 32 variables: two instances per wavefront over the work queue -- WAVE wins up to the
+    // largest batch the queue takes: 0.65 against 1.00 ms at 32 768 x N = 10, 0.20 against 0.21 at N = 4;
+    // without the queue, at 49 152, it loses 1.6 to 1.0)
+    const bool paired = dtype == TPC_MPC_F64 && I * H <= kWave / 2;
+    const int64_t crossover = I * H > kWave ? lanes * 19 / 64
+                              : ((H >= 20 || paired) ? kWaveQueueMaxInstances + 1 : lanes * 7 / 16);
     return (n >= crossover || !wave_ok) ? TPC_MPC_ALGO_LANE : TPC_MPC_ALGO_WAVE;
 }
 
@@ -239,7 +244,7 @@ int reserve_lane_workspace(tpc_mpc_context* h, int H, int dtype, int64_t n) {
 
 int compact_launch(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy,
                    const void* dphi, void* front, void* rear, int32_t* iters, hipStream_t s) {
-    const int algo = pick_algo(h, p->algo, 2, p->horizon, n);
+    const int algo = pick_algo(h, p->algo, 2, p->horizon, n, p->dtype);
     if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel exists for the specialised horizons with inputs*horizon <= 64 only; use LANE or AUTO");
     CompactArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -438,7 +443,7 @@ int tpc_mpc_solve_batch_general(tpc_mpc_handle h, const tpc_mpc_params* p,
         const int64_t es = (int64_t)esize(p->dtype);
         const int I = io->inputs, H = p->horizon;
         const int64_t n = io->n;
-        const int algo = pick_algo(h, p->algo, I, H, n);
+        const int algo = pick_algo(h, p->algo, I, H, n, p->dtype);
         if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel exists for the specialised horizons with inputs*horizon <= 64 only; use LANE or AUTO");
         rc = stream_order_begin(h, s);
         if (rc) return rc;
@@ -525,7 +530,7 @@ int tpc_mpc_rollout(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mpc_gen
         const int64_t es = (int64_t)esize(p->dtype);
         const int I = io->inputs, H = p->horizon;
         const int64_t n = io->n, ld = io->ld;
-        const int algo = pick_algo(h, p->algo, I, H, n);
+        const int algo = pick_algo(h, p->algo, I, H, n, p->dtype);
         if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel exists for the specialised horizons with inputs*horizon <= 64 only; use LANE or AUTO");
         rc = stream_order_begin(h, s);
         if (rc) return rc;
@@ -708,7 +713,7 @@ int tpc_mpc_follow_batch_horizon(tpc_mpc_handle h, const tpc_mpc_params* p, cons
         hipStream_t s = (hipStream_t)stream;
         const int64_t n = t->n;
         const int H = p->horizon, I = 2;
-        const int algo = pick_algo(h, p->algo, I, H, n);
+        const int algo = pick_algo(h, p->algo, I, H, n, p->dtype);
         if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel exists for the specialised horizons with inputs*horizon <= 64 only; use LANE or AUTO");
         rc = stream_order_begin(h, s);
         if (rc) return rc;

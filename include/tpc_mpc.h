@@ -58,15 +58,18 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
 /* Kernel family.
  *   WAVE : one 64-lane wavefront per instance; lane j owns decision variable j and its row of the
  *          dense (I*H)x(I*H) Hessian (two variables per lane where I*H > 64: I = 2, H <= 64), the
- *          controls are exchanged by DPP / lane swaps, reductions by wavefront DPP/ballot.  Lowest
+ *          controls are exchanged by DPP / lane swaps, reductions by wavefront DPP/ballot.  (fp64
+ *          batches of more than one instance per SIMD with I*H <= 32 run two instances per wavefront,
+ *          one per 32-lane half: same arithmetic per instance, every verdict per half.)  Lowest
  *          latency; used for small and mid-size batches and solve_one.  Needs a specialised horizon
  *          with I*H <= 64 or I = 2.  Agrees with the reference to ~1e-14 (same decisions, different
  *          summation).
  *   LANE : one lane per instance, dlib's O(H) recurrences unrolled in registers, 64 instances
  *          per wavefront with dynamic refill of finished lanes.  Bit-identical to the reference
  *          arithmetic in fp64; highest throughput on large batches.
- *   AUTO : WAVE below a measured crossover (about 29 000 instances on a 256-CU part, 32 768 from
- *          N = 20, 19 456 at N = 40 with two inputs), LANE from there up. */
+ *   AUTO : WAVE below a measured crossover (on a 256-CU part: 32 768 instances, the largest batch the
+ *          WAVE work queue takes, in fp64 with I*H <= 32 and from N = 20 up; about 29 000 in fp32 below
+ *          N = 20; 19 456 at N = 40 with two inputs), LANE from there up. */
 typedef enum tpc_mpc_algo { TPC_MPC_ALGO_AUTO = 0, TPC_MPC_ALGO_WAVE = 1, TPC_MPC_ALGO_LANE = 2 } tpc_mpc_algo;
 
 /* Non-fatal per-call flags, OR-ed into *flags_out (may be NULL). */

@@ -14,7 +14,7 @@ rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 CONFIGS = {   # tag -> (kernel in the csv, bench key, k, note)
     "headline": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_f64_H20_n262144", 1, "strided record reads: k=1 (calibrated)"),
     "fp32": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_f32_H20_n262144", 1, "strided record reads: k=1"),
-    "config2": ("tpc::wave_queue_kernel", "wave_kernel_f64_H10_n4096", 1, "broadcast loads of 3 scalars per wavefront + the queue order: uncalibrated, k=1"),
+    "config2": ("tpc::wave_pair_queue_kernel", "wave_kernel_f64_H10_n4096", 1, "broadcast loads of 3 scalars per wavefront + the queue order: uncalibrated, k=1"),
     "h30": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_f64_H30_n262144", 1, "strided record reads: k=1"),
     "h40": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_f64_H40_n262144", 1, "strided record reads: k=1"),
     "general": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_general_I2_f64_H20_n262144", 1, "strided record reads + SoA model loads: k=1"),

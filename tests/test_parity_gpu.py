@@ -14,6 +14,8 @@ Tolerances (stated once, used below):
   fp32 vs fp64       : a throughput / tolerance-sweep mode, not a parity mode (SURVEY.md section 0
                        fact 3): only loose sanity bounds are asserted, the histogram is reported.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -763,6 +765,38 @@ def test_wave_queue_vs_oracle(torch_cuda, oracle, H):
             gu0, git = s.solve_batch_general(*[_soa(g[k]) for k in GEN_NAMES], inputs=I, want_iters=True)
             assert np.array_equal(git, git0), I
             assert np.abs(gu0.T - u0).max() <= WAVE_ATOL, I
+
+
+_ONE_PER_WAVE = r'''
+import sys
+sys.path.insert(0, {root!r})
+import numpy as np
+from oracle.bindings import Oracle, build_oracle
+from trajectory_controller_amd import MpcSolver
+from trajectory_controller_amd.synth import compact_inputs
+build_oracle()
+o = Oracle()
+for H, n in ((10, 5000), (5, 3000)):
+    v, dy, dphi = compact_inputs(H, n, first=91000 + H)
+    of, orr, oit = o.solve_compact(H, v, dy, dphi, nthreads=8)
+    with MpcSolver(horizon=H, algo="wave") as s:
+        f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+    assert np.array_equal(it, oit), H
+    assert max(np.abs(f - of).max(), np.abs(r - orr).max()) <= 1e-9, H
+print("one-per-wavefront ok")
+'''
+
+
+def test_wave_one_instance_per_wavefront_switch(torch_cuda, tmp_path):
+    """TPC_MPC_WAVE_PAIRS=0 (read once per process, hence the child) keeps the fp64 WAVE batches of up to 32
+    variables on the one-instance-per-wavefront kernels the paired path replaced by default: same iteration
+    counts, same tolerance."""
+    import subprocess, sys
+    script = tmp_path / "one_per_wave.py"
+    script.write_text(_ONE_PER_WAVE.format(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, TPC_MPC_WAVE_PAIRS="0"),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "one-per-wavefront ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 def test_wave_queue_boundaries(torch_cuda, oracle):

@@ -1,6 +1,8 @@
 // One translation unit per horizon (compile with -DTPC_WAVE_H=<H>): instantiates the WAVE kernel
 // for fp64/fp32, compact and general (I = 1, 2) models, and exports its launchers.  Horizons with
 // I*H > 64 have no WAVE kernel; their launchers report hipErrorNotSupported.
+#include <cstdlib>
+
 #include "mpc_wave.h"
 
 #ifndef TPC_WAVE_H
@@ -47,18 +49,21 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
         // (at every horizon: paired, even N = 4 and 5 are long enough for the queue to pay -- 280 -> 239 us for
         // 32 768 instances at N = 5, 207 -> 195 at N = 4)
         constexpr bool pair_ok = sizeof(T) == 8 && I * kH <= kWave / 2;
+        // TPC_MPC_WAVE_PAIRS=0 in the environment keeps strictly one instance per wavefront (for A/B measurements)
+        static const bool pairs_wanted = [] { const char* e = getenv("TPC_MPC_WAVE_PAIRS"); return !e || atoi(e) != 0; }();
         if constexpr (pair_ok) {
             // from more than one wavefront per SIMD on: 2 048 instances at N = 10 take 141 us one per wavefront (two
             // wavefronts sharing every SIMD) and ~120 us as 1 024 pairs of neighbours in the queue order
-            if (a.n > slots / kQueueWorkgroupsPerCu && a.n <= kQueueMaxInstances && ws.order) {
+            if (pairs_wanted && a.n > slots / kQueueWorkgroupsPerCu && a.n <= kQueueMaxInstances && ws.order) {
                 hipLaunchKernelGGL((wave_order_kernel<T, I, kH, Model, Args>), dim3(1), dim3(kOrderThreads), 0, s, a,
                                    ws.order, ws.ticket);
                 hipLaunchKernelGGL((wave_pair_queue_kernel<T, I, kH, Model, Args>), dim3((unsigned)(slots / kWavesPerBlock)),
                                    dim3(kWavesPerBlock * kWave), 0, s, a, k, (const uint32_t*)ws.order, ws.ticket);
                 queued = true;
             }
-        } else if constexpr (queue_ok) {
-            if (a.n > slots && a.n <= kQueueMaxInstances && ws.order) {
+        }
+        if constexpr (queue_ok) {
+            if (!queued && a.n > slots && a.n <= kQueueMaxInstances && ws.order) {
                 hipLaunchKernelGGL((wave_order_kernel<T, I, kH, Model, Args>), dim3(1), dim3(kOrderThreads), 0, s, a,
                                    ws.order, ws.ticket);
                 hipLaunchKernelGGL((wave_queue_kernel<T, I, kH, Model, Args>), dim3((unsigned)(slots / wpb)),

@@ -60,8 +60,9 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
  *          dense (I*H)x(I*H) Hessian (two variables per lane where I*H > 64: I = 2, H <= 64), the
  *          controls are exchanged by DPP / lane swaps, reductions by wavefront DPP/ballot.  (fp64
  *          batches of more than one instance per SIMD with I*H <= 32 run two instances per wavefront,
- *          one per 32-lane half: same arithmetic per instance, every verdict per half;
- *          TPC_MPC_WAVE_PAIRS=0 in the environment keeps strictly one per wavefront.)  Lowest
+ *          one per 32-lane half, and four -- one per 16-lane row -- with I*H <= 16: same arithmetic per
+ *          instance, every verdict per group; TPC_MPC_WAVE_PAIRS=0 in the environment keeps strictly
+ *          one per wavefront.)  Lowest
  *          latency; used for small and mid-size batches and solve_one.  Needs a specialised horizon
  *          with I*H <= 64 or I = 2.  Agrees with the reference to ~1e-14 (same decisions, different
  *          summation).

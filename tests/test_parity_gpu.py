@@ -799,17 +799,23 @@ def test_wave_one_instance_per_wavefront_switch(torch_cuda, tmp_path):
     assert out.returncode == 0 and "one-per-wavefront ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
-def test_wave_queue_boundaries(torch_cuda, oracle):
-    """Batch sizes at every seam of the WAVE work queue (W persistent wavefronts = 8 per CU): the first size that
-    uses it, the end of the two static rounds (2W), the first dynamic positions and the seams between the 16
-    ticket counters they are dealt from, and the largest batch the queue takes.  Every instance must be solved
-    exactly once: iteration counts equal the oracle's and outputs within the family's tolerance."""
+@pytest.mark.parametrize("H", [10, 5])
+def test_wave_queue_boundaries(torch_cuda, oracle, H):
+    """Batch sizes at every seam of the WAVE work queue (W persistent wavefronts = 8 per CU): where one instance
+    per wavefront gives way to two (N = 10) and to four (N = 5), the end of the two static rounds, the first
+    dynamic positions and the seams between the 16 ticket counters they are dealt from -- in units of one, two
+    and four instances -- ragged last groups, and the largest batch the queue takes.  Every instance must be
+    solved exactly once: iteration counts equal the oracle's and outputs within the family's tolerance."""
     import torch
     from trajectory_controller_amd.synth import compact_inputs
-    H = 10
     W = 8 * torch.cuda.get_device_properties(0).multi_processor_count
-    sizes = sorted({W + 1, 2 * W - 1, 2 * W, 2 * W + 1, 2 * W + 15, 2 * W + 16, 2 * W + 17, 2 * W + 1000, 32767, 32768} - {0})
-    v, dy, dphi = compact_inputs(H, max(sizes), first=77000)
+    sizes = set()
+    for unit in (1, 2, 4):          # instances per queue position
+        for pos in (W // 2, W, 2 * W, 2 * W + 16):
+            for d in (-1, 0, 1, 2, 3, 15 * unit, 16 * unit, 16 * unit + 1):
+                sizes.add(unit * pos + d)
+    sizes = sorted(n for n in sizes | {32767, 32768} if 0 < n <= 32768)
+    v, dy, dphi = compact_inputs(H, max(sizes), first=77000 + H)
     of, orr, oit = oracle.solve_compact(H, v, dy, dphi, nthreads=8)
     with _solver(H, "wave") as s:
         for n in sizes:

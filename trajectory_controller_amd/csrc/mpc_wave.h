@@ -611,6 +611,18 @@ TPC_DEV unsigned long long halves_any_to_all(unsigned long long mask) {   // per
     asm("s_cmp_lg_u32 %1, 0\n\ts_cselect_b32 %0, -1, 0" : "=s"(hi) : "s"((unsigned)(mask >> 32)) : "scc");
     return ((unsigned long long)hi << 32) | lo;
 }
+// per 16-lane row: any bit set -> all ones (carry-free field arithmetic on the scalar unit: no select, no branch)
+TPC_DEV unsigned long long rows_any_to_all(unsigned long long mask) {
+    auto spread = [](unsigned w) {
+        const unsigned top = (((w & 0x7fff7fffu) + 0x7fff7fffu) | w) & 0x80008000u;   // bit 15 of a field: field != 0
+        return (top >> 15) * 0xffffu;
+    };
+    return ((unsigned long long)spread((unsigned)(mask >> 32)) << 32) | spread((unsigned)mask);
+}
+template <int G> TPC_DEV unsigned long long groups_any_to_all(unsigned long long mask) {
+    if constexpr (G == 2) return halves_any_to_all(mask);
+    else return rows_any_to_all(mask);
+}
 TPC_DEV uint32_t add_lane_bit(uint32_t x, unsigned long long mask) {   // x + (bit of this lane in mask): one v_addc
     uint32_t r;
     unsigned long long carry_out;
@@ -627,15 +639,20 @@ template <int N> TPC_DEV double half_max_all(double x) {
     }
 }
 
-template <typename T, int I, int H, class Model, class Args, class Hook = NoHook>
-TPC_DEV void wave_pair_solve(const Args& g, const Knobs& kn, int64_t k0, int64_t k1, T* s_w, Hook before_loops = Hook{}) {
+// G = 4: the same with one instance per 16-lane row (at most 16 variables: N = 4 and 5 with two inputs), ks[0..3].
+template <typename T, int I, int H, int G, class Model, class Args, class Hook = NoHook>
+TPC_DEV void wave_pair_solve(const Args& g, const Knobs& kn, const int64_t (&ks)[G], T* s_w, Hook before_loops = Hook{}) {
     static_assert(sizeof(T) == 8, "fp64 only");
-    constexpr int N = I * H, L = kWave / 2;
-    static_assert(N <= L, "one instance per 32-lane half");
+    static_assert(G == 2 || G == 4, "a half or a row per instance");
+    constexpr int N = I * H, L = kWave / G;
+    static_assert(N <= L, "one instance per group of lanes");
     const int lane = threadIdx.x & (kWave - 1);
-    const int half = lane / L, ll = lane % L;
-    const bool present = half == 0 || k1 >= 0;
-    const int64_t k = (half == 0 || k1 < 0) ? k0 : k1;      // (a missing second instance shadows the first: valid addresses)
+    const int half = lane / L, ll = lane % L;               // (half: the lane's group -- a 32-lane half or a 16-lane row)
+    int64_t k_mine = ks[0];
+#pragma unroll
+    for (int j = 1; j < G; ++j) k_mine = half == j ? ks[j] : k_mine;
+    const bool present = k_mine >= 0;
+    const int64_t k = present ? k_mine : ks[0];             // (a missing instance shadows the first: valid addresses)
     const bool owns = ll < N && present;                     // this lane holds a variable of an instance
     const int qi = owns ? ll / I : 0, qj = owns ? ll % I : 0;
     const int slot = 2 * qi + qj;
@@ -762,7 +779,7 @@ TPC_DEV void wave_pair_solve(const Args& g, const Knobs& kn, int64_t k0, int64_t
             const T v_new = clamp3(tfma(-inv_lambda, df, u), lo, hi);
             const T u_new = clamp3(tfma(beta, v_new - v, v_new), lo, hi);
             go_mask = __ballot(tabs(cs) >= eps) & pg_alive;                      // mpc.h:310-311, per half below
-            const unsigned long long go_all = halves_any_to_all(go_mask);
+            const unsigned long long go_all = groups_any_to_all<G>(go_mask);
             v = lane_select(go_all, v_new, v);
             u = lane_select(go_all, u_new, u);
             iter_l = add_lane_bit(iter_l, go_all);
@@ -779,10 +796,10 @@ TPC_DEV void wave_pair_solve(const Args& g, const Knobs& kn, int64_t k0, int64_t
         for (uint32_t rest = go_mask != 0ull ? cd_end % kUnrollCd : 0u; rest; --rest) cd_step();
         go_mask = __ballot(go_lane);
         iter_l = cnt;
-        still = halves_any_to_all(go_mask);
+        still = groups_any_to_all<G>(go_mask);
         if (go_mask == 0ull) return;
         {   // mpc.h:330-334, per half: the last CD iteration seeds v unless it was skipped
-            const unsigned long long seeded = halves_any_to_all(__ballot(last_take && qd_nz));
+            const unsigned long long seeded = groups_any_to_all<G>(__ballot(last_take && qd_nz));
             const bool mine = ((seeded >> lane) & 1ull) != 0ull;
             if (mine && iter_l == kn.smo_iters) v = u;
         }
@@ -1205,30 +1222,34 @@ __global__ __launch_bounds__(kOrderThreads) void wave_order_kernel(Args g, uint3
         if (j * kOrderThreads + t < n) order[atomicAdd(&bins[bin_of(key[j])], 1u)] = (uint32_t)(j * kOrderThreads + t);
 }
 
-// The same queue walked in pairs: position p stands for the instances order[2p] and order[2p + 1] -- neighbours of
-// the longest-first order, i.e. alike in length -- solved by one wavefront (wave_pair_solve).
-template <typename T, int I, int H, class Model, class Args>
+// The same queue walked in groups of G (2 or 4): position p stands for the instances order[G p] .. order[G p + G - 1]
+// -- neighbours of the longest-first order, i.e. alike in length -- solved by one wavefront (wave_pair_solve).
+template <typename T, int I, int H, int G, class Model, class Args>
 __global__ __launch_bounds__((kWavesPerBlock * kWave)) __attribute__((amdgpu_waves_per_eu(2)))
 void wave_pair_queue_kernel(Args g, Knobs kn, const uint32_t* __restrict__ order, uint32_t* tickets) {
-    __shared__ __attribute__((aligned(16))) T s_w[kWavesPerBlock][4 * H];
+    __shared__ __attribute__((aligned(16))) T s_w[kWavesPerBlock][G * 2 * H];
     const int w = threadIdx.x / kWave;
-    const uint32_t n = (uint32_t)g.n, pairs = (n + 1u) / 2u;
+    const uint32_t n = (uint32_t)g.n, groups = (n + (uint32_t)G - 1u) / (uint32_t)G;
     const uint32_t waves = gridDim.x * kWavesPerBlock, wid = blockIdx.x * kWavesPerBlock + w;
     const uint32_t sub = wid % kQueueTickets;
     uint32_t* my_ticket = tickets + sub * kQueueTicketStride;
     uint32_t t = wid;
     bool first = true;
-    while (t < pairs) {
-        const bool dynamic = !first && 2u * waves < pairs;
+    while (t < groups) {
+        const bool dynamic = !first && 2u * waves < groups;
         uint32_t drawn = 0;
         auto ask = [&]() {
             if (dynamic && (threadIdx.x & (kWave - 1)) == 0) drawn = atomicAdd(my_ticket, 1u);
         };
-        const int64_t k0 = (int64_t)order[2u * t];
-        const int64_t k1 = 2u * t + 1u < n ? (int64_t)order[2u * t + 1u] : (int64_t)-1;
-        wave_pair_solve<T, I, H, Model, Args>(g, kn, k0, k1, s_w[w], ask);
+        int64_t ks[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const uint32_t pos = (uint32_t)G * t + (uint32_t)j;
+            ks[j] = pos < n ? (int64_t)order[pos] : (int64_t)-1;
+        }
+        wave_pair_solve<T, I, H, G, Model, Args>(g, kn, ks, s_w[w], ask);
         const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)drawn);
-        t = first ? 2u * waves - 1u - wid : (dynamic ? 2u * waves + d * kQueueTickets + sub : pairs);
+        t = first ? 2u * waves - 1u - wid : (dynamic ? 2u * waves + d * kQueueTickets + sub : groups);
         first = false;
     }
 }

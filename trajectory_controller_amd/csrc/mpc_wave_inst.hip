@@ -57,8 +57,21 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
             if (pairs_wanted && a.n > slots / kQueueWorkgroupsPerCu && a.n <= kQueueMaxInstances && ws.order) {
                 hipLaunchKernelGGL((wave_order_kernel<T, I, kH, Model, Args>), dim3(1), dim3(kOrderThreads), 0, s, a,
                                    ws.order, ws.ticket);
-                hipLaunchKernelGGL((wave_pair_queue_kernel<T, I, kH, Model, Args>), dim3((unsigned)(slots / kWavesPerBlock)),
-                                   dim3(kWavesPerBlock * kWave), 0, s, a, k, (const uint32_t*)ws.order, ws.ticket);
+                // at most 16 variables: four instances per wavefront, one per 16-lane row, once pairs would put more
+                // than one wavefront on a SIMD (32 768 x N = 4: 198 us in pairs, 147 in fours; 4 096: 47 / 44;
+                // TPC_MPC_WAVE_GROUP=2|4 forces either)
+                constexpr bool quad_ok = I * kH <= kWave / 4;
+                static const int group_forced = [] { const char* e = getenv("TPC_MPC_WAVE_GROUP"); return e ? atoi(e) : 0; }();
+                bool quads = false;
+                if constexpr (quad_ok) quads = group_forced == 4 || (group_forced == 0 && a.n > slots);
+                if constexpr (quad_ok) {
+                    if (quads)
+                        hipLaunchKernelGGL((wave_pair_queue_kernel<T, I, kH, 4, Model, Args>), dim3((unsigned)(slots / kWavesPerBlock)),
+                                           dim3(kWavesPerBlock * kWave), 0, s, a, k, (const uint32_t*)ws.order, ws.ticket);
+                }
+                if (!quads)
+                    hipLaunchKernelGGL((wave_pair_queue_kernel<T, I, kH, 2, Model, Args>), dim3((unsigned)(slots / kWavesPerBlock)),
+                                       dim3(kWavesPerBlock * kWave), 0, s, a, k, (const uint32_t*)ws.order, ws.ticket);
                 queued = true;
             }
         }

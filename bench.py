@@ -23,6 +23,8 @@ the average over the timed region of the library's events around each kernel (la
 handle), "kernel_ms_serial" the same measured right after the timed region with one batch in flight.
 A one-GPU run with the default one batch in flight also times the same K steps with two in flight and
 reports that figure under "pipelined" (value, ms_per_step, alu_frac), next to `value`.
+The default one-GPU run also times BASELINE config 2 (4 096 instances, N = 10, the WAVE family) and reports it
+under "config2".
 
 `value` is measured in fp64, the only dtype that meets the 1e-6 parity target (SURVEY.md section 0
 fact 3); the fp32 rate of the same workload is reported beside it under "fp32" with its error
@@ -65,6 +67,7 @@ def parse():
     ap.add_argument("--no-fp32", action="store_true")
     ap.add_argument("--inflight", type=int, default=1, help="batches kept in flight (handle + stream each)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-batches-in-flight leg")
+    ap.add_argument("--no-config2", action="store_true", help="skip the BASELINE config 2 leg (4 096 x N=10, WAVE)")
     return ap.parse_args()
 
 
@@ -375,6 +378,21 @@ def main():
                                       for t in (1e-2, 1e-3, 1e-4, 1e-5, 1e-6)},
                            "max_abs_du_vs_fp64": float(err.max().item())}
             s32.close()
+        if world == 1 and not a.no_config2 and a.dtype == "f64" and n == 262144 and H == 20:
+            # BASELINE config 2 beside the headline: 4 096 instances at N = 10 through the WAVE family (the same
+            # workload `--batch 4096 --horizon 10 --algo wave` times on its own; profiles/r02_config2_*)
+            c2 = [torch.from_numpy(x).to(dev) for x in compact_inputs(10, 4096)]
+            with MpcSolver(horizon=10, device=local_rank, dtype="f64", algo="wave") as sw:
+                for _ in range(3):
+                    sw.solve_batch_compact(*c2, want_flags=False)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(50):
+                    sw.solve_batch_compact(*c2, want_flags=False)
+                torch.cuda.synchronize()
+                d2 = time.perf_counter() - t1
+            out["config2"] = {"workload": "batch 4096, N=10, fp64, WAVE family", "value": 4096 * 50 / d2,
+                              "unit": "solves/s", "ms_per_step": d2 / 50 * 1e3}
         print(json.dumps(out), flush=True)
     for sv in solvers:
         sv.close()

@@ -737,10 +737,11 @@ def test_wave_mask_forms_vs_oracle(torch_cuda, oracle, I):
     run(g)
 
 
-@pytest.mark.parametrize("H", [10, 20, 30, 40])
+@pytest.mark.parametrize("H", [4, 5, 10, 20, 30, 40])
 def test_wave_queue_vs_oracle(torch_cuda, oracle, H):
-    """More instances than the WAVE family's persistent grid holds (two wavefronts per SIMD): they are taken
-    from a longest-first queue, ordered by lambda or by the caller's work hint.  The order must not change a
+    """More instances than one wavefront per SIMD (fp64, up to 32 variables: two or four instances per wavefront)
+    or than the WAVE family's persistent grid holds (two wavefronts per SIMD): they are taken from a
+    longest-first queue, ordered by lambda or by the caller's work hint.  The order must not change a
     result: iteration counts equal the oracle's, outputs within the family's tolerance, with and without a
     hint, compact and general form, and a batch that fits the grid (no queue) agrees on its share."""
     from trajectory_controller_amd.synth import compact_inputs, general_inputs

@@ -766,6 +766,14 @@ def test_wave_queue_vs_oracle(torch_cuda, oracle, H):
             gu0, git = s.solve_batch_general(*[_soa(g[k]) for k in GEN_NAMES], inputs=I, want_iters=True)
             assert np.array_equal(git, git0), I
             assert np.abs(gu0.T - u0).max() <= WAVE_ATOL, I
+            if H == 10:   # a warm start (controls in and out) through the grouped path: four (I = 1) and two (I = 2) per wavefront
+                cin = np.random.default_rng(5 + I).uniform(-0.5, 0.5, size=(g["A"].shape[0], H, I))
+                wu0, wc, wit = oracle.solve_general(I, H, *[g[k] for k in GEN_NAMES], controls_in=cin, nthreads=8)
+                controls = _soa(cin)
+                gu0, git = s.solve_batch_general(*[_soa(g[k]) for k in GEN_NAMES], controls=controls, inputs=I, want_iters=True)
+                assert np.array_equal(git, wit), I
+                assert np.abs(gu0.T - wu0).max() <= WAVE_ATOL, I
+                assert np.abs(controls.T.reshape(wc.shape) - wc).max() <= WAVE_ATOL, I
 
 
 _ONE_PER_WAVE = r'''

@@ -2,7 +2,8 @@
 innermost loop.  Background: one build of the two-variables-per-lane WAVE kernel ran out of
 AGPRs, kept a dword of a Hessian entry in scratch and reloaded it inside its iteration loops -- and returned wrong
 controls for one instance in nine, while every scratch-free build of the same source agrees with dlib to 1e-13
-(caught by test_wave_queue_vs_oracle[40] on the GPU).  The cause was not found, so the kernels the BASELINE configs
+(caught by test_wave_queue_vs_oracle[40] on the GPU).  The cause was not found (another build that spills
+inside its loops is correct, so the spill is a marker of that build, not the bug), so the kernels the BASELINE configs
 run -- the compact-form WAVE kernels and the resident single-solve kernels -- must not spill inside a loop; it would
 also be a performance bug there.  (The LANE fp64 N = 40 kernels spill in their loop by design and are checked bit for
 bit against dlib; general-form WAVE kernels that do are listed, not refused.)"""

@@ -776,6 +776,23 @@ def test_wave_queue_vs_oracle(torch_cuda, oracle, H):
                 assert np.abs(controls.T.reshape(wc.shape) - wc).max() <= WAVE_ATOL, I
 
 
+@pytest.mark.parametrize("H", [10, 20])
+def test_wave_queue_fp32_equals_unqueued(torch_cuda, H):
+    """fp32 WAVE has no oracle of its own (it is a tolerance-sweep mode), but its work queue -- one instance per
+    wavefront, static rounds plus ticket counters -- must not change a bit: a batch large enough for the dynamic
+    part of the queue equals the same instances solved in chunks that fit the chip at once (no queue)."""
+    from trajectory_controller_amd.synth import compact_inputs
+    n = 5000
+    v, dy, dphi = (a.astype(np.float32) for a in compact_inputs(H, n, first=64000 + H))
+    with _solver(H, "wave", dtype="f32") as s:
+        f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+        for a in range(0, n, 1000):
+            fc, rc, ic = s.solve_batch_compact(v[a:a + 1000], dy[a:a + 1000], dphi[a:a + 1000], want_iters=True)
+            assert np.array_equal(ic, it[a:a + 1000]), a
+            assert np.array_equal(fc.view(np.uint32), f[a:a + 1000].view(np.uint32)), a
+            assert np.array_equal(rc.view(np.uint32), r[a:a + 1000].view(np.uint32)), a
+
+
 _ONE_PER_WAVE = r'''
 import sys
 sys.path.insert(0, {root!r})

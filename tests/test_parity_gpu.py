@@ -793,6 +793,22 @@ def test_wave_queue_fp32_equals_unqueued(torch_cuda, H):
             assert np.array_equal(rc.view(np.uint32), r[a:a + 1000].view(np.uint32)), a
 
 
+@pytest.mark.parametrize("H", [4, 5, 10])
+def test_wave_groups_equal_one_per_wavefront(torch_cuda, H):
+    """fp64, up to 32 variables: two (N = 10) or four (N = 4, 5) instances per wavefront run every instance through
+    the arithmetic of the one-instance kernel (maxima are exact, the sums associate alike), so a grouped batch
+    equals the same instances solved in chunks of one per wavefront BIT FOR BIT -- iteration counts and outputs."""
+    from trajectory_controller_amd.synth import compact_inputs
+    n = 9000
+    v, dy, dphi = compact_inputs(H, n, first=83000 + H)
+    with _solver(H, "wave") as s:
+        f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+        for a in range(0, n, 1000):
+            fc, rc, ic = s.solve_batch_compact(v[a:a + 1000], dy[a:a + 1000], dphi[a:a + 1000], want_iters=True)
+            assert np.array_equal(ic, it[a:a + 1000]), a
+            assert bits_equal(fc, f[a:a + 1000]) and bits_equal(rc, r[a:a + 1000]), a
+
+
 _ONE_PER_WAVE = r'''
 import sys
 sys.path.insert(0, {root!r})

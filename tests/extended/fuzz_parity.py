@@ -47,9 +47,18 @@ for s_i in range(sets):
         f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
     # bits, except that any NaN equals any NaN (x86 and the GPU disagree on the default NaN's sign bit)
     diff = lambda x, y: (x.view(UI) != y.view(UI)) & ~(np.isnan(x) & np.isnan(y))
-    mism = int(np.sum(diff(f, of) | diff(r, orr) | (it != oit)))
+    # Beyond the model screen's bound on |T v| (1e4 in fp32, 1e60 in fp64) dlib's intermediates can overflow, and its
+    # products with the literal zeros of A then make NaNs (0 * inf) that the compact model's shortcuts do not form:
+    # outputs are still compared there, iteration counts are not ("one known deviation").
+    wild = np.abs(T * v.astype(np.float64)) > (1e60 if DT == "f64" else 1e4)
+    mism = int(np.sum(diff(f, of) | diff(r, orr) | ((it != oit) & ~wild)))
+    wild_counts = int(np.sum((it != oit) & wild))
     bad += mism
+    if mism:   # the evidence, for whoever has to explain it
+        for i in np.nonzero(diff(f, of) | diff(r, orr) | ((it != oit) & ~wild))[0][:5]:
+            print(f"    instance {i}: v {v[i]!r} dy {dy[i]!r} dphi {dphi[i]!r}  gpu ({f[i]!r}, {r[i]!r}, {it[i]})  oracle ({of[i]!r}, {orr[i]!r}, {oit[i]})")
     print(f"set {s_i:3d} H={H:2d} n={m:5d} bounds kind {kind} eps {eps:.1e} cap {cap:5d} smo {smo:3d} "
-          f"mean iters {oit.mean():7.1f}: mismatching instances {mism}", flush=True)
+          f"mean iters {oit.mean():7.1f}: mismatching instances {mism}"
+          + (f" (+{wild_counts} overflowing instances whose iteration count differs, outputs equal)" if wild_counts else ""), flush=True)
 print(f"{sets} parameter sets, total mismatches {bad}, {time.time() - t_start:.0f} s")
 sys.exit(1 if bad else 0)

@@ -79,6 +79,10 @@ typedef enum tpc_mpc_algo { TPC_MPC_ALGO_AUTO = 0, TPC_MPC_ALGO_WAVE = 1, TPC_MP
                                         start point like dlib does (every NaN comparison is
                                         false, mpc.h:298-311) and this flag is raised           */
 #define TPC_MPC_FLAG_MAX_ITER  0x2u  /* an instance stopped on max_iter, not on eps             */
+/*   (compact form, absurd speeds only -- |step_size * v| beyond 1e4 in fp32, 1e60 in fp64, where dlib's own
+ *    intermediates overflow: dlib can stop early on an all-NaN gradient (its 0 * inf products) where these
+ *    kernels keep +-inf and run to max_iter with the same controls; outputs agree, the iteration count and
+ *    this flag may not.  DESIGN.md section 4.1.)                                                          */
 #define TPC_MPC_FLAG_BAD_MODEL 0x4u  /* general form: an instance's Q, R or bounds break dlib's
                                         requires clause (mpc_abstract.h:90-97; min(Q) >= 0,
                                         min(R) > 0, upper >= lower).  dlib asserts (compiled out in

@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=262144, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=20)
-    ap.add_argument("--algo", default="auto", choices=["auto", "lane", "wave"])
+    ap.add_argument("--algo", default="auto", choices=["auto", "lane", "lane_fma", "wave"])
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
@@ -282,7 +282,7 @@ def main():
         torch.cuda.synchronize()
         mean_iters = float(iters_t.double().mean().item())
         lane_stats = None
-        if algo_ran == 2:
+        if algo_ran in (2, 3):
             wi, rb = solver.last_lane_stats()
             pg_iters = float((iters_t.double() - 50.0).clamp(min=0).sum().item())
             lane_stats = {"wave_iterations": wi, "refill_blocks": rb,
@@ -292,7 +292,8 @@ def main():
         value = total / elapsed
         # dominant kernel = the longer of the two launches of a step
         dom_ms = max(k1, k2)
-        dom_name = {1: "wave_kernel", 2: "lane_pg_fused_kernel" if k2 >= k1 else "lane_cd_kernel"}[algo_ran]
+        dom_name = {1: "wave_kernel", 2: "lane_pg_fused_kernel" if k2 >= k1 else "lane_cd_kernel",
+                    3: "ub_pg_kernel" if k2 >= k1 else "ub_cd_kernel"}[algo_ran]
         alg_bytes = 5 * esz * n                       # 3 in + 2 out scalars per solve
         # the PG kernel also reads what the CD kernel left per instance (not algorithmic traffic)
         hbm_gbs = alg_bytes / (dom_ms * 1e-3) / 1e9
@@ -314,7 +315,7 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"batch {n} trajectories per GPU, N={H}, 2 inputs, compact "
                                    f"(mpcControllerTobi) form, cold start, eps 0.01, max_iter 10000",
-                       "global_batch": world * n, "horizon": H, "algo": {1: "wave", 2: "lane"}[algo_ran],
+                       "global_batch": world * n, "horizon": H, "algo": {1: "wave", 2: "lane", 3: "lane_fma"}[algo_ran],
                        "parallelism": f"batch-sharded x{world}", "batches_in_flight": slots,
                        "gather": gather_path, "gather_verified": gather_ok},
             "build": MpcSolver.build_info(),

@@ -69,10 +69,24 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
  *   LANE : one lane per instance, dlib's O(H) recurrences unrolled in registers, 64 instances
  *          per wavefront with dynamic refill of finished lanes.  Bit-identical to the reference
  *          arithmetic in fp64; highest throughput on large batches.
- *   AUTO : WAVE below a measured crossover (on a 256-CU part: 32 768 instances, the largest batch the
- *          WAVE work queue takes, in fp64 with I*H <= 32 and from N = 20 up; about 29 000 in fp32 below
- *          N = 20; 19 456 at N = 40 with two inputs), LANE from there up. */
-typedef enum tpc_mpc_algo { TPC_MPC_ALGO_AUTO = 0, TPC_MPC_ALGO_WAVE = 1, TPC_MPC_ALGO_LANE = 2 } tpc_mpc_algo;
+ *   LANE_FMA : LANE's layout (one lane per instance, persistent wavefronts, refill queue) with the
+ *          arithmetic rebuilt for the hardware instead of for dlib's rounding: controls in unit-box
+ *          coordinates (dlib's clamp is the free [0,1] output clamp of the instruction that produces the
+ *          value), fused multiply-adds, and the linear term folded into the backward recurrence (nothing
+ *          of the model in memory): about half of LANE's instructions per iteration.  Same iteration and
+ *          the same decisions as dlib on quantities that differ by rounding: max |du| vs dlib ~2e-13 at
+ *          N = 20, ~1e-12 at N = 40, iteration counts identical on the BASELINE workloads (they can differ
+ *          only where dlib's largest gradient component comes within rounding of eps).  Compact form
+ *          (solve_batch_compact, _mixed, _sharded, follow_batch) with hi > lo finite, specialised
+ *          horizons; requests it cannot take (general form, degenerate bounds, other horizons) run LANE.
+ *   AUTO : the fastest family that meets the 1e-6 parity target: WAVE below a measured crossover (on a
+ *          256-CU part: 32 768 instances, the largest batch the WAVE work queue takes, in fp64 with
+ *          I*H <= 32 and from N = 20 up; about 29 000 in fp32 below N = 20; 19 456 at N = 40 with two
+ *          inputs), from there up LANE_FMA for the compact form and LANE for the general form.  A host
+ *          that needs dlib's bits asks for LANE. */
+typedef enum tpc_mpc_algo {
+    TPC_MPC_ALGO_AUTO = 0, TPC_MPC_ALGO_WAVE = 1, TPC_MPC_ALGO_LANE = 2, TPC_MPC_ALGO_LANE_FMA = 3
+} tpc_mpc_algo;
 
 /* Non-fatal per-call flags, OR-ed into *flags_out (may be NULL). */
 #define TPC_MPC_FLAG_NONFINITE 0x1u  /* an instance had NaN/Inf inputs: it returns the untouched

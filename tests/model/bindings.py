@@ -1,0 +1,61 @@
+"""tests/model/bindings.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+ctypes binding of the CPU model of the LANE_FMA kernel family (tests/model/ub_model.cpp): the same
+IEEE operations as the gfx950 kernels of that family, so GPU results are compared with it bit for bit.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MODEL_SO = os.path.join(_HERE, "libub_model.so")
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+_SRCS = [os.path.join(_HERE, "ub_model.cpp"),
+         os.path.join(_ROOT, "trajectory_controller_amd", "csrc", "mpc_ub_model.h")]
+
+ALPHA_MAX = 22.0 * np.pi / 180.0
+DEFAULT_WEIGHTS = (20.0, 7.0, 0.0005, 10.0)
+
+
+def build_model(force: bool = False) -> str:
+    stale = (not os.path.exists(MODEL_SO)) or any(
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(MODEL_SO) for p in _SRCS)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libub_model.so"], stdout=subprocess.DEVNULL)
+    return MODEL_SO
+
+
+class UbModel:
+    def __init__(self, dtype: str = "f64"):
+        build_model()
+        self.dtype = dtype
+        self.np = {"f64": np.float64, "f32": np.float32}[dtype]
+        self.lib = C.CDLL(MODEL_SO)
+        rp = C.POINTER(C.c_double if dtype == "f64" else C.c_float)
+        self._rp = rp
+        self.fn = getattr(self.lib, f"ub_model_solve_compact_{dtype}")
+        self.fn.restype = C.c_int
+        self.fn.argtypes = [C.c_int, C.c_long, C.c_int, rp, rp, rp, rp, C.c_double, C.c_double, rp, rp,
+                            C.c_double, C.c_ulong, C.c_ulong, C.c_int, rp, rp, C.POINTER(C.c_int),
+                            C.POINTER(C.c_uint)]
+
+    def solve_compact(self, H, v, dy, dphi, weights=DEFAULT_WEIGHTS, T=0.1, l=0.21,
+                      lo=(-ALPHA_MAX, -ALPHA_MAX), hi=(ALPHA_MAX, ALPHA_MAX), eps=0.01, max_iter=10000,
+                      smo_iters=50, nthreads=1, fast_stop=True):
+        a = lambda z: np.ascontiguousarray(z, dtype=self.np)
+        p = lambda z: z.ctypes.data_as(self._rp)
+        v, dy, dphi, w, lo, hi = a(v), a(dy), a(dphi), a(weights), a(lo), a(hi)
+        n = v.shape[0]
+        front, rear = np.empty(n, dtype=self.np), np.empty(n, dtype=self.np)
+        iters = np.empty(n, dtype=np.int32)
+        flags = C.c_uint(0)
+        rc = self.fn(H, n, nthreads, p(v), p(dy), p(dphi), p(w), T, l, p(lo), p(hi), eps, max_iter, smo_iters,
+                     1 if fast_stop else 0, p(front), p(rear), iters.ctypes.data_as(C.POINTER(C.c_int)),
+                     C.byref(flags))
+        if rc != 0:
+            raise ValueError(f"ub model: unsupported H={H}")
+        return front, rear, iters, flags.value

@@ -1,0 +1,70 @@
+"""CPU tests (`-m "not gpu"`) of the CPU model of the LANE_FMA kernel family (tests/model/): the model
+is what the GPU tests compare that family with bit for bit, so it is itself held against the pinned
+oracle and the real-dlib golden vectors here.
+
+Tolerance of the family (and therefore of its model), stated once:
+  |du| <= 1e-9 absolute against dlib (bounds are +-0.384; observed <= 3e-13 up to N = 30, 1.3e-12 at
+  N = 40) and IDENTICAL iteration counts on the fixtures and the seeded sets below.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+UB_ATOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def model():
+    from tests.model.bindings import UbModel
+    return UbModel()
+
+
+@pytest.mark.parametrize("H", [4, 5, 10, 20, 40])
+def test_model_vs_real_dlib_fixtures(model, H):
+    g = load_golden(f"compact_H{H}.npz")
+    f, r, it, flags = model.solve_compact(H, g["v"], g["dy"], g["dphi"], nthreads=8)
+    assert flags & 1 == 0
+    assert max(np.abs(f - g["front"]).max(), np.abs(r - g["rear"]).max()) <= UB_ATOL
+    known = g["iters_lb"] >= 0
+    assert np.all(it[known] >= g["iters_lb"][known])
+
+
+@pytest.mark.parametrize("H,n", [(4, 6000), (10, 3000), (20, 1500), (30, 400)])
+@pytest.mark.parametrize("fast", [True, False])
+def test_model_vs_oracle_iters(model, oracle, H, n, fast):
+    from trajectory_controller_amd.synth import compact_inputs
+    v, dy, dphi = compact_inputs(H, n, first=300000)
+    of, orr, oit = oracle.solve_compact(H, v, dy, dphi, nthreads=8)
+    f, r, it, _ = model.solve_compact(H, v, dy, dphi, nthreads=8, fast_stop=fast)
+    assert np.array_equal(it, oit)
+    assert max(np.abs(f - of).max(), np.abs(r - orr).max()) <= UB_ATOL
+    # a control dlib leaves on a bound is on the bound here, bit for bit
+    A = 22.0 * np.pi / 180.0
+    assert np.array_equal(np.abs(of) == A, np.abs(f) == A) and np.array_equal(np.abs(orr) == A, np.abs(r) == A)
+
+
+def test_model_knobs_and_edges(model, oracle):
+    g = load_golden("compact_knobs_H10.npz")
+    f, r, it, _ = model.solve_compact(10, g["v"], g["dy"], g["dphi"], eps=float(g["eps"]),
+                                      max_iter=int(g["max_iter"]), nthreads=4)
+    assert max(np.abs(f - g["front"]).max(), np.abs(r - g["rear"]).max()) <= UB_ATOL and it.max() <= 300
+    e = load_golden("compact_edge.npz")
+    for H in (4, 20):
+        f, r, it, flags = model.solve_compact(H, e["v"], e["dy"], e["dphi"])
+        assert np.nanmax(np.abs(f - e[f"front_H{H}"])) <= UB_ATOL and np.nanmax(np.abs(r - e[f"rear_H{H}"])) <= UB_ATOL
+        assert np.all(f[:4] == 0) and np.all(r[:4] == 0) and np.all(it[:4] == 0) and flags & 1
+
+
+@pytest.mark.parametrize("lo,hi", [((-0.3, -0.2), (0.25, 0.4)), ((0.05, -0.3), (0.3, -0.1)), ((-1e-3, -0.5), (2e-3, 0.5))])
+def test_model_other_bounds(model, oracle, lo, hi):
+    """Unequal bounds (the build with the extra addition per step) and boxes that do not contain the
+    start point u = 0 (exact stop test: the screen of the fast one refuses them)."""
+    from trajectory_controller_amd.synth import compact_inputs
+    H, n = 10, 1500
+    v, dy, dphi = compact_inputs(H, n, first=7000)
+    of, orr, oit = oracle.solve_compact(H, v, dy, dphi, lo=lo, hi=hi, nthreads=8)
+    inside = all(l <= 0 <= h for l, h in zip(lo, hi))
+    f, r, it, _ = model.solve_compact(H, v, dy, dphi, lo=lo, hi=hi, nthreads=8, fast_stop=inside)
+    assert np.array_equal(it, oit)
+    assert max(np.abs(f - of).max(), np.abs(r - orr).max()) <= UB_ATOL

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("TPC_MPC_LIB") or os.path.join(_HERE, "lib", "libtpc_m
 OK = 0
 F64, F32 = 0, 1
 HOST, DEVICE = 0, 1
-ALGO_AUTO, ALGO_WAVE, ALGO_LANE = 0, 1, 2
+ALGO_AUTO, ALGO_WAVE, ALGO_LANE, ALGO_LANE_FMA = 0, 1, 2, 3
 FLAG_NONFINITE, FLAG_MAX_ITER, FLAG_BAD_MODEL = 0x1, 0x2, 0x4
 
 STATUS_NAMES = {0: "OK", 1: "BAD_ARG", 2: "BAD_WEIGHTS", 3: "BAD_BOUNDS", 4: "BAD_HORIZON",

@@ -76,7 +76,7 @@ constexpr int64_t kQueueTicketBytes = (int64_t)kQueueTickets * kQueueTicketStrid
 constexpr int64_t kWaveQueueMaxInstances = 32768;   // what one wave_order_kernel workgroup sorts (mpc_wave.h)
 
 // mpc_generic.hip: the any-horizon fallback (run-time H, per-instance arrays in a global workspace)
-constexpr int kAlgoGeneric = 3;   // internal kernel-family code next to TPC_MPC_ALGO_WAVE / _LANE
+constexpr int kAlgoGeneric = 100;   // internal kernel-family code next to TPC_MPC_ALGO_WAVE / _LANE / _LANE_FMA
 constexpr int kMaxHorizon = 64;
 int64_t generic_scratch_bytes(int H, int dtype, int64_t n);
 hipError_t generic_compact(int dtype, int H, const CompactArgs& a, const Knobs& k, void* scratch, hipStream_t s);

@@ -1,0 +1,455 @@
+// LANE_FMA kernels: one lane per MPC instance like the LANE family (mpc_lane.h), in the unit-box /
+// fused-multiply-add arithmetic of mpc_ub_model.h -- the tolerance-grade throughput family.
+//
+// Same three launches per batch and the same scratch as LANE (records, queue keys, counting sort,
+// ticket): ub_cd_kernel (coordinate descent, mpc.h:319-335), the queue order (mpc_sort.hip),
+// ub_pg_kernel (accelerated projected gradient with lane refill, mpc.h:336-345).  What differs is
+// the arithmetic: an iteration of the projected-gradient kernel is ~25 VALU instructions per
+// horizon step instead of 49 (see mpc_ub_model.h for why), nothing of the model lives in memory
+// any more (no linear term MM), and the only LDS traffic left is dlib's momentum vector v.
+// Compact model only (the general form keeps the LANE family).
+//
+// Results: identical decisions on quantities that differ from dlib's by rounding: max |du| vs dlib
+// ~2e-13 at N = 20 (1e-12 at N = 40), identical iteration counts on every instance of the BASELINE
+// workloads; bit-identical to the CPU model tests/model/ub_model.cpp.
+#pragma once
+
+#include "mpc_lane.h"
+#include "mpc_ub_model.h"
+
+namespace tpc {
+
+// Screen of the fast stop test (per instance; one failing instance sends the batch through the
+// exact build, like LANE).  Needed: no intermediate can overflow or be NaN, the start point u = 0
+// lies inside the box, and a projected step that vanishes in rounding implies |df| < eps:
+// lambda * s * 2^-50 < eps (mpc_ub_model.h; fp32: finiteness only, its test keeps dlib's mask).
+// fp64 magnitudes with |a|,|c|,|target| <= 1e50, q <= 1e30, r <= 1e100, s,|bound| <= 1e10, H <= 40:
+// |Y| <= 4e61, |Z| <= 2e113, |N0| <= 7e144, |N1| <= 3e196, |df| <= 3e246.
+template <typename T, bool EQB>
+TPC_DEV bool ub_fast_stop_ok(const ub::Unit<T, EQB>& m, T ty, T tphi, T q0, T q1, T r0, T r1, T eps, T lambda) {
+    constexpr bool D = sizeof(T) == 8;
+    constexpr T kAl = (T)(D ? 1e50 : 1e3), kQ = (T)(D ? 1e30 : 1e3), kR = (T)(D ? 1e100 : 1e10);
+    constexpr T kS = (T)(D ? 1e10 : 1e2), kEpsLo = (T)(D ? 1e-60 : 1e-10), kEpsHi = (T)(D ? 1e30 : 1e10);
+    const T smax = tmax(m.s0, m.s1);
+    bool ok = tabs(m.a) <= kAl && tabs(m.c) <= kAl && tabs(ty) <= kAl && tabs(tphi) <= kAl;
+    ok = ok && tabs(q0) <= kQ && tabs(q1) <= kQ && tabs(r0) <= kR && tabs(r1) <= kR;
+    ok = ok && smax <= kS && tabs(m.lo0) <= kS && tabs(m.lo1) <= kS && tabs(m.hi0) <= kS && tabs(m.hi1) <= kS;
+    ok = ok && m.xz0 >= (T)0 && m.xz0 <= (T)1 && m.xz1 >= (T)0 && m.xz1 <= (T)1;
+    ok = ok && eps >= kEpsLo && eps <= kEpsHi;
+    if (D) ok = ok && lambda * smax * (T)0x1p-50 < eps;
+    else ok = ok && lambda <= (T)1e30;
+    return ok;
+}
+
+template <typename T, bool EQB> TPC_DEV void ub_set_uniform(ub::Unit<T, EQB>& m, T gscale, const CompactArgs& g) {
+    const T q[2] = {(T)g.q[0], (T)g.q[1]}, r[2] = {(T)g.r[0], (T)g.r[1]};
+    const T lo[2] = {(T)g.lo[0], (T)g.lo[1]}, hi[2] = {(T)g.hi[0], (T)g.hi[1]};
+    m.set_uniform(gscale, q, r, lo, hi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Phase 1: coordinate descent, 64 instances per wave in lockstep (see lane_cd_kernel).  Only the
+// reciprocals 1 / (Q_diag s) sit in LDS ([var][lane], read at the arg-max's index).
+template <typename T, int H, bool EQB>
+__global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void ub_cd_kernel(CompactArgs g, Knobs kn, T* __restrict__ recs,
+                                                                         uint32_t* __restrict__ keys,
+                                                                         uint32_t* __restrict__ key_rank,
+                                                                         uint32_t* __restrict__ key_hist,
+                                                                         unsigned long long* __restrict__ stats) {
+    constexpr int RL = LaneRec<T, H>::kLen;
+    __shared__ T s_iqd[2 * H][kWave];
+    const int lane = threadIdx.x;
+    const int64_t k = (int64_t)blockIdx.x * kWave + lane;
+    if (k >= g.n) return;
+
+    ub::Unit<T, EQB> m;
+    ub_set_uniform(m, (T)1, g);
+    const T ty = ((const T*)g.dy)[k], tphi = ((const T*)g.dphi)[k];
+    m.set_instance((T)g.step, (T)g.wheelbase, ((const T*)g.v)[k], ty, tphi);
+    const bool nonfinite = m.nonfinite_inputs(ty, tphi);
+    const T q0 = (T)g.q[0], q1 = (T)g.q[1], r0 = (T)g.r[0], r1 = (T)g.r[1];
+
+    T x[2 * H], w[2 * H];
+#pragma unroll
+    for (int i = 0; i < H; ++i) { x[2 * i] = m.xz0; x[2 * i + 1] = m.xz1; }
+    const T lambda = ub::ctor_lambda_qdiag<T, H>(m.a, m.c, q0, q1, r0, r1, [&](int i, int j, T val) {
+        s_iqd[2 * i + j][lane] = val != (T)0 ? (T)1 / (val * m.s(j)) : (T)0;   // mpc.h:322: a zero Q_diag never updates
+    });
+    const T eps = (T)kn.eps;
+    {
+        const unsigned long long failing = __ballot(!ub_fast_stop_ok(m, ty, tphi, q0, q1, r0, r1, eps, lambda));
+        if (failing != 0ull && lane == __ffsll((long long)failing) - 1) atomicOr(&stats[2], 1ull);
+    }
+    const uint32_t cd_iters = kn.smo_iters < kn.max_iter ? kn.smo_iters : kn.max_iter;
+    uint32_t iter = 0;
+    bool stopped = nonfinite;
+    bool vinit = false;
+#pragma unroll 1
+    for (uint32_t it = 0; it < cd_iters; ++it) {
+        if (__ballot(!stopped) == 0ull) break;
+        // gradient (mpc.h:275-283 in unit coordinates): w <- (Z, Y) forward, then df backward
+        T Z, Y;
+        m.fwd_init(Z, Y);
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            m.fwd(Z, Y, x[2 * i], x[2 * i + 1]);
+            w[2 * i] = Z; w[2 * i + 1] = Y;
+        }
+        T n0, n1;
+        m.bwd_last(n0, n1, Z, Y);
+#pragma unroll
+        for (int i = H - 1; i >= 0; --i) {
+            if (i < H - 1) m.bwd(n0, n1, w[2 * i], w[2 * i + 1]);
+            w[2 * i] = m.df0(n1, x[2 * i]);
+            w[2 * i + 1] = m.df1(n0, n1, x[2 * i + 1]);
+        }
+        // arg-max |df| over free variables, i then j, strict '>' (mpc.h:289-309), as selects
+        T max_df = (T)0, best_x = (T)0;
+        int best = 0, best_sign = 0;
+#pragma unroll
+        for (int q = 0; q < 2 * H; ++q) {
+            const T xx = x[q], dd = w[q];
+            const T up = (xx <= (T)0) ? (T)0 : dd;
+            const T dn = (xx >= (T)1) ? (T)0 : -dd;
+            const T mag = tmax(up, dn);
+            const bool better = mag > max_df;
+            max_df = tmax(max_df, mag);
+            best = better ? q : best;
+            best_sign = better ? sign_word(dd) : best_sign;
+            best_x = better ? xx : best_x;
+        }
+        if (!stopped && max_df < eps) stopped = true;           // mpc.h:310-311
+        if (!stopped) {
+            const T best_df = with_sign(max_df, best_sign);
+            const T iq = s_iqd[best][lane];
+            if (iq != (T)0) {                                   // mpc.h:322 (`continue` still counts)
+                const T nx = ub::clamp01(ub::fma_(-iq, best_df, best_x));   // mpc.h:325-326
+#pragma unroll
+                for (int q = 0; q < 2 * H; ++q) x[q] = (q == best) ? nx : x[q];
+                vinit = (it + 1 == kn.smo_iters);               // mpc.h:330-334
+            }
+            ++iter;
+        }
+    }
+
+    T* rec = recs + (int64_t)k * RL;
+#pragma unroll
+    for (int q = 0; q < 2 * H; ++q) rec[q] = x[q];
+    rec[2 * H] = lambda;
+    uint64_t meta = (uint64_t)iter;
+    if (stopped) meta |= kMetaStopped;
+    if (vinit) meta |= kMetaVInit;
+    if (nonfinite) meta |= kMetaNonFinite;
+    store_meta<T>(rec + 2 * H + 1, meta);
+    // queue key: as lane_cd_kernel (longest first by lambda, the floor rule, finished instances last)
+    const bool finished = stopped || iter >= kn.max_iter;
+    const T lambda_floor = (r0 + r1) * (T)H;
+    const bool uninformative = lambda < (T)1.5 * lambda_floor;
+    const float lf = g.work_hint ? (float)(g.work_hint[k] > 0 ? g.work_hint[k] : 1) : (float)lambda;
+    const uint32_t spread = (uint32_t)k & 127u;
+    uint32_t key = __float_as_uint(lf);
+    if (finished) key = spread << 16;
+    else if (!g.work_hint && uninformative) key = (0x7f00u + spread) << 16;
+    else if (!(lf > 0.0f) || key < 0x00800000u) key = 0x00800000u;
+    else if (key >= 0x7f000000u) key = 0x7effffffu;
+    uint32_t f = 0;
+    if (finished) {   // complete: published here, the PG kernel's queue ends before these
+        ((T*)g.front)[k] = nonfinite ? (T)0 : m.control(0, x[0]);
+        ((T*)g.rear)[k] = nonfinite ? (T)0 : m.control(1, x[1]);
+        if (g.iters) g.iters[k] = (int32_t)iter;
+        if (nonfinite) f |= 0x1u;
+        if (!stopped) f |= 0x2u;
+    }
+    raise_flags(g.flags, f);
+    keys[k] = key;
+    key_rank[k] = atomicAdd(&key_hist[key >> 16], 1u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Phase 2: the fused projected-gradient kernel.  Structure and refill protocol are those of
+// lane_pg_fused_kernel (mpc_lane.h), where every design decision is explained; here only what differs.
+//
+// State of one instance: x (2H), the forward pass (Z, Y per step: 2H), dlib's momentum v (2H).
+// Where it lives (UbPlan): x always in VGPRs; the forward pass in VGPRs, or -- where x and it do
+// not both fit the 256 a VALU instruction can name -- checkpointed on the even steps in AGPRs
+// (odd steps recomputed in the backward pass, FusedCkpt in mpc_lane.h); v in VGPRs for the first KV
+// steps, in LDS beyond ([var][lane] columns, fetched one step ahead).
+#ifndef TPC_UB_OCC
+#define TPC_UB_OCC 0
+#endif
+#ifndef TPC_UB_KV
+#define TPC_UB_KV -1
+#endif
+template <typename T, int H> struct UbPlan {
+    static constexpr bool D = sizeof(T) == 8;
+    static constexpr int words = D ? 2 : 1;
+    // everything in registers: 6H values
+    static constexpr bool regs = 6 * H * words <= 200 || !D;
+    // waves per SIMD
+    static constexpr int occ_default = (6 * H * words <= 120) ? 2 : 1;
+    static constexpr int occ = TPC_UB_OCC > 0 ? TPC_UB_OCC : occ_default;
+    // forward pass checkpointed into AGPRs: x and w together exceed the VGPRs (fp64, H >= 30)
+    static constexpr bool ckpt = D && H >= 30;
+    // steps of v in VGPRs (the rest in LDS)
+    static constexpr int kv_default = regs ? H : (H == 20 ? 8 : 8);
+    static constexpr int kv = regs ? H : (TPC_UB_KV >= 0 ? TPC_UB_KV : kv_default);
+};
+#ifdef TPC_UB_EXIT_EVERY_STOP
+template <typename T, int H> struct UbExitEveryStop { static constexpr bool value = TPC_UB_EXIT_EVERY_STOP != 0; };
+#else
+template <typename T, int H> struct UbExitEveryStop { static constexpr bool value = false; };
+#endif
+#ifdef TPC_UB_REFILL_BATCH
+template <int H> struct UbRefillBatch { static constexpr int value = TPC_UB_REFILL_BATCH; };
+#else
+template <int H> struct UbRefillBatch { static constexpr int value = RefillBatch<H>::value; };
+#endif
+
+// an fma the optimiser cannot merge with an identical one elsewhere (checkpoint re-computation)
+TPC_DEV double fma_opaque(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+TPC_DEV float fma_opaque(float a, float b, float c) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+template <typename T, int H, bool EQB, bool FAST>
+__global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void ub_pg_kernel(
+    CompactArgs g, Knobs kn, const T* __restrict__ recs, const uint32_t* __restrict__ order,
+    uint32_t* __restrict__ ticket, unsigned long long* __restrict__ stats, const uint32_t* __restrict__ queue_len) {
+    using P = UbPlan<T, H>;
+    constexpr int RL = LaneRec<T, H>::kLen;
+    const int64_t n_queue = (int64_t)__builtin_nontemporal_load(queue_len);
+    {   // two builds, launched back to back; the coordinate-descent kernel's screen picked one
+        const bool need_exact = __builtin_nontemporal_load(&stats[2]) != 0ull;
+        if (need_exact == FAST) return;
+    }
+    constexpr int BT = kWave * P::occ;
+    constexpr bool CK = P::ckpt;
+    constexpr int KV = P::kv, VL = H - KV;
+    static_assert(!CK || H % 2 == 0, "checkpoints sit on the even steps");
+    __shared__ T s_all[VL > 0 ? 2 * VL : 1][BT];
+    T r_v[2 * KV + 1];
+    AgprWord a_w[CK ? H : 1];
+    const int lane = threadIdx.x;
+    auto v_put = [&](int q, T val) { if (q < 2 * KV) r_v[q] = val; else s_all[q - 2 * KV][threadIdx.x] = val; };
+    auto v_get = [&](int q) -> T { if (q < 2 * KV) return r_v[q]; else return s_all[q - 2 * KV][threadIdx.x]; };
+    T w[CK ? 1 : 2 * H];
+    // CK keeps the even steps only: (Z, Y) of step i (even) at a_w[i], a_w[i+1]
+    auto w_put = [&](int i, T Z, T Y) {
+        if constexpr (CK) { if ((i & 1) == 0) { agpr_put(a_w[i], Z); agpr_put(a_w[i + 1], Y); } }
+        else { w[2 * i] = Z; w[2 * i + 1] = Y; }
+    };
+    auto w_getz = [&](int i) -> T { if constexpr (CK) return agpr_get<T>(a_w[i]); else return w[2 * i]; };
+    auto w_gety = [&](int i) -> T { if constexpr (CK) return agpr_get<T>(a_w[i + 1]); else return w[2 * i + 1]; };
+
+    constexpr T gs = ub::GradScale<T>::g;
+    const T geps = gs * (T)kn.eps;
+    // fp32 FAST: dlib's mask as arithmetic -- (x - 0) * 2^100 and (1 - x) * 2^100 are zero exactly on
+    // the bound and beyond every admissible eps off it; |med3(df, -g_hi, g_lo)| is dlib's masked |df|
+    // wherever that is below eps.  fp64 FAST reads the mask off the projected step (mpc_ub_model.h).
+    constexpr bool MOVED = FAST && sizeof(T) == 8;
+    T huge = (T)0x1p100;
+    asm volatile("" : "+v"(huge));
+
+    ub::Unit<T, EQB> m;
+    ub_set_uniform(m, gs, g);
+    m.a = m.c = m.as1 = m.cs0 = m.cs1 = m.dlt = m.z0 = m.q1th = (T)0;
+    T x[2 * H];
+    T x0_prev[2] = {(T)0, (T)0};
+    T il[2] = {(T)0, (T)0}, beta = (T)0;
+    int64_t k = 0;
+    uint32_t iter = 0;
+    bool have = false, exhausted = false;
+    uint32_t flags = 0;
+    uint32_t wave_iters = 0, refills = 0;
+#pragma unroll
+    for (int q = 0; q < 2 * H; ++q) { x[q] = (T)0; v_put(q, (T)0); }
+#pragma unroll
+    for (int i = 0; i < H; ++i) w_put(i, (T)0, (T)0);
+
+    auto publish = [&](T a0, T a1, uint32_t it) {
+        ((T*)g.front)[k] = m.control(0, a0);
+        ((T*)g.rear)[k] = m.control(1, a1);
+        if (g.iters) g.iters[k] = (int32_t)it;
+    };
+
+#pragma unroll 1
+    while (true) {
+        // ---- refill: see lane_pg_fused_kernel
+        const unsigned long long want = __ballot(!have && !exhausted);
+        if (want != 0ull && (__popcll(want) >= UbRefillBatch<H>::value || __ballot(have) == 0ull)) {
+            ++refills;
+            const int wl = lane & (kWave - 1);
+            uint32_t first_ticket = 0;
+            if (wl == __ffsll((long long)want) - 1) first_ticket = atomicAdd(ticket, (uint32_t)__popcll(want));
+            first_ticket = (uint32_t)__shfl((int)first_ticket, __ffsll((long long)want) - 1);
+            if (!have && !exhausted) {
+                const uint32_t t = first_ticket + (uint32_t)__popcll(want & ((1ull << wl) - 1ull));
+                if ((int64_t)t >= n_queue) {
+                    exhausted = true;
+                } else {
+                    k = (int64_t)order[t];
+                    const T* rec = recs + k * RL;
+                    const T vk = ((const T*)g.v)[k], ty = ((const T*)g.dy)[k], tphi = ((const T*)g.dphi)[k];
+#pragma unroll
+                    for (int q = 0; q < 2 * H; ++q) x[q] = rec[q];
+                    const T lambda = rec[2 * H];
+                    const uint64_t meta = load_meta<T>(rec + 2 * H + 1);
+                    iter = (uint32_t)meta;
+                    if (meta & kMetaNonFinite) flags |= 0x1u;
+                    const bool vinit = (meta & kMetaVInit) != 0;   // mpc.h:330-334, else a fresh v = 0
+#pragma unroll
+                    for (int q = 0; q < 2 * H; ++q) v_put(q, vinit ? x[q] : m.xz(q & 1));
+                    m.set_instance((T)g.step, (T)g.wheelbase, vk, ty, tphi);
+                    if ((meta & kMetaStopped) || iter >= kn.max_iter) {
+                        // (the coordinate-descent kernel publishes these itself; kept for a queue that holds one)
+                        if (!(meta & kMetaStopped)) flags |= 0x2u;
+                        if (meta & kMetaNonFinite) { ((T*)g.front)[k] = (T)0; ((T*)g.rear)[k] = (T)0; if (g.iters) g.iters[k] = (int32_t)iter; }
+                        else publish(x[0], x[1], iter);
+                    } else {
+                        ub::pg_constants<T>(lambda, m.s0, m.s1, il[0], il[1], beta);   // mpc.h:342-343
+                        have = true;
+                    }
+                }
+            }
+        }
+        if (__ballot(have) == 0ull) {
+            if (__ballot(!exhausted) == 0ull) break;
+            continue;
+        }
+
+        bool stop = false, cap = false;
+#pragma unroll 1
+        do {
+        T pv[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) pv[(H - 1) & 1][j] = v_get(2 * (H - 1) + j);
+        // ---- forward pass
+        T Z, Y;
+        m.fwd_init(Z, Y);
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            m.fwd(Z, Y, x[2 * i], x[2 * i + 1]);
+            w_put(i, Z, Y);
+        }
+        // ---- backward pass fused with the stop test and the speculative update
+        x0_prev[0] = x[0]; x0_prev[1] = x[1];
+#ifndef TPC_UB_ACC_N
+#define TPC_UB_ACC_N 4
+#endif
+        constexpr int NA = TPC_UB_ACC_N;
+        T acc[NA];
+#pragma unroll
+        for (int z = 0; z < NA; ++z) acc[z] = (T)0;
+        T n0, n1;
+        m.bwd_last(n0, n1, Z, Y);
+        T cz = (T)0, cy = (T)0;   // CK: the checkpoint of step i-1 read at an odd step i, used again at step i-1
+        static_for<H>([&](auto ic) {
+            constexpr int i = H - 1 - decltype(ic)::value;
+            constexpr int cur = i & 1, nxt = (i - 1) & 1;
+            if constexpr (i > 0) {
+                static_for<2>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    pv[nxt][j] = v_get(2 * (i - 1) + j);
+                });
+            }
+#ifndef TPC_UB_NO_SCHED_BARRIER
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            if constexpr (CK) {
+                if constexpr (i < H - 1) {
+                    if constexpr (i % 2 == 1) {
+                        // (Z, Y) of step i again from the checkpoint of step i-1 and x[i], which this
+                        // step has not updated yet: the forward pass's own operations, opaque to CSE
+                        cz = w_getz(i - 1); cy = w_gety(i - 1);
+                        const T rz = fma_opaque(m.as1, x[2 * i + 1], fma_opaque(m.a, cy, cz));
+                        T ry = fma_opaque(m.cs0, x[2 * i], fma_opaque(-m.cs1, x[2 * i + 1], cy));
+                        if constexpr (!EQB) ry = ry + m.dlt;
+                        m.bwd(n0, n1, rz, ry);
+                    } else {
+                        m.bwd(n0, n1, cz, cy);
+                    }
+                } else {
+                    cz = w_getz(i - 1); cy = w_gety(i - 1);   // i = H-1 (odd): its own (Z, Y) went into bwd_last
+                }
+            } else {
+                if constexpr (i < H - 1) m.bwd(n0, n1, w_getz(i), w_gety(i));
+            }
+            T vn[2], st[2];
+            static_for<2>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                constexpr int q = 2 * i + j;
+                const T xx = x[q];
+                T dd;
+                if constexpr (j == 0) dd = m.df0(n1, xx); else dd = m.df1(n0, n1, xx);
+                vn[j] = ub::clamp01(ub::fma_(-il[j], dd, xx));                      // mpc.h:342
+                if constexpr (MOVED) {
+                    acc[(2 * i + j) % NA] = tmax(acc[(2 * i + j) % NA], tmin(tabs(dd), tabs(xx - vn[j])));
+                } else if constexpr (FAST) {
+                    const T g_lo = xx * huge;
+                    const T g_hi = ub::fma_(-huge, xx, huge);
+                    st[j] = (T)med3_neglo((float)dd, (float)g_hi, (float)g_lo);
+                    if constexpr (j == 1) acc[i % NA] = (T)max3_abs((float)acc[i % NA], (float)st[0], (float)st[1]);
+                } else {
+                    const T up = (xx <= (T)0) ? (T)0 : dd;                          // mpc.h:298-299
+                    const T dn = (xx >= (T)1) ? (T)0 : -dd;
+                    acc[(2 * i + j) % NA] = tmax(acc[(2 * i + j) % NA], tmax(up, dn));
+                }
+                x[q] = ub::clamp01(ub::fma_(beta, vn[j] - pv[cur][j], vn[j]));       // mpc.h:343
+#ifndef TPC_UB_NO_UPIN
+                asm volatile("" : "+v"(x[q]));
+#endif
+            });
+            static_for<2>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                v_put(2 * i + j, vn[j]);
+            });
+        });
+        T max_df = acc[0];
+#pragma unroll
+        for (int z = 1; z < NA; ++z) max_df = tmax(max_df, acc[z]);
+        ++wave_iters;
+        stop = have && (max_df < geps);                                         // mpc.h:310-311
+        ++iter;
+        cap = have && !stop && iter >= kn.max_iter;                             // mpc.h:271
+        if constexpr (UbExitEveryStop<T, H>::value) {
+            if (__ballot(stop || cap) != 0ull) break;
+        } else if (__ballot(stop || cap) != 0ull) {
+            if (stop) {
+                publish(x0_prev[0], x0_prev[1], iter - 1);
+                have = false;
+            }
+            if (cap) {
+                flags |= 0x2u;
+                publish(x[0], x[1], iter);
+                have = false;
+            }
+            const unsigned long long waiting = __ballot(!have && !exhausted);
+            if (__popcll(waiting) >= UbRefillBatch<H>::value || __ballot(have) == 0ull) break;
+        }
+        } while (true);
+        if constexpr (UbExitEveryStop<T, H>::value) {
+            if (stop) {
+                publish(x0_prev[0], x0_prev[1], iter - 1);
+                have = false;
+            }
+            if (cap) {
+                flags |= 0x2u;
+                publish(x[0], x[1], iter);
+                have = false;
+            }
+        }
+    }
+    raise_flags(g.flags, flags);
+    if (stats && (lane & (kWave - 1)) == 0) {
+        atomicAdd(&stats[0], (unsigned long long)wave_iters);
+        atomicAdd(&stats[1], (unsigned long long)refills);
+    }
+}
+
+}  // namespace tpc

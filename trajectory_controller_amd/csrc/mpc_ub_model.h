@@ -1,0 +1,183 @@
+// Arithmetic of the LANE_FMA kernel family ("unit-box" form), shared by the gfx950 kernels
+// (mpc_ub.h) and by the CPU model the tests check them against bit for bit (tests/model/).
+//
+// What the family computes is dlib::mpc<2,2,H>::solve_linear_mpc for the compact model
+// (reference: dlib_files/dlib/control/mpc.h:253-347 driven as in
+// src/trajectory_point_follower.cpp:326-380) -- the same iteration: <= smo_iters coordinate-descent
+// steps on the arg-max free gradient component, then accelerated projected gradient with step
+// 1/lambda, stop when the largest free gradient component is < eps -- but NOT in dlib's operation
+// order.  It is the tolerance-grade sibling of the bit-exact LANE family: every decision dlib takes
+// is taken on the same quantity, the quantities differ from dlib's by rounding (~1e-14 on the
+// BASELINE workloads), and an iteration count can differ only where dlib's max|df| comes within
+// that rounding of eps.  Three changes buy ~half the instructions of an iteration:
+//
+//   1. controls in unit-box coordinates   u_j = lo_j + s_j * x_j,  s_j = hi_j - lo_j,  0 <= x_j <= 1.
+//      dlib's three-argument clamp (matrix_utilities.h:2835-2846) becomes the [0,1] output clamp
+//      that every gfx950 VOP3 instruction carries for free, so both clamps of mpc.h:342-343 cost
+//      nothing; "u sits on a bound" (mpc.h:298-299) is x == 0 or x == 1, exactly.
+//   2. fused multiply-adds everywhere (the reference binary has none).
+//   3. no stored linear term.  dlib precomputes MM = trans(K) Q (M0 - target) (mpc.h:258-266) and
+//      adds it to every gradient; by linearity the same gradient comes out of ONE backward pass
+//      driven by the predicted state ERROR  E[i] = M[i] - target  (x0 = 0, C = 0 for this model,
+//      so dlib's M0[i] is zero), at one extra subtraction per step and no memory at all.
+//
+// With Z[i] = M[i](0) - ty, Y[i] = M[i](1) + lo1 (the shift absorbs B*lo into the recurrence):
+//   forward   Z[i] = fma(a s1, x[i](1), fma(a, Y[i-1], Z[i-1]))            Z[-1] = -ty
+//             Y[i] = fma(c s0, x[i](0), fma(-c s1, x[i](1), Y[i-1])) (+ c (lo0 - lo1))   Y[-1] = lo1
+//   backward  N0[i] = fma(g q0, Z[i], N0[i+1])
+//             N1[i] = fma(a, N0[i+1], N1[i+1]) + fma(g q1, Y[i], -g q1 (lo1 + tphi))
+//   gradient  df[i](0) = fma(c, N1[i], fma(g r0 s0, x[i](0), g r0 lo0))
+//             df[i](1) = fma(a, N0[i], fma(-c, N1[i], fma(g r1 s1, x[i](1), g r1 lo1)))
+// g scales the whole gradient: 1 in the coordinate-descent phase, 2^-600 (fp64) in the projected-
+// gradient phase, where it lets the stop test read "blocked" off the projected step with no extra
+// multiply: min(|g df|, |x - x_new|) is >= g eps exactly where dlib's masked |df| is >= eps (the
+// step of a free variable is |df| / (lambda s) >> g |df|; a blocked variable's is exactly 0).
+// 25 instructions per horizon step instead of the bit-exact family's 49.
+//
+// Everything is written with explicit fma / mul / add calls and compiled with -ffp-contract=off on
+// both sides, so the CPU model and the kernels execute the same IEEE operations.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define TPC_HD __host__ __device__ __forceinline__
+#else
+#define TPC_HD inline
+#endif
+
+namespace tpc {
+namespace ub {
+
+TPC_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+TPC_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+TPC_HD double abs_(double x) { return __builtin_fabs(x); }
+TPC_HD float abs_(float x) { return __builtin_fabsf(x); }
+TPC_HD double max_(double a, double b) { return __builtin_fmax(a, b); }
+TPC_HD float max_(float a, float b) { return __builtin_fmaxf(a, b); }
+TPC_HD double min_(double a, double b) { return __builtin_fmin(a, b); }
+TPC_HD float min_(float a, float b) { return __builtin_fminf(a, b); }
+TPC_HD double sqrt_(double x) { return __builtin_sqrt(x); }
+TPC_HD float sqrt_(float x) { return __builtin_sqrtf(x); }
+// [0,1] clamp in the operand order LLVM folds into the producing instruction's clamp bit
+template <typename T> TPC_HD T clamp01(T x) { return min_(max_(x, (T)0), (T)1); }
+
+// Gradient scale of the projected-gradient phase and its inverse (powers of two: exact).
+template <typename T> struct GradScale;
+template <> struct GradScale<double> {
+    static constexpr double g = 0x1p-600, inv_g = 0x1p600;
+};
+// fp32 has no room for such a scale (and its stop test keeps dlib's mask, see mpc_ub.h)
+template <> struct GradScale<float> {
+    static constexpr float g = 1.0f, inv_g = 1.0f;
+};
+
+// The compact model in unit-box coordinates.  EQB: both inputs share their bounds (the reference's
+// configuration, src/trajectory_point_follower.cpp:16-18), which drops one addition per step.
+template <typename T, bool EQB> struct Unit {
+    // uniform over a batch
+    T s0, s1, lo0, lo1, hi0, hi1;
+    T xz0, xz1;                               // u = 0 (dlib's start point, mpc.h:110) in unit coordinates
+    T gq0, gq1, grs0, grs1, grl0, grl1;       // g q, g r s, g r lo
+    // per instance
+    T a, c, as1, cs0, cs1, dlt, z0, q1th;
+
+    TPC_HD T s(int j) const { return j == 0 ? s0 : s1; }
+    TPC_HD T lo(int j) const { return j == 0 ? lo0 : lo1; }
+    TPC_HD T hi(int j) const { return j == 0 ? hi0 : hi1; }
+    TPC_HD T xz(int j) const { return j == 0 ? xz0 : xz1; }
+
+    // q, r, lo, hi: dlib's Q, R, lower, upper (src/trajectory_point_follower.cpp:359-363, :16-18)
+    TPC_HD void set_uniform(T g, const T* q, const T* r, const T* lo, const T* hi) {
+        lo0 = lo[0]; lo1 = lo[1]; hi0 = hi[0]; hi1 = hi[1];
+        s0 = hi0 - lo0; s1 = hi1 - lo1;
+        xz0 = ((T)0 - lo0) / s0; xz1 = ((T)0 - lo1) / s1;
+        gq0 = g * q[0]; gq1 = g * q[1];
+        const T gr0 = g * r[0], gr1 = g * r[1];
+        grs0 = gr0 * s0; grs1 = gr1 * s1;
+        grl0 = gr0 * lo0; grl1 = gr1 * lo1;
+    }
+    // a = T v, c = T v / l  (src/trajectory_point_follower.cpp:327-330); target (ty, tphi) (:371)
+    TPC_HD void set_instance(T step, T wheelbase, T v, T ty, T tphi) {
+        a = step * v;
+        c = step * v / wheelbase;
+        as1 = a * s1; cs0 = c * s0; cs1 = c * s1;
+        dlt = c * (lo0 - lo1);
+        z0 = (T)0 - ty;
+        q1th = gq1 * (lo1 + tphi);
+    }
+    TPC_HD bool nonfinite_inputs(T ty, T tphi) const {
+        const T big = sizeof(T) == 8 ? (T)1.7976931348623157e308 : (T)3.4028234663852886e38;
+        return !(abs_(a) <= big && abs_(c) <= big && abs_(ty) <= big && abs_(tphi) <= big);
+    }
+    // forward pass, one step (mpc.h:275-277 in the coordinates above); (Z, Y) <- step i from step i-1
+    TPC_HD void fwd_init(T& Z, T& Y) const { Z = z0; Y = lo1; }
+    TPC_HD void fwd(T& Z, T& Y, T x0, T x1) const {
+        const T zn = fma_(as1, x1, fma_(a, Y, Z));
+        T yn = fma_(cs0, x0, fma_(-cs1, x1, Y));
+        if (!EQB) yn = yn + dlt;
+        Z = zn; Y = yn;
+    }
+    // backward pass (mpc.h:278-281): the last step, then one step
+    TPC_HD void bwd_last(T& n0, T& n1, T Z, T Y) const {
+        n0 = gq0 * Z;
+        n1 = fma_(gq1, Y, -q1th);
+    }
+    TPC_HD void bwd(T& n0, T& n1, T Z, T Y) const {
+        const T e1 = fma_(gq1, Y, -q1th);
+        const T t1 = fma_(a, n0, n1) + e1;
+        n0 = fma_(gq0, Z, n0);
+        n1 = t1;
+    }
+    // gradient components of one step (mpc.h:283)
+    TPC_HD T df0(T n1, T x0) const { return fma_(c, n1, fma_(grs0, x0, grl0)); }
+    TPC_HD T df1(T n0, T n1, T x1) const { return fma_(a, n0, fma_(-c, n1, fma_(grs1, x1, grl1))); }
+    // unit coordinate -> control; the bounds and the untouched start point come out exactly
+    TPC_HD T control(int j, T x) const {
+        return x == (T)1 ? hi(j) : (x == xz(j) ? (T)0 : fma_(s(j), x, lo(j)));
+    }
+};
+
+// dlib's constructor quantities for the compact model (mpc.h:116-123), in dlib's own operation order
+// (no fused operations): lambda, and through emit(i, j, value) Q_diag[i](j).
+template <typename T, int H, class Emit> TPC_HD T ctor_lambda_qdiag(T a, T c, T q0, T q1, T r0, T r1, Emit emit) {
+    // A = [1 a; 0 1], B = [0 a; c -c]
+    const T A[2][2] = {{(T)1, a}, {(T)0, (T)1}};
+    const T B[2][2] = {{(T)0, a}, {c, (T)0 - c}};
+    T lambda = (r0 + r1) * (T)H;
+    T t00 = q0, t01 = (T)0, t10 = (T)0, t11 = q1;
+    for (int cidx = 0; cidx < H; ++cidx) {
+        // W(r,:) = trans(B)(r,:) * T ; P(r,r) = W(r,:) * B(:,r)
+        auto diag = [&](T b0, T b1) {
+            const T w0 = b0 * t00 + b1 * t10;
+            const T w1 = b0 * t01 + b1 * t11;
+            return w0 * b0 + w1 * b1;
+        };
+        const T p0 = diag(B[0][0], B[1][0]), p1 = diag(B[0][1], B[1][1]);
+        emit(H - cidx - 1, 0, p0);
+        emit(H - cidx - 1, 1, p1);
+        const T tr = p0 + p1;
+        lambda = lambda + tr;
+        const T u00 = A[0][0] * t00 + A[1][0] * t10, u01 = A[0][0] * t01 + A[1][0] * t11;
+        const T u10 = A[0][1] * t00 + A[1][1] * t10, u11 = A[0][1] * t01 + A[1][1] * t11;
+        const T n00 = (u00 * A[0][0] + u01 * A[1][0]) + q0;
+        const T n01 = (u00 * A[0][1] + u01 * A[1][1]) + (T)0;
+        const T n10 = (u10 * A[0][0] + u11 * A[1][0]) + (T)0;
+        const T n11 = (u10 * A[0][1] + u11 * A[1][1]) + q1;
+        t00 = n00; t01 = n01; t10 = n10; t11 = n11;
+    }
+    return lambda;
+}
+
+// Step constants of the projected-gradient phase (mpc.h:342-343) in unit coordinates:
+// x_new = clamp01(x - il_j * (g df)),  il_j = 1 / (g lambda s_j);  beta = (sqrt(lambda)-1)/(sqrt(lambda)+1)
+template <typename T> TPC_HD void pg_constants(T lambda, T s0, T s1, T& il0, T& il1, T& beta) {
+    il0 = ((T)1 / (lambda * s0)) * GradScale<T>::inv_g;
+    il1 = ((T)1 / (lambda * s1)) * GradScale<T>::inv_g;
+    const T sq = sqrt_(lambda);
+    beta = (sq - (T)1) / (sq + (T)1);
+}
+
+}  // namespace ub
+}  // namespace tpc

@@ -14,6 +14,7 @@ namespace tpc {
     hipError_t lane_general_h##h(int, int, const GeneralArgs&, const Knobs&, const Workspace&, hipStream_t); \
     hipError_t wave_compact_h##h(int, const CompactArgs&, const Knobs&, const Workspace&, hipStream_t); \
     hipError_t wave_general_h##h(int, int, const GeneralArgs&, const Knobs&, const Workspace&, hipStream_t); \
+    hipError_t ub_compact_h##h(int, int, const CompactArgs&, const Knobs&, const Workspace&, hipStream_t); \
     int64_t lane_rec_len_h##h(int dtype);                                                          \
     const char* lane_build_h##h();
 TPC_DECL_H(4) TPC_DECL_H(5) TPC_DECL_H(10) TPC_DECL_H(20) TPC_DECL_H(30) TPC_DECL_H(40)
@@ -58,11 +59,14 @@ const int32_t* take_hint(tpc_mpc_context* h, int64_t n) {
 // wins at 32 768, the largest batch its work queue takes (5.4 against 6.9 ms), and loses without the queue beyond.
 // The WAVE kernel maps one decision variable to one lane, so it exists for I*H <= 64 only.
 // Returns the kernel family to run, or -1 when WAVE was demanded for a shape it cannot take.
-int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n, int dtype) {
+// `fma_ok`: the request is one the LANE_FMA family takes (compact form, usable bounds: fma_usable()).
+int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n, int dtype, bool fma_ok = false) {
     if (!horizon_specialised(H)) return algo == TPC_MPC_ALGO_WAVE ? -1 : kAlgoGeneric;
     const bool wave_ok = I * H <= kWave || (I == 2 && H <= kWave);   // (two variables per lane past 64)
+    const int lane = fma_ok ? TPC_MPC_ALGO_LANE_FMA : TPC_MPC_ALGO_LANE;   // the throughput family of AUTO
     if (algo == TPC_MPC_ALGO_WAVE) return wave_ok ? algo : -1;
     if (algo == TPC_MPC_ALGO_LANE) return algo;
+    if (algo == TPC_MPC_ALGO_LANE_FMA) return lane;
     const int64_t lanes = (int64_t)h->cu_count * 4 * kWave;
     // (N = 40 with two inputs: the two-variables-per-lane WAVE kernel against a LANE pass that lasts as long
     // as its slowest instance, 50 ms whatever the batch: 42.0 against 50.0 ms at 16 384, 62.4 against 49.9 at 24 576)
@@ -72,7 +76,15 @@ int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n, int d
     const bool paired = dtype == TPC_MPC_F64 && I * H <= kWave / 2;
     const int64_t crossover = I * H > kWave ? lanes * 19 / 64
                               : ((H >= 20 || paired) ? kWaveQueueMaxInstances + 1 : lanes * 7 / 16);
-    return (n >= crossover || !wave_ok) ? TPC_MPC_ALGO_LANE : TPC_MPC_ALGO_WAVE;
+    return (n >= crossover || !wave_ok) ? lane : TPC_MPC_ALGO_WAVE;
+}
+
+// The unit-box coordinates of the LANE_FMA family need a box: finite bounds with upper > lower (dlib
+// also accepts upper == lower, a pinned input: that goes to LANE).
+bool fma_usable(const tpc_mpc_params* p) {
+    for (int j = 0; j < 2; ++j)
+        if (!(std::isfinite(p->lower[j]) && std::isfinite(p->upper[j]) && p->upper[j] > p->lower[j])) return false;
+    return true;
 }
 
 int64_t lane_rec_len(int H, int dtype) {
@@ -95,6 +107,17 @@ template <class Launch> hipError_t generic_launch(const Workspace& ws, hipStream
 hipError_t dispatch_compact(int algo, int H, int dtype, const CompactArgs& a, const Knobs& k,
                             const Workspace& ws, hipStream_t s) {
     if (algo == kAlgoGeneric) return generic_launch(ws, s, [&] { return generic_compact(dtype, H, a, k, ws.state, s); });
+    if (algo == TPC_MPC_ALGO_LANE_FMA) {
+        // (compared in the arithmetic type: the kernels see the bounds rounded to it)
+        const bool eqb = dtype == TPC_MPC_F64 ? (a.lo[0] == a.lo[1] && a.hi[0] == a.hi[1])
+                                              : ((float)a.lo[0] == (float)a.lo[1] && (float)a.hi[0] == (float)a.hi[1]);
+        switch (H) {
+#define X(h) case h: return ub_compact_h##h(dtype, eqb ? 1 : 0, a, k, ws, s);
+            X(4) X(5) X(10) X(20) X(30) X(40)
+#undef X
+        }
+        return hipErrorInvalidValue;
+    }
     switch (H) {
 #define X(h) case h: return algo == TPC_MPC_ALGO_LANE ? lane_compact_h##h(dtype, a, k, ws, s) \
                                                        : wave_compact_h##h(dtype, a, k, ws, s);
@@ -141,7 +164,7 @@ int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n,
         ws->ticket = (uint32_t*)((char*)h->ws_state + pad256(n * 4));
         ws->capacity_bytes = h->ws_bytes;
     }
-    if (algo == TPC_MPC_ALGO_LANE) {
+    if (algo == TPC_MPC_ALGO_LANE || algo == TPC_MPC_ALGO_LANE_FMA) {
         // records | keys | rank | order | counting-sort bins
         const int64_t rec_b = pad256(lane_rec_len(H, dtype) * (int64_t)esize(dtype) * n);
         const int64_t col_b = pad256(n * 4);
@@ -187,7 +210,7 @@ int check_common(tpc_mpc_context* h, const tpc_mpc_params* p) {
     if (!horizon_ok(p->horizon))
         return fail(h, TPC_MPC_ERR_BAD_HORIZON, "horizon %d outside 1 .. %d", p->horizon, kMaxHorizon);
     if (p->dtype != TPC_MPC_F64 && p->dtype != TPC_MPC_F32) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad dtype");
-    if (p->algo < TPC_MPC_ALGO_AUTO || p->algo > TPC_MPC_ALGO_LANE) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad algo");
+    if (p->algo < TPC_MPC_ALGO_AUTO || p->algo > TPC_MPC_ALGO_LANE_FMA) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad algo");
     if (!(p->eps > 0)) return fail(h, TPC_MPC_ERR_BAD_EPS, "eps must be > 0 (mpc.h:202)");
     if (p->max_iter > 0x7fffffffull || p->smo_iters > 0x7fffffffull)
         return fail(h, TPC_MPC_ERR_BAD_ARG, "max_iter / smo_iters must fit in 31 bits");
@@ -244,7 +267,7 @@ int reserve_lane_workspace(tpc_mpc_context* h, int H, int dtype, int64_t n) {
 
 int compact_launch(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy,
                    const void* dphi, void* front, void* rear, int32_t* iters, hipStream_t s) {
-    const int algo = pick_algo(h, p->algo, 2, p->horizon, n, p->dtype);
+    const int algo = pick_algo(h, p->algo, 2, p->horizon, n, p->dtype, fma_usable(p));
     if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel exists for the specialised horizons with inputs*horizon <= 64 only; use LANE or AUTO");
     CompactArgs a;
     std::memset(&a, 0, sizeof(a));

@@ -35,7 +35,8 @@ class MpcSolver:
             raise capi.TpcMpcError(rc, self._lib.tpc_mpc_last_error(None).decode())
         self.device = int(device)
         self.dtype = {"f64": capi.F64, "f32": capi.F32}[dtype]
-        self.algo = {"auto": capi.ALGO_AUTO, "wave": capi.ALGO_WAVE, "lane": capi.ALGO_LANE}[algo]
+        self.algo = {"auto": capi.ALGO_AUTO, "wave": capi.ALGO_WAVE, "lane": capi.ALGO_LANE,
+                     "lane_fma": capi.ALGO_LANE_FMA}[algo]
         self.params = capi.default_params(horizon, self.dtype, self.algo, **params)
         self.last_flags = 0
         self.rank, self.world = 0, 1     # a handle without a communicator is a world of one

@@ -27,8 +27,13 @@ The default one-GPU run also times BASELINE config 2 (4 096 instances, N = 10, t
 under "config2".
 
 `value` is measured in fp64, the only dtype that meets the 1e-6 parity target (SURVEY.md section 0
-fact 3); the fp32 rate of the same workload is reported beside it under "fp32" with its error
-histogram against the fp64 result.  `roofline` prices the dominant kernel against HBM as the
+fact 3), through AUTO, i.e. the LANE_FMA family (unit-box coordinates, fused multiply-adds: dlib's
+iteration on quantities that differ from dlib's by rounding).  Its outputs are compared with real dlib
+run on the host in the same run ("max_abs_du_vs_dlib", "max_rel_du_vs_dlib": north_star's bar is 1e-6
+relative) and, over the whole batch, with the bit-exact LANE family ("vs_bit_exact": fraction of equal
+iteration counts, max |du|).  The bit-exact family's own rate is timed right after and reported under
+"bit_exact" (its outputs equal dlib's bit for bit).  The fp32 rate of the same workload is reported
+under "fp32" with its error histogram against the fp64 result.  `roofline` prices the dominant kernel against HBM as the
 contract asks (this path moves 40 B per solve, so that fraction is tiny by construction), and
 "alu" prices the same kernel against the FP64 vector peak with ALGORITHMIC flops
 ((46H-16) x mean iterations).  `cpu_baseline` is the real dlib path
@@ -68,6 +73,7 @@ def parse():
     ap.add_argument("--inflight", type=int, default=1, help="batches kept in flight (handle + stream each)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-batches-in-flight leg")
     ap.add_argument("--no-config2", action="store_true", help="skip the BASELINE config 2 leg (4 096 x N=10, WAVE)")
+    ap.add_argument("--no-bit-exact", action="store_true", help="skip the bit-exact LANE family leg")
     return ap.parse_args()
 
 
@@ -94,6 +100,16 @@ def usable_cores():
             continue
     env = os.environ.get("TPC_BENCH_CPU_THREADS")
     return int(env) if env else cores
+
+
+def library_sha256():
+    import hashlib
+    from trajectory_controller_amd import capi
+    path = os.environ.get("TPC_MPC_LIB", capi.LIB_PATH)
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()
+    except OSError:
+        return None
 
 
 def cpu_baseline(H, v, dy, dphi, budget_s):
@@ -267,6 +283,8 @@ def main():
         dist.all_reduce(local, op=dist.ReduceOp.SUM)
         whole = torch.stack([chk(front_all[0]), chk(rear_all[0])])
         gather_ok = bool(torch.equal(local, whole))
+        print(f"[bench] rank {rank}/{world}: instances [{rank * n}, {(rank + 1) * n}) of {n_total}; "
+              f"gather {'verified' if gather_ok else 'FAILED'} ({gather_path})", file=sys.stderr, flush=True)
     else:
         front, rear = fronts[0], rears[0]
         gather_ok = None
@@ -301,13 +319,22 @@ def main():
         tfl = alg_flops / (elapsed / a.steps) / 1e12                 # what a whole step delivers
         tfl_serial = alg_flops / ((s1 + s2) * 1e-3) / 1e12             # the two kernels on their own
         peak_tf = FP64_VECTOR_PEAK_TF if a.dtype == "f64" else FP32_VECTOR_PEAK_TF
-        traffic = None
+        # HBM bytes per launch of the dominant kernel from the PMC passes (scripts/profile.sh ->
+        # scripts/make_traffic.py).  rocprofv3 cannot run inside this process, so the figure is taken from
+        # profiles/traffic.json -- but only if that file was made from THIS binary (sha256 of the .so).
+        traffic, traffic_note = None, "no profiles/traffic.json entry for this kernel"
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):
             try:
-                traffic = json.load(open(tj)).get(f"{dom_name}_{a.dtype}_H{H}_n{n}")
-            except Exception:
-                traffic = None
+                tdata = json.load(open(tj))
+                entry = tdata.get(f"{dom_name}_{a.dtype}_H{H}_n{n}")
+                if entry is not None and tdata.get("_library_sha256") == library_sha256():
+                    traffic, traffic_note = entry, "PMC passes of this binary (profiles/traffic.json)"
+                elif entry is not None:
+                    traffic_note = ("profiles/traffic.json was measured on a different build of libtpc_mpc.so "
+                                    f"({entry} B per launch there): not reported for this binary")
+            except Exception as exc:   # noqa: BLE001
+                traffic_note = f"profiles/traffic.json unreadable: {exc}"
         out = {
             "metric": "MPC QP solves/sec (horizon N=20, 2 inputs) at 1/2/4/8 MI355X; max|du| vs dlib",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -323,7 +350,7 @@ def main():
             "kernel_ms_serial": {"first": s1, "second": s2},
             "mean_iterations": mean_iters, "lane_stats": lane_stats,
             "roofline": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "note": "40 B/solve algorithmic: this path is issue-bound, not HBM-bound; see alu"},
             "alu": {"bound": "fp64 vector issue" if a.dtype == "f64" else "fp32 vector issue",
                     "achieved": tfl, "peak": peak_tf, "unit": "TFLOP/s", "frac": tfl / peak_tf,
@@ -335,7 +362,41 @@ def main():
             gf, gr = front[:ns].cpu().numpy().astype(np.float64), rear[:ns].cpu().numpy().astype(np.float64)
             out["cpu_baseline"] = cb
             out["max_abs_du_vs_dlib"] = float(max(np.abs(gf - cf).max(), np.abs(gr - cr).max()))
+            # relative to dlib's own output (north_star: within 1e-6 rel); where dlib returns exactly 0 the
+            # absolute difference is taken against the bound's magnitude instead
+            den_f = np.where(cf != 0, np.abs(cf), 22 * np.pi / 180)
+            den_r = np.where(cr != 0, np.abs(cr), 22 * np.pi / 180)
+            out["max_rel_du_vs_dlib"] = float(max((np.abs(gf - cf) / den_f).max(), (np.abs(gr - cr) / den_r).max()))
+            out["dlib_sample"] = ns
             out["gpu_over_cpu"] = value / cb["value"]
+        if world == 1 and a.dtype == "f64" and algo_ran == 3 and not a.no_bit_exact:
+            # the bit-exact LANE family on the same K steps, and the whole batch of the two families side by side
+            with MpcSolver(horizon=H, device=local_rank, dtype="f64", algo="lane") as sl:
+                sl.set_profiling(True)
+                sl.reserve(n)
+                lf, lr = torch.empty_like(tv), torch.empty_like(tv)
+                for _ in range(max(1, a.warmup)):
+                    sl.solve_batch_compact(tv, ty, tp, out=(lf, lr), want_flags=False)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(a.steps):
+                    sl.solve_batch_compact(tv, ty, tp, out=(lf, lr), want_flags=False)
+                torch.cuda.synchronize()
+                dl = time.perf_counter() - t1
+                b1, b2, _ = sl.last_kernel_times()
+                _, _, lit = sl.solve_batch_compact(tv, ty, tp, want_iters=True)
+                torch.cuda.synchronize()
+            be = {"algo": "lane", "value": n * a.steps / dl, "unit": "solves/s", "ms_per_step": dl / a.steps * 1e3,
+                  "kernel_ms": {"first": b1, "second": b2},
+                  "alu_frac": alg_flops / (dl / a.steps) / 1e12 / peak_tf}
+            if not a.no_cpu:
+                lfc, lrc = lf[:ns].cpu().numpy(), lr[:ns].cpu().numpy()
+                be["max_abs_du_vs_dlib"] = float(max(np.abs(lfc - cf).max(), np.abs(lrc - cr).max()))
+            out["bit_exact"] = be
+            out["vs_bit_exact"] = {
+                "instances": n,
+                "iteration_counts_equal": float((iters_t == lit).double().mean().item()),
+                "max_abs_du": float(torch.maximum((front - lf).abs().max(), (rear - lr).abs().max()).item())}
         if world == 1 and slots == 1 and not a.no_pipelined:
             # the same K steps with two batches in flight (two handles, two streams): the next batch's
             # coordinate-descent kernel and queue sort run while the previous batch's last long instances
@@ -365,16 +426,26 @@ def main():
             s2.close()
         if not a.no_fp32 and a.dtype == "f64":
             s32 = MpcSolver(horizon=H, device=local_rank, dtype="f32", algo=a.algo)
+            s32.set_profiling(True)
+            s32.reserve(n)
             v32, y32, p32 = tv.float(), ty.float(), tp.float()
-            s32.solve_batch_compact(v32, y32, p32, want_flags=False)
+            f32, r32 = torch.empty_like(v32), torch.empty_like(v32)
+            for _ in range(max(1, a.warmup)):
+                s32.solve_batch_compact(v32, y32, p32, out=(f32, r32), want_flags=False)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(a.steps):
-                f32, r32 = s32.solve_batch_compact(v32, y32, p32, want_flags=False)
+                s32.solve_batch_compact(v32, y32, p32, out=(f32, r32), want_flags=False)
             torch.cuda.synchronize()
             d32 = time.perf_counter() - t1
+            c1, c2, c_algo = s32.last_kernel_times()
+            _, _, it32 = s32.solve_batch_compact(v32, y32, p32, want_iters=True)
             err = torch.maximum((f32.double() - front).abs(), (r32.double() - rear).abs())
             out["fp32"] = {"value": n * a.steps / d32, "unit": "solves/s (1 GPU)",
+                           "ms_per_step": d32 / a.steps * 1e3,
+                           "algo": {1: "wave", 2: "lane", 3: "lane_fma"}.get(c_algo, str(c_algo)),
+                           "kernel_ms": {"first": c1, "second": c2},
+                           "mean_iterations": float(it32.double().mean().item()),
                            "within": {str(t): float((err <= t).double().mean().item())
                                       for t in (1e-2, 1e-3, 1e-4, 1e-5, 1e-6)},
                            "max_abs_du_vs_fp64": float(err.max().item())}
@@ -400,6 +471,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+        if not gather_ok:
+            raise SystemExit(f"[bench] rank {rank}: the gathered outputs do not contain every rank's block")
 
 
 if __name__ == "__main__":

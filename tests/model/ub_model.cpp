@@ -52,14 +52,14 @@ void solve_one(T v, T ty, T tphi, const T* q, const T* r, double step, double wh
         T max_df = (T)0;
         int best = 0;
         for (int qv = 0; qv < 2 * H; ++qv) {       // mpc.h:289-309: i then j, strict '>'
-            const T up = (x[qv] <= (T)0) ? (T)0 : dd[qv];
-            const T dn = (x[qv] >= (T)1) ? (T)0 : -dd[qv];
+            const T up = (x[qv] <= m.bl(qv & 1)) ? (T)0 : dd[qv];
+            const T dn = (x[qv] >= m.bh(qv & 1)) ? (T)0 : -dd[qv];
             const T mag = max_(up, dn);
             if (mag > max_df) { max_df = mag; best = qv; }
         }
         if (max_df < eps) { stopped = true; break; }
         if (iqd[best] != (T)0) {
-            x[best] = clamp01(fma_(-iqd[best], dd[best], x[best]));
+            x[best] = m.project(fma_(-iqd[best], dd[best], x[best]), best & 1);
             vinit = (it + 1 == smo_iters);
         }
         ++iter;
@@ -80,34 +80,38 @@ void solve_one(T v, T ty, T tphi, const T* q, const T* r, double step, double wh
         }
         const T huge = (T)0x1p100;   // fp32 stop test (two-fma form)
         while (true) {
+            constexpr bool RV = Reverse<T, H>::value;
             T Z, Y;
             m.fwd_init(Z, Y);
             for (int i = 0; i < H; ++i) { m.fwd(Z, Y, x[2 * i], x[2 * i + 1]); wz[i] = Z; wy[i] = Y; }
             const T p0 = x[0], p1 = x[1];
             T n0, n1, acc = (T)0;
-            m.bwd_last(n0, n1, wz[H - 1], wy[H - 1]);
+            m.bwd_last(n0, n1, Z, Y);
             for (int i = H - 1; i >= 0; --i) {
-                if (i < H - 1) m.bwd(n0, n1, wz[i], wy[i]);
+                if (i < H - 1) m.bwd(n0, n1, RV ? Z : wz[i], RV ? Y : wy[i]);   // RV: (Z, Y) hold step i
+                const T xo0 = x[2 * i], xo1 = x[2 * i + 1];
                 for (int j = 0; j < 2; ++j) {
                     const int qv = 2 * i + j;
                     const T xx = x[qv];
                     const T d = j == 0 ? m.df0(n1, xx) : m.df1(n0, n1, xx);
-                    const T vn = clamp01(fma_(-(j == 0 ? il0 : il1), d, xx));
+                    const T xn = fast_stop ? pg_update<true>(m, j, xx, d, j == 0 ? il0 : il1, beta, vv[qv])
+                                           : pg_update<false>(m, j, xx, d, j == 0 ? il0 : il1, beta, vv[qv]);
+                    const T vn = vv[qv];
                     T mag;
                     if (!fast_stop) {
-                        const T up = (xx <= (T)0) ? (T)0 : d;
-                        const T dn = (xx >= (T)1) ? (T)0 : -d;
+                        const T up = (xx <= m.bl(j)) ? (T)0 : d;
+                        const T dn = (xx >= m.bh(j)) ? (T)0 : -d;
                         mag = max_(up, dn);
                     } else if (sizeof(T) == 8) {
                         mag = min_(abs_(d), abs_(xx - vn));
                     } else {
-                        const T g_lo = xx * huge, g_hi = fma_(-huge, xx, huge);
+                        const T g_lo = m.gap_lo(j, xx, huge), g_hi = m.gap_hi(j, xx, huge);
                         mag = abs_(max_(min_(d, g_lo), -g_hi));
                     }
                     acc = max_(acc, mag);
-                    x[qv] = clamp01(fma_(beta, vn - vv[qv], vn));
-                    vv[qv] = vn;
+                    x[qv] = xn;
                 }
+                if (RV && i > 0) m.rev(Z, Y, xo0, xo1);   // step i-1 from step i and the controls it was made from
             }
             if (acc < geps) { x[0] = p0; x[1] = p1; break; }   // stop: the controls before this update
             ++iter;

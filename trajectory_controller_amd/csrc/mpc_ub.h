@@ -33,11 +33,18 @@ TPC_DEV bool ub_fast_stop_ok(const ub::Unit<T, EQB>& m, T ty, T tphi, T q0, T q1
     const T smax = tmax(m.s0, m.s1);
     bool ok = tabs(m.a) <= kAl && tabs(m.c) <= kAl && tabs(ty) <= kAl && tabs(tphi) <= kAl;
     ok = ok && tabs(q0) <= kQ && tabs(q1) <= kQ && tabs(r0) <= kR && tabs(r1) <= kR;
-    ok = ok && smax <= kS && tabs(m.lo0) <= kS && tabs(m.lo1) <= kS && tabs(m.hi0) <= kS && tabs(m.hi1) <= kS;
-    ok = ok && m.xz0 >= (T)0 && m.xz0 <= (T)1 && m.xz1 >= (T)0 && m.xz1 <= (T)1;
     ok = ok && eps >= kEpsLo && eps <= kEpsHi;
-    if (D) ok = ok && lambda * smax * (T)0x1p-50 < eps;
-    else ok = ok && lambda <= (T)1e30;
+    if constexpr (ub::Unit<T, EQB>::kUnitBox) {
+        ok = ok && smax <= kS && tabs(m.lo0) <= kS && tabs(m.lo1) <= kS && tabs(m.hi0) <= kS && tabs(m.hi1) <= kS;
+        ok = ok && m.xz0 >= (T)0 && m.xz0 <= (T)1 && m.xz1 >= (T)0 && m.xz1 <= (T)1;
+        ok = ok && lambda * smax * (T)0x1p-50 < eps;
+    } else {
+        // dlib's coordinates (fp32): the start point 0 strictly inside the box, and a gap of one ulp off a
+        // bound, times 2^100, beyond every admissible eps: |bound| >= 1e-10
+        constexpr T kBmin = (T)1e-10;
+        ok = ok && m.bl0 <= -kBmin && m.bl1 <= -kBmin && m.bh0 >= kBmin && m.bh1 >= kBmin;
+        ok = ok && m.bl0 >= -kS && m.bl1 >= -kS && m.bh0 <= kS && m.bh1 <= kS && lambda <= (T)1e30;
+    }
     return ok;
 }
 
@@ -109,8 +116,8 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void ub_cd_kernel(Compact
 #pragma unroll
         for (int q = 0; q < 2 * H; ++q) {
             const T xx = x[q], dd = w[q];
-            const T up = (xx <= (T)0) ? (T)0 : dd;
-            const T dn = (xx >= (T)1) ? (T)0 : -dd;
+            const T up = (xx <= m.bl(q & 1)) ? (T)0 : dd;
+            const T dn = (xx >= m.bh(q & 1)) ? (T)0 : -dd;
             const T mag = tmax(up, dn);
             const bool better = mag > max_df;
             max_df = tmax(max_df, mag);
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void ub_cd_kernel(Compact
             const T best_df = with_sign(max_df, best_sign);
             const T iq = s_iqd[best][lane];
             if (iq != (T)0) {                                   // mpc.h:322 (`continue` still counts)
-                const T nx = ub::clamp01(ub::fma_(-iq, best_df, best_x));   // mpc.h:325-326
+                const T nx = m.project(ub::fma_(-iq, best_df, best_x), best & 1);   // mpc.h:325-326
 #pragma unroll
                 for (int q = 0; q < 2 * H; ++q) x[q] = (q == best) ? nx : x[q];
                 vinit = (it + 1 == kn.smo_iters);               // mpc.h:330-334
@@ -184,14 +191,24 @@ template <typename T, int H> struct UbPlan {
     static constexpr bool D = sizeof(T) == 8;
     static constexpr int words = D ? 2 : 1;
     // everything in registers: 6H values
-    static constexpr bool regs = 6 * H * words <= 200 || !D;
-    // waves per SIMD
-    static constexpr int occ_default = (6 * H * words <= 120) ? 2 : 1;
+    static constexpr bool reverse = ub::Reverse<T, H>::value;   // no stored forward pass (mpc_ub_model.h)
+    static constexpr bool regs = 6 * H * words <= 200 || !D || reverse;
+    // waves per SIMD.  fp64: ONE at every horizon -- two were measured slower wherever they fit (N = 4 / 5 / 10:
+    // 0.237 / 0.260 / 0.963 ms per 262 144 instances against 0.195 / 0.236 / 0.929 with one; N = 20 with v in
+    // LDS or with the forward pass regenerated: 6.9-7.7 ms against 5.35): a second wave adds no issue slots
+    // to a stream of 3-operand fp64 instructions, and halves the instances per lane of the persistent grid.
+    static constexpr int occ_default = D ? 1 : ((6 * H * words <= 120) ? 2 : 1);
     static constexpr int occ = TPC_UB_OCC > 0 ? TPC_UB_OCC : occ_default;
-    // forward pass checkpointed into AGPRs: x and w together exceed the VGPRs (fp64, H >= 30)
-    static constexpr bool ckpt = D && H >= 30;
+    // forward pass checkpointed (even steps kept, odd steps recomputed in the backward pass): in AGPRs where
+    // x and w together exceed the VGPRs (fp64, H >= 30); TPC_UB_CKPT=1: in VGPRs (A/B at H = 20)
+    static constexpr bool ckpt_agpr = D && H >= 30 && !reverse;
+#ifdef TPC_UB_CKPT
+    static constexpr bool ckpt = ckpt_agpr || (TPC_UB_CKPT != 0 && D && !regs);
+#else
+    static constexpr bool ckpt = ckpt_agpr;
+#endif
     // steps of v in VGPRs (the rest in LDS)
-    static constexpr int kv_default = regs ? H : (H == 20 ? 8 : 8);
+    static constexpr int kv_default = regs ? H : (H == 20 ? 16 : 8);
     static constexpr int kv = regs ? H : (TPC_UB_KV >= 0 ? TPC_UB_KV : kv_default);
 };
 #ifdef TPC_UB_EXIT_EVERY_STOP
@@ -234,18 +251,27 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
     static_assert(!CK || H % 2 == 0, "checkpoints sit on the even steps");
     __shared__ T s_all[VL > 0 ? 2 * VL : 1][BT];
     T r_v[2 * KV + 1];
-    AgprWord a_w[CK ? H : 1];
+    constexpr bool CKA = P::ckpt_agpr;   // checkpoints in AGPRs (else in VGPRs)
+    AgprWord a_w[CKA ? H : 1];
+    T c_w[(CK && !CKA) ? H : 1];
     const int lane = threadIdx.x;
     auto v_put = [&](int q, T val) { if (q < 2 * KV) r_v[q] = val; else s_all[q - 2 * KV][threadIdx.x] = val; };
     auto v_get = [&](int q) -> T { if (q < 2 * KV) return r_v[q]; else return s_all[q - 2 * KV][threadIdx.x]; };
-    T w[CK ? 1 : 2 * H];
+    constexpr bool RV = P::reverse;
+    T w[(CK || RV) ? 1 : 2 * H];
     // CK keeps the even steps only: (Z, Y) of step i (even) at a_w[i], a_w[i+1]
     auto w_put = [&](int i, T Z, T Y) {
-        if constexpr (CK) { if ((i & 1) == 0) { agpr_put(a_w[i], Z); agpr_put(a_w[i + 1], Y); } }
+        if constexpr (RV) {}
+        else if constexpr (CKA) { if ((i & 1) == 0) { agpr_put(a_w[i], Z); agpr_put(a_w[i + 1], Y); } }
+        else if constexpr (CK) { if ((i & 1) == 0) { c_w[i] = Z; c_w[i + 1] = Y; } }
         else { w[2 * i] = Z; w[2 * i + 1] = Y; }
     };
-    auto w_getz = [&](int i) -> T { if constexpr (CK) return agpr_get<T>(a_w[i]); else return w[2 * i]; };
-    auto w_gety = [&](int i) -> T { if constexpr (CK) return agpr_get<T>(a_w[i + 1]); else return w[2 * i + 1]; };
+    auto w_getz = [&](int i) -> T {
+        if constexpr (CKA) return agpr_get<T>(a_w[i]); else if constexpr (CK) return c_w[i]; else return w[2 * i];
+    };
+    auto w_gety = [&](int i) -> T {
+        if constexpr (CKA) return agpr_get<T>(a_w[i + 1]); else if constexpr (CK) return c_w[i + 1]; else return w[2 * i + 1];
+    };
 
     constexpr T gs = ub::GradScale<T>::g;
     const T geps = gs * (T)kn.eps;
@@ -326,9 +352,12 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
         bool stop = false, cap = false;
 #pragma unroll 1
         do {
+        // v of the LDS-resident steps is fetched one step ahead into a two-slot ring
         T pv[2][2];
+        if constexpr (H - 1 >= KV) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) pv[(H - 1) & 1][j] = v_get(2 * (H - 1) + j);
+            for (int j = 0; j < 2; ++j) pv[(H - 1) & 1][j] = v_get(2 * (H - 1) + j);
+        }
         // ---- forward pass
         T Z, Y;
         m.fwd_init(Z, Y);
@@ -352,13 +381,13 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
         static_for<H>([&](auto ic) {
             constexpr int i = H - 1 - decltype(ic)::value;
             constexpr int cur = i & 1, nxt = (i - 1) & 1;
-            if constexpr (i > 0) {
+            if constexpr (i > 0 && i - 1 >= KV) {
                 static_for<2>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
                     pv[nxt][j] = v_get(2 * (i - 1) + j);
                 });
             }
-#ifndef TPC_UB_NO_SCHED_BARRIER
+#ifdef TPC_UB_SCHED_BARRIER   // (A/B: pins the prefetch at the top of its step; measured 5 % slower here)
             __builtin_amdgcn_sched_barrier(0);
 #endif
             if constexpr (CK) {
@@ -377,9 +406,12 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
                 } else {
                     cz = w_getz(i - 1); cy = w_gety(i - 1);   // i = H-1 (odd): its own (Z, Y) went into bwd_last
                 }
+            } else if constexpr (RV) {
+                if constexpr (i < H - 1) m.bwd(n0, n1, Z, Y);   // (Z, Y) hold step i (regenerated below)
             } else {
                 if constexpr (i < H - 1) m.bwd(n0, n1, w_getz(i), w_gety(i));
             }
+            [[maybe_unused]] const T xo0 = x[2 * i], xo1 = x[2 * i + 1];
             T vn[2], st[2];
             static_for<2>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
@@ -387,28 +419,43 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
                 const T xx = x[q];
                 T dd;
                 if constexpr (j == 0) dd = m.df0(n1, xx); else dd = m.df1(n0, n1, xx);
-                vn[j] = ub::clamp01(ub::fma_(-il[j], dd, xx));                      // mpc.h:342
+                vn[j] = m.template project<FAST>(ub::fma_(-il[j], dd, xx), j);      // mpc.h:342
                 if constexpr (MOVED) {
                     acc[(2 * i + j) % NA] = tmax(acc[(2 * i + j) % NA], tmin(tabs(dd), tabs(xx - vn[j])));
                 } else if constexpr (FAST) {
-                    const T g_lo = xx * huge;
-                    const T g_hi = ub::fma_(-huge, xx, huge);
+                    const T g_lo = m.gap_lo(j, xx, huge);
+                    const T g_hi = m.gap_hi(j, xx, huge);
                     st[j] = (T)med3_neglo((float)dd, (float)g_hi, (float)g_lo);
                     if constexpr (j == 1) acc[i % NA] = (T)max3_abs((float)acc[i % NA], (float)st[0], (float)st[1]);
                 } else {
-                    const T up = (xx <= (T)0) ? (T)0 : dd;                          // mpc.h:298-299
-                    const T dn = (xx >= (T)1) ? (T)0 : -dd;
+                    const T up = (xx <= m.bl(j)) ? (T)0 : dd;                       // mpc.h:298-299
+                    const T dn = (xx >= m.bh(j)) ? (T)0 : -dd;
                     acc[(2 * i + j) % NA] = tmax(acc[(2 * i + j) % NA], tmax(up, dn));
                 }
-                x[q] = ub::clamp01(ub::fma_(beta, vn[j] - pv[cur][j], vn[j]));       // mpc.h:343
-#ifndef TPC_UB_NO_UPIN
+            });
+#ifdef TPC_UB_MID_BARRIER
+            // everything that reads the old x comes before everything that defines the new one, so the new x
+            // can take the old one's register
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            static_for<2>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                constexpr int q = 2 * i + j;
+                T vold;
+                if constexpr (i >= KV) vold = pv[cur][j]; else vold = r_v[q];
+                x[q] = m.template project<FAST>(ub::fma_(beta, vn[j] - vold, vn[j]), j);   // mpc.h:343 (difference form: pg_update)
+                if constexpr (i < KV) r_v[q] = vn[j];
+#ifdef TPC_UB_UPIN   // (A/B: LANE's pin of the update to its step; here it costs register copies)
                 asm volatile("" : "+v"(x[q]));
 #endif
             });
-            static_for<2>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                v_put(2 * i + j, vn[j]);
-            });
+            if constexpr (i >= KV) {
+                static_for<2>([&](auto jc) {   // adjacent stores: one ds_write2st64 per step
+                    constexpr int j = decltype(jc)::value;
+                    v_put(2 * i + j, vn[j]);
+                });
+            }
+            if constexpr (RV && i > 0) m.rev(Z, Y, xo0, xo1);
         });
         T max_df = acc[0];
 #pragma unroll

@@ -76,7 +76,7 @@ hipError_t run(const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStr
 hipError_t TPC_CAT(ub_compact_h, TPC_UB_H)(int dtype, int equal_bounds, const CompactArgs& a, const Knobs& k,
                                             const Workspace& ws, hipStream_t s) {
     if (dtype == 0) return equal_bounds ? run<double, true>(a, k, ws, s) : run<double, false>(a, k, ws, s);
-    return equal_bounds ? run<float, true>(a, k, ws, s) : run<float, false>(a, k, ws, s);
+    return run<float, true>(a, k, ws, s);   // fp32 keeps dlib's coordinates: no bound-dependent build (mpc_ub_model.h)
 }
 
 }  // namespace tpc

@@ -73,12 +73,24 @@ template <> struct GradScale<float> {
     static constexpr float g = 1.0f, inv_g = 1.0f;
 };
 
-// The compact model in unit-box coordinates.  EQB: both inputs share their bounds (the reference's
-// configuration, src/trajectory_point_follower.cpp:16-18), which drops one addition per step.
-template <typename T, bool EQB> struct Unit {
+// Unit-box coordinates are an fp64 device.  In fp32 they would cost accuracy: a control near zero sits at
+// x ~ 0.5, where one ulp of x is 6e-8 of the box however small the control is, so steps dlib's float
+// arithmetic still resolves vanish here (measured: +10 % iterations at N = 20, +57 % at N = 30, results
+// further from the fp64 ones) -- and fp32 has v_med3_f32, dlib's clamp in one instruction, so the box buys
+// little there.  fp32 therefore keeps dlib's own coordinates: the same recurrences with the identity map
+// (s = 1, offset 0) and the box [lower, upper].
+template <typename T> struct UnitBox { static constexpr bool value = sizeof(T) == 8; };
+
+// The compact model in the family's coordinates  u_j = lo_j + s_j x_j,  x_j in [bl_j, bh_j].
+// UBOX: the unit box (s = upper - lower, offset lower, box [0, 1]); otherwise dlib's coordinates (s = 1,
+// offset 0, box [lower, upper]).  EQB: both inputs share their bounds (the reference's configuration,
+// src/trajectory_point_follower.cpp:16-18), which drops one addition per step (always so without UBOX).
+template <typename T, bool EQB, bool UBOX = UnitBox<T>::value> struct Unit {
+    static constexpr bool kUnitBox = UBOX;
     // uniform over a batch
-    T s0, s1, lo0, lo1, hi0, hi1;
-    T xz0, xz1;                               // u = 0 (dlib's start point, mpc.h:110) in unit coordinates
+    T s0, s1, lo0, lo1, hi0, hi1;             // the map (hi: dlib's upper, for exact outputs on the bound)
+    T bl0, bl1, bh0, bh1;                     // the box in x coordinates
+    T xz0, xz1;                               // u = 0 (dlib's start point, mpc.h:110) in x coordinates
     T gq0, gq1, grs0, grs1, grl0, grl1;       // g q, g r s, g r lo
     // per instance
     T a, c, as1, cs0, cs1, dlt, z0, q1th;
@@ -87,12 +99,33 @@ template <typename T, bool EQB> struct Unit {
     TPC_HD T lo(int j) const { return j == 0 ? lo0 : lo1; }
     TPC_HD T hi(int j) const { return j == 0 ? hi0 : hi1; }
     TPC_HD T xz(int j) const { return j == 0 ? xz0 : xz1; }
+    TPC_HD T bl(int j) const { return UBOX ? (T)0 : (j == 0 ? bl0 : bl1); }
+    TPC_HD T bh(int j) const { return UBOX ? (T)1 : (j == 0 ? bh0 : bh1); }
+
+    // dlib's three-argument clamp (matrix_utilities.h:2835-2846) onto the box.  NONAN (the screened builds):
+    // one v_med3_f32 on the GPU, the same value for every non-NaN operand.
+    template <bool NONAN = false> TPC_HD T project(T val, int j) const {
+        if (UBOX) return clamp01(val);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (NONAN && sizeof(T) == 4) return (T)__builtin_amdgcn_fmed3f((float)val, (float)bl(j), (float)bh(j));
+#endif
+        return max_(min_(val, bh(j)), bl(j));
+    }
 
     // q, r, lo, hi: dlib's Q, R, lower, upper (src/trajectory_point_follower.cpp:359-363, :16-18)
     TPC_HD void set_uniform(T g, const T* q, const T* r, const T* lo, const T* hi) {
-        lo0 = lo[0]; lo1 = lo[1]; hi0 = hi[0]; hi1 = hi[1];
-        s0 = hi0 - lo0; s1 = hi1 - lo1;
-        xz0 = ((T)0 - lo0) / s0; xz1 = ((T)0 - lo1) / s1;
+        hi0 = hi[0]; hi1 = hi[1];
+        if (UBOX) {
+            lo0 = lo[0]; lo1 = lo[1];
+            s0 = hi0 - lo0; s1 = hi1 - lo1;
+            xz0 = ((T)0 - lo0) / s0; xz1 = ((T)0 - lo1) / s1;
+            bl0 = bl1 = (T)0; bh0 = bh1 = (T)1;
+        } else {
+            lo0 = lo1 = (T)0;
+            s0 = s1 = (T)1;
+            xz0 = xz1 = (T)0;
+            bl0 = lo[0]; bl1 = lo[1]; bh0 = hi[0]; bh1 = hi[1];
+        }
         gq0 = g * q[0]; gq1 = g * q[1];
         const T gr0 = g * r[0], gr1 = g * r[1];
         grs0 = gr0 * s0; grs1 = gr1 * s1;
@@ -116,8 +149,19 @@ template <typename T, bool EQB> struct Unit {
     TPC_HD void fwd(T& Z, T& Y, T x0, T x1) const {
         const T zn = fma_(as1, x1, fma_(a, Y, Z));
         T yn = fma_(cs0, x0, fma_(-cs1, x1, Y));
-        if (!EQB) yn = yn + dlt;
+        if (!EQB && UBOX) yn = yn + dlt;
         Z = zn; Y = yn;
+    }
+    // The forward recurrence run backwards: (Z, Y) of step i-1 from those of step i and x[i].  Used by the
+    // plans that do not keep the forward pass (Reverse below): the backward sweep regenerates each step's
+    // (Z, Y) from the next one's at four operations per step.  The regenerated values differ from the
+    // forward ones by rounding (a few ulp over the horizon), like everything else in this family.
+    TPC_HD void rev(T& Z, T& Y, T x0, T x1) const {
+        T yp = Y;
+        if (!EQB && UBOX) yp = yp - dlt;
+        yp = fma_(cs1, x1, fma_(-cs0, x0, yp));
+        Z = fma_(-a, yp, fma_(-as1, x1, Z));
+        Y = yp;
     }
     // backward pass (mpc.h:278-281): the last step, then one step
     TPC_HD void bwd_last(T& n0, T& n1, T Z, T Y) const {
@@ -133,10 +177,23 @@ template <typename T, bool EQB> struct Unit {
     // gradient components of one step (mpc.h:283)
     TPC_HD T df0(T n1, T x0) const { return fma_(c, n1, fma_(grs0, x0, grl0)); }
     TPC_HD T df1(T n0, T n1, T x1) const { return fma_(a, n0, fma_(-c, n1, fma_(grs1, x1, grl1))); }
-    // unit coordinate -> control; the bounds and the untouched start point come out exactly
+    // x -> control; the bounds and the untouched start point come out exactly
     TPC_HD T control(int j, T x) const {
+        if (!UBOX) return x;
         return x == (T)1 ? hi(j) : (x == xz(j) ? (T)0 : fma_(s(j), x, lo(j)));
     }
+    // fp32 stop test (dlib's mask as arithmetic): (x - bl) 2^100 and (bh - x) 2^100, zero exactly on the bound
+    TPC_HD T gap_lo(int j, T x, T huge) const { return fma_(x, huge, -(bl(j) * huge)); }
+    TPC_HD T gap_hi(int j, T x, T huge) const { return fma_(-huge, x, bh(j) * huge); }
+};
+
+// Which (dtype, horizon) regenerate the forward pass in the backward sweep instead of keeping it: part of
+// the family's arithmetic, so it lives here where kernels and model both see it.
+#ifndef TPC_UB_REVERSE
+#define TPC_UB_REVERSE 0
+#endif
+template <typename T, int H> struct Reverse {
+    static constexpr bool value = TPC_UB_REVERSE != 0 && sizeof(T) == 8 && H == 20;
 };
 
 // dlib's constructor quantities for the compact model (mpc.h:116-123), in dlib's own operation order
@@ -171,12 +228,21 @@ template <typename T, int H, class Emit> TPC_HD T ctor_lambda_qdiag(T a, T c, T 
 }
 
 // Step constants of the projected-gradient phase (mpc.h:342-343) in unit coordinates:
-// x_new = clamp01(x - il_j * (g df)),  il_j = 1 / (g lambda s_j);  beta = (sqrt(lambda)-1)/(sqrt(lambda)+1)
+// v_new = clamp01(x - il_j * (g df)),  il_j = 1 / (g lambda s_j);  beta = (sqrt(lambda)-1)/(sqrt(lambda)+1)
 template <typename T> TPC_HD void pg_constants(T lambda, T s0, T s1, T& il0, T& il1, T& beta) {
     il0 = ((T)1 / (lambda * s0)) * GradScale<T>::inv_g;
     il1 = ((T)1 / (lambda * s1)) * GradScale<T>::inv_g;
     const T sq = sqrt_(lambda);
     beta = (sq - (T)1) / (sq + (T)1);
+}
+// One variable's projected-gradient update (mpc.h:342-343): returns the new x, leaves the new v in `v`.
+// The momentum term must stay in dlib's difference form v + beta (v - v_old): only that form returns v
+// EXACTLY when v == v_old, which is what keeps a variable that sits on a bound on it (the algebraically equal
+// fma(1 + beta, v, -beta v_old) leaves the bound by an ulp, and the stop test then sees a free variable).
+template <bool NONAN, class M, typename T> TPC_HD T pg_update(const M& m, int j, T x, T d, T il, T beta, T& v) {
+    const T vold = v;
+    v = m.template project<NONAN>(fma_(-il, d, x), j);
+    return m.template project<NONAN>(fma_(beta, v - vold, v), j);
 }
 
 }  // namespace ub

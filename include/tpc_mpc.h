@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TPC_MPC_ABI_VERSION 2
+#define TPC_MPC_ABI_VERSION 3
 
 typedef struct tpc_mpc_context* tpc_mpc_handle;
 
@@ -61,8 +61,8 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
  *          controls are exchanged by DPP / lane swaps, reductions by wavefront DPP/ballot.  (fp64
  *          batches of more than one instance per SIMD with I*H <= 32 run two instances per wavefront,
  *          one per 32-lane half, and four -- one per 16-lane row -- with I*H <= 16: same arithmetic per
- *          instance, every verdict per group; TPC_MPC_WAVE_PAIRS=0 in the environment keeps strictly
- *          one per wavefront.)  Lowest
+ *          instance, every verdict per group; tpc_mpc_set_option(TPC_MPC_OPT_WAVE_GROUP, 1) keeps
+ *          strictly one per wavefront.)  Lowest
  *          latency; used for small and mid-size batches and solve_one.  Needs a specialised horizon
  *          with I*H <= 64 or I = 2.  Agrees with the reference to ~1e-14 (same decisions, different
  *          summation).
@@ -167,8 +167,8 @@ int tpc_mpc_solve_one(tpc_mpc_handle h, const tpc_mpc_params* p, double v, doubl
  * the idle timeout.  idle_timeout_us <= 0 turns the resident mode off: every solve_one is then one
  * kernel launch.
  * Where the CPU can write device memory (hipDeviceAttributeIsLargeBar) the request is written into
- * device memory through the BAR, otherwise into pinned host memory; the environment variable
- * TPC_MPC_MAILBOX=host, read when a handle first uses solve_one, forces the latter. */
+ * device memory through the BAR, otherwise into pinned host memory (TPC_MPC_OPT_MAILBOX_HOST forces the
+ * latter). */
 int tpc_mpc_set_resident(tpc_mpc_handle h, int64_t idle_timeout_us);
 
 /* The same computation for n independent instances in one launch.  Arrays are `p->dtype`,
@@ -287,6 +287,11 @@ int tpc_mpc_follow_batch_horizon(tpc_mpc_handle h, const tpc_mpc_params* p, cons
 int tpc_mpc_comm_unique_id(void* id, size_t len);
 int tpc_mpc_comm_init_rank(tpc_mpc_handle h, const void* id, size_t len, int rank, int world);
 int tpc_mpc_comm_destroy(tpc_mpc_handle h);
+/* TEST HOOK, not for hosts: a world of one normally needs no communicator and the exchange is skipped.
+ * force_communicator != 0 makes the next tpc_mpc_comm_init_rank(h, id, len, 0, 1) build a real one-rank RCCL
+ * communicator, so that a one-GPU box runs the library's own ncclAllGather calls; force_ragged != 0 makes the
+ * sharded solve take its ragged form (one in-place ncclBroadcast per owner) whatever the sizes. */
+int tpc_mpc_comm_test_mode(tpc_mpc_handle h, int force_communicator, int force_ragged);
 /* ncclGroupStart / ncclGroupEnd: a single thread that drives several handles brackets its
  * tpc_mpc_comm_init_rank calls, and each round of tpc_mpc_solve_batch_compact_sharded calls, with these. */
 int tpc_mpc_group_begin(void);
@@ -315,23 +320,18 @@ int tpc_mpc_solve_batch_compact_sharded(tpc_mpc_handle h, const tpc_mpc_params* 
  * allocates. */
 int tpc_mpc_reserve(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n, int mem);
 
-/* ---- scheduling hint --------------------------------------------------------------------------- */
+/* ---- library options -------------------------------------------------------------------------- */
 
-/* EXPERIMENTAL; no reference counterpart (one controller solves one problem per cycle there).  Instances of a
- * batch need between a few and several thousand iterations (mpc.h:271, :310), and the batch
- * finishes when its slowest lane does, so the LANE kernels -- and the WAVE kernels when a batch has
- * more instances than wavefronts fit the chip (N >= 10) -- start the instances expected to run
- * longest first.  Their own estimate is dlib's lambda (mpc.h:116-123) with a correction where it
- * is uninformative.  A caller that knows the iteration counts better passes them here: hint[k] =
- * expected iteration count of instance k (e.g. the `iters` output of an earlier solve of the SAME
- * instances: +7 % throughput at N=20; counts taken from a previous control cycle whose inputs have
- * since moved by as little as 0.5 % of their range are no better than the built-in order at N=20,
- * because the count is a ragged function of the inputs).  The hint applies to the NEXT
- * tpc_mpc_solve_batch_compact / tpc_mpc_solve_batch_general call on this handle if that call has
- * the same n, and is forgotten afterwards; the hint is copied into the handle by this call (the
- * caller's array is not referenced afterwards); hint = NULL clears.  It only decides which lane solves which instance when:
- * outputs, iteration counts and flags are bit-for-bit the same with any hint. */
-int tpc_mpc_set_work_hint(tpc_mpc_handle h, const int32_t* hint, int64_t n, int mem);
+/* No reference counterpart: switches of this implementation that a host may want to pin (A/B measurements,
+ * boards without a large BAR).  They belong to the handle -- the library reads nothing from the environment.
+ *   TPC_MPC_OPT_WAVE_GROUP   instances per wavefront of the fp64 WAVE kernels: 0 (default) = as many as fit and
+ *                            pay (4 with inputs*horizon <= 16, 2 with <= 32, from one wavefront per SIMD on),
+ *                            1 = strictly one, 2 / 4 = pairs / fours where they fit.  Same arithmetic per instance.
+ *   TPC_MPC_OPT_MAILBOX_HOST 1 = tpc_mpc_solve_one's request lines live in pinned host memory even where the
+ *                            CPU could write device memory through the BAR (0, default: device memory where
+ *                            hipDeviceAttributeIsLargeBar says so).  Restarts the resident wavefront. */
+typedef enum tpc_mpc_option { TPC_MPC_OPT_WAVE_GROUP = 1, TPC_MPC_OPT_MAILBOX_HOST = 2 } tpc_mpc_option;
+int tpc_mpc_set_option(tpc_mpc_handle h, int option, int64_t value);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 

@@ -67,6 +67,27 @@ int main(int argc, char** argv) {
                     std::atan2((double)tp.directory.y, (double)tp.directory.x), st->steering_front, st->steering_rear,
                     st->targetSpeed, st->state == street_environment::CarCommand::StateType::DRIVING);
     }
+    // a lane change ahead sets the indicators (reference :227-241); they are reset every cycle
+    (*traj)[8].right = false;
+    mod.cycle();
+    const street_environment::CarCommand::State* ind = car->getState("DEFAULT");
+    std::printf("{\"indicator_left\": %s, \"indicator_right\": %s", ind->indicatorLeft ? "true" : "false",
+                ind->indicatorRight ? "true" : "false");
+    (*traj)[8].right = true;
+    mod.cycle();
+    ind = car->getState("DEFAULT");
+    std::printf(", \"reset_left\": %s, \"reset_right\": %s}\n", ind->indicatorLeft ? "true" : "false",
+                ind->indicatorRight ? "true" : "false");
+    // IDLE drive mode publishes the priority-100 stand-still state and leaves DEFAULT alone; leaving the mode
+    // removes it again (reference :35-52)
+    phx->mode = phoenix_CC2016_service::CCDriveMode::IDLE;
+    mod.cycle();
+    const street_environment::CarCommand::State* idle = car->getState("IDLE");
+    std::printf("{\"idle_state\": %s, \"priority\": %d, \"idle_speed\": %.9g", idle ? "true" : "false",
+                idle ? idle->priority : -1, idle ? idle->targetSpeed : -1.0);
+    phx->mode = phoenix_CC2016_service::CCDriveMode::FOH;
+    mod.cycle();
+    std::printf(", \"removed_after\": %s}\n", car->getState("IDLE") ? "false" : "true");
     // a back-end outside this build's scope is refused, not emulated
     mod.config().set("type", "PID");
     std::printf("{\"other_backend_refused\": %s}\n", mod.cycle() ? "false" : "true");

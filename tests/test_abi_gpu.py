@@ -253,20 +253,20 @@ def test_sharded_entry_world_of_one(torch_cuda):
     assert torch.equal(f, f2) and torch.equal(r, r2) and int(it.min()) >= 0
 
 
-@pytest.mark.parametrize("form", ["1", "2"])
-def test_sharded_entry_through_rccl_world_of_one(torch_cuda, monkeypatch, form):
-    """The RCCL calls themselves on the one-GPU box: TPC_MPC_FORCE_RCCL=1 makes tpc_mpc_comm_init_rank build
-    a real one-rank communicator (dlopen, ncclGetUniqueId, ncclCommInitRank), and the sharded solve then
-    runs its grouped in-place ncclAllGather (form "1") or the per-owner ncclBroadcast of ragged batches
-    (form "2") on the caller's stream.  Results = the plain solve."""
+@pytest.mark.parametrize("ragged", [False, True])
+def test_sharded_entry_through_rccl_world_of_one(torch_cuda, ragged):
+    """The RCCL calls themselves on the one-GPU box: after tpc_mpc_comm_test_mode(force_communicator = 1)
+    tpc_mpc_comm_init_rank builds a real one-rank communicator (dlopen, ncclGetUniqueId, ncclCommInitRank), and
+    the sharded solve then runs its grouped in-place ncclAllGather or (force_ragged = 1) the per-owner
+    ncclBroadcast of ragged batches on the caller's stream.  Results = the plain solve."""
     from trajectory_controller_amd import MpcSolver
     from trajectory_controller_amd.synth import compact_inputs
     torch = torch_cuda
-    monkeypatch.setenv("TPC_MPC_FORCE_RCCL", form)
     H, n = 10, 4097
     v, dy, dphi = (torch.from_numpy(a).cuda() for a in compact_inputs(H, n, first=11))
     with _solver(H, "lane") as s:
         want = s.solve_batch_compact(v, dy, dphi)
+        s.comm_test_mode(True, ragged)
         s.comm_init(MpcSolver.comm_unique_id(), 0, 1)
         stream = torch.cuda.Stream()
         with torch.cuda.stream(stream):
@@ -461,20 +461,20 @@ def test_solve_one_resident_vs_oracle(torch_cuda, oracle, H):
 
 
 @pytest.mark.parametrize("where", ["device", "host"])
-def test_solve_one_request_lines_placement(torch_cuda, oracle, monkeypatch, where):
+def test_solve_one_request_lines_placement(torch_cuda, oracle, where):
     """The resident wave takes its requests from device memory the CPU writes through the BAR (where the
-    part has a large BAR) or from the pinned block (TPC_MPC_MAILBOX=host, the fallback): same answers, also
+    part has a large BAR) or from the pinned block (TPC_MPC_OPT_MAILBOX_HOST, the fallback): same answers, also
     across a horizon swap, an idle timeout and two handles alive at once."""
+    from trajectory_controller_amd import capi
     from trajectory_controller_amd.synth import compact_inputs
-    if where == "host":
-        monkeypatch.setenv("TPC_MPC_MAILBOX", "host")
-    else:
-        monkeypatch.delenv("TPC_MPC_MAILBOX", raising=False)
     ref = {}
     for H in (4, 10):
         v, dy, dphi = compact_inputs(H, 24, first=991 + H)
         ref[H] = (v, dy, dphi) + tuple(oracle.solve_compact(H, v, dy, dphi)[:2])
-    with _solver(4, "auto") as s, _solver(10, "auto") as t:      # the placement is chosen per handle, at its first solve
+    with _solver(4, "auto") as s, _solver(10, "auto") as t:      # the placement is chosen per handle
+        if where == "host":
+            s.set_option(capi.OPT_MAILBOX_HOST, 1)
+            t.set_option(capi.OPT_MAILBOX_HOST, 1)
         for rep in range(2):
             for k in range(24):
                 for slv, H in ((s, 4), (t, 10), (s, 10)):        # s swaps its resident wave between two horizons
@@ -504,3 +504,26 @@ def test_solve_one_latency_and_coexistence(torch_cuda):
         assert bits_equal(f[:1024].cpu().numpy(), g["front"])
         assert abs(f1 - 0.28258865451261717) <= 1e-12 and abs(r1 - 0.059891817493776013) <= 1e-12
     assert dt < 200e-6
+
+
+def _build_example(tmp_path, name, extra=()):
+    import subprocess
+    lib = os.path.join(ROOT, "trajectory_controller_amd", "lib")
+    exe = str(tmp_path / name)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"),
+                           "-I/opt/rocm/include", os.path.join(ROOT, "examples", name + ".c"), "-o", exe, "-L" + lib,
+                           "-ltpc_mpc", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + lib, *extra])
+    return exe
+
+
+def test_sharded_inprocess_example(torch_cuda, tmp_path):
+    """examples/sharded_inprocess.c = INTEGRATION.md section 3 compiled as C: one host process, one handle and
+    stream per GPU, one RCCL communicator, the sharded call per GPU between group_begin / group_end.  On the
+    one-GPU test box G = 1 and the example asks for a real one-rank communicator, so RCCL's all-gather runs;
+    it verifies by itself that every GPU holds all outputs, bit-identical to a one-GPU solve."""
+    import json, subprocess
+    exe = _build_example(tmp_path, "sharded_inprocess")
+    r = subprocess.run([exe, "0", "20011", "10"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    last = json.loads(r.stdout.strip().splitlines()[-1])
+    assert last["verified"] is True and last["gpus"] >= 1 and last["n_total"] == 20011

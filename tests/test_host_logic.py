@@ -27,7 +27,7 @@ def test_library_exports_whole_abi():
     out = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH], text=True)
     exported = set(re.findall(r" T (tpc_mpc_[a-z_0-9]+)", out))
     assert set(decl) <= exported
-    assert lib.tpc_mpc_abi_version() == capi.ABI_VERSION == 2
+    assert lib.tpc_mpc_abi_version() == capi.ABI_VERSION == 3
 
 
 def test_header_is_plain_c(tmp_path):
@@ -150,3 +150,17 @@ def test_sharded_solve_world2_gloo(tmp_path):
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+def test_examples_compile_as_c99(tmp_path):
+    """Every C host under examples/ builds as plain C99 against the header and links the library (they are run
+    on the GPU box by tests/test_abi_gpu.py)."""
+    from trajectory_controller_amd import capi
+    libdir = os.path.dirname(capi.LIB_PATH)
+    for name in sorted(os.listdir(os.path.join(ROOT, "examples"))):
+        if not name.endswith(".c"):
+            continue
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__",
+                               "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+                               os.path.join(ROOT, "examples", name), "-o", str(tmp_path / name[:-2]), "-L" + libdir,
+                               "-ltpc_mpc", "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-Wl,-rpath," + libdir])

@@ -53,6 +53,8 @@ def test_cycle_matches_reference_solver(tmp_path, oracle, H):
         else:
             assert abs(s["steering_front"] - f[i]) <= 1e-9 and abs(s["steering_rear"] - rr[i]) <= 1e-9
         assert s["driving"] == 1
+    assert lines[-3] == {"indicator_left": True, "indicator_right": False, "reset_left": False, "reset_right": False}
+    assert lines[-2] == {"idle_state": True, "priority": 100, "idle_speed": 0, "removed_after": True}
     assert lines[-1] == {"other_backend_refused": True}
 
 

@@ -178,11 +178,11 @@ def test_bad_arguments(torch_cuda):
         assert lib.tpc_mpc_reserve(h, C.byref(p), 0, capi.DEVICE) == capi.OK
         assert lib.tpc_mpc_reserve(h, C.byref(p), 100000, capi.HOST) == capi.OK
         hint = (C.c_int32 * 4)(1, 2, 3, 4)
-        assert lib.tpc_mpc_set_work_hint(h, hint, -1, capi.HOST) != capi.OK
-        assert lib.tpc_mpc_set_work_hint(h, hint, 4, 9) != capi.OK
-        assert lib.tpc_mpc_set_work_hint(h, hint, 4, capi.HOST) == capi.OK
-        assert lib.tpc_mpc_set_work_hint(h, None, 0, capi.HOST) == capi.OK      # clears
-        assert lib.tpc_mpc_set_work_hint(None, hint, 4, capi.HOST) != capi.OK
+        assert lib.tpc_mpc_x_set_work_hint(h, hint, -1, capi.HOST) != capi.OK
+        assert lib.tpc_mpc_x_set_work_hint(h, hint, 4, 9) != capi.OK
+        assert lib.tpc_mpc_x_set_work_hint(h, hint, 4, capi.HOST) == capi.OK
+        assert lib.tpc_mpc_x_set_work_hint(h, None, 0, capi.HOST) == capi.OK      # clears
+        assert lib.tpc_mpc_x_set_work_hint(None, hint, 4, capi.HOST) != capi.OK
 
 
 # ---------------------------------------------------------------------------------------------
@@ -809,36 +809,21 @@ def test_wave_groups_equal_one_per_wavefront(torch_cuda, H):
             assert bits_equal(fc, f[a:a + 1000]) and bits_equal(rc, r[a:a + 1000]), a
 
 
-_ONE_PER_WAVE = r'''
-import sys
-sys.path.insert(0, {root!r})
-import numpy as np
-from oracle.bindings import Oracle, build_oracle
-from trajectory_controller_amd import MpcSolver
-from trajectory_controller_amd.synth import compact_inputs
-build_oracle()
-o = Oracle()
-for H, n in ((10, 5000), (5, 3000)):
-    v, dy, dphi = compact_inputs(H, n, first=91000 + H)
-    of, orr, oit = o.solve_compact(H, v, dy, dphi, nthreads=8)
-    with MpcSolver(horizon=H, algo="wave") as s:
-        f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
-    assert np.array_equal(it, oit), H
-    assert max(np.abs(f - of).max(), np.abs(r - orr).max()) <= 1e-9, H
-print("one-per-wavefront ok")
-'''
-
-
-def test_wave_one_instance_per_wavefront_switch(torch_cuda, tmp_path):
-    """TPC_MPC_WAVE_PAIRS=0 (read once per process, hence the child) keeps the fp64 WAVE batches of up to 32
-    variables on the one-instance-per-wavefront kernels the paired path replaced by default: same iteration
-    counts, same tolerance."""
-    import subprocess, sys
-    script = tmp_path / "one_per_wave.py"
-    script.write_text(_ONE_PER_WAVE.format(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-    out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, TPC_MPC_WAVE_PAIRS="0"),
-                         capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "one-per-wavefront ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+def test_wave_one_instance_per_wavefront_switch(torch_cuda, oracle):
+    """tpc_mpc_set_option(TPC_MPC_OPT_WAVE_GROUP, 1) keeps the fp64 WAVE batches of up to 32 variables on the
+    one-instance-per-wavefront kernels the grouped path replaced by default: same iteration counts, same
+    tolerance; 2 and 4 force pairs / fours."""
+    from trajectory_controller_amd import capi
+    from trajectory_controller_amd.synth import compact_inputs
+    for H, n in ((10, 5000), (5, 3000)):
+        v, dy, dphi = compact_inputs(H, n, first=91000 + H)
+        of, orr, oit = oracle.solve_compact(H, v, dy, dphi, nthreads=8)
+        for group in (1, 2, 4, 0):
+            with _solver(H, "wave") as s:
+                s.set_option(capi.OPT_WAVE_GROUP, group)
+                f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+            assert np.array_equal(it, oit), (H, group)
+            assert max(np.abs(f - of).max(), np.abs(r - orr).max()) <= 1e-9, (H, group)
 
 
 @pytest.mark.parametrize("H", [10, 5])

@@ -17,11 +17,12 @@ OK = 0
 F64, F32 = 0, 1
 HOST, DEVICE = 0, 1
 ALGO_AUTO, ALGO_WAVE, ALGO_LANE, ALGO_LANE_FMA = 0, 1, 2, 3
+OPT_WAVE_GROUP, OPT_MAILBOX_HOST = 1, 2
 FLAG_NONFINITE, FLAG_MAX_ITER, FLAG_BAD_MODEL = 0x1, 0x2, 0x4
 
 STATUS_NAMES = {0: "OK", 1: "BAD_ARG", 2: "BAD_WEIGHTS", 3: "BAD_BOUNDS", 4: "BAD_HORIZON",
                 5: "BAD_EPS", 6: "NO_DEVICE", 7: "HIP", 8: "ALLOC", 9: "COMM"}
-ABI_VERSION = 2
+ABI_VERSION = 3
 COMM_ID_BYTES = 128
 
 # every symbol include/tpc_mpc.h declares
@@ -29,11 +30,11 @@ EXPORTS = ("tpc_mpc_default_params", "tpc_mpc_create", "tpc_mpc_destroy", "tpc_m
            "tpc_mpc_supported_horizons", "tpc_mpc_abi_version", "tpc_mpc_solve_one",
            "tpc_mpc_solve_batch_compact", "tpc_mpc_solve_batch_general", "tpc_mpc_rollout",
            "tpc_mpc_set_profiling", "tpc_mpc_last_kernel_times", "tpc_mpc_last_lane_stats",
-           "tpc_mpc_follow_batch", "tpc_mpc_set_work_hint", "tpc_mpc_reserve",
+           "tpc_mpc_follow_batch", "tpc_mpc_set_option", "tpc_mpc_reserve",
            "tpc_mpc_build_info", "tpc_mpc_set_resident", "tpc_mpc_solve_batch_compact_mixed",
            "tpc_mpc_follow_batch_horizon", "tpc_mpc_comm_unique_id", "tpc_mpc_comm_init_rank",
            "tpc_mpc_comm_destroy", "tpc_mpc_group_begin", "tpc_mpc_group_end", "tpc_mpc_shard_range",
-           "tpc_mpc_solve_batch_compact_sharded")
+           "tpc_mpc_solve_batch_compact_sharded", "tpc_mpc_comm_test_mode")
 
 
 class Params(C.Structure):
@@ -105,7 +106,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.tpc_mpc_follow_batch.argtypes = [vp, C.POINTER(Params), C.POINTER(Trajectories), vp, vp, C.c_int32,
                                          vp, vp, vp, vp, vp, u32p, vp]
     lib.tpc_mpc_last_lane_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-    lib.tpc_mpc_set_work_hint.argtypes = [vp, vp, C.c_int64, C.c_int]
+    lib.tpc_mpc_x_set_work_hint.argtypes = [vp, vp, C.c_int64, C.c_int]   # experimental (csrc/tpc_mpc_experimental.h)
+    lib.tpc_mpc_set_option.argtypes = [vp, C.c_int, C.c_int64]
     lib.tpc_mpc_reserve.argtypes = [vp, C.POINTER(Params), C.c_int64, C.c_int]
     lib.tpc_mpc_build_info.restype = C.c_char_p
     lib.tpc_mpc_set_resident.argtypes = [vp, C.c_int64]
@@ -115,6 +117,7 @@ def load_library(path: str | None = None) -> C.CDLL:
                                                  C.c_int32, vp, vp, vp, vp, vp, vp, u32p, vp]
     lib.tpc_mpc_comm_unique_id.argtypes = [vp, C.c_size_t]
     lib.tpc_mpc_comm_init_rank.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int]
+    lib.tpc_mpc_comm_test_mode.argtypes = [vp, C.c_int, C.c_int]
     lib.tpc_mpc_comm_destroy.argtypes = [vp]
     lib.tpc_mpc_shard_range.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.tpc_mpc_solve_batch_compact_sharded.argtypes = [vp, C.POINTER(Params), C.c_int64, vp, vp, vp, vp, vp, vp,

@@ -65,6 +65,7 @@ struct Workspace {
     // optional profiling: events recorded on the launch stream around each kernel
     // (ev[0] .. ev[1] first kernel, ev[1] .. ev[2] second kernel); null when profiling is off
     hipEvent_t* ev;
+    int wave_group = 0;   // TPC_MPC_OPT_WAVE_GROUP: 0 auto, 1 / 2 / 4 instances per wavefront
 };
 
 // WAVE work queue (mpc_wave.h): the dynamic part of the queue is dealt out through kQueueTickets counters on

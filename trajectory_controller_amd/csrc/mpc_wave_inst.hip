@@ -49,8 +49,8 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
         // (at every horizon: paired, even N = 4 and 5 are long enough for the queue to pay -- 280 -> 239 us for
         // 32 768 instances at N = 5, 207 -> 195 at N = 4)
         constexpr bool pair_ok = sizeof(T) == 8 && I * kH <= kWave / 2;
-        // TPC_MPC_WAVE_PAIRS=0 in the environment keeps strictly one instance per wavefront (for A/B measurements)
-        static const bool pairs_wanted = [] { const char* e = getenv("TPC_MPC_WAVE_PAIRS"); return !e || atoi(e) != 0; }();
+        // TPC_MPC_OPT_WAVE_GROUP = 1 keeps strictly one instance per wavefront (for A/B measurements)
+        const bool pairs_wanted = ws.wave_group != 1;
         if constexpr (pair_ok) {
             // from more than one wavefront per SIMD on: 2 048 instances at N = 10 take 141 us one per wavefront (two
             // wavefronts sharing every SIMD) and ~120 us as 1 024 pairs of neighbours in the queue order
@@ -59,9 +59,9 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
                                    ws.order, ws.ticket);
                 // at most 16 variables: four instances per wavefront, one per 16-lane row, once pairs would put more
                 // than one wavefront on a SIMD (32 768 x N = 4: 198 us in pairs, 147 in fours; 4 096: 47 / 44;
-                // TPC_MPC_WAVE_GROUP=2|4 forces either)
+                // TPC_MPC_OPT_WAVE_GROUP = 2 | 4 forces either)
                 constexpr bool quad_ok = I * kH <= kWave / 4;
-                static const int group_forced = [] { const char* e = getenv("TPC_MPC_WAVE_GROUP"); return e ? atoi(e) : 0; }();
+                const int group_forced = ws.wave_group;
                 bool quads = false;
                 if constexpr (quad_ok) quads = group_forced == 4 || (group_forced == 0 && a.n > slots);
                 if constexpr (quad_ok) {

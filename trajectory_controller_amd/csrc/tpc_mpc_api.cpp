@@ -3,9 +3,11 @@
 // point ends in a gfx950 kernel launch or fails.  (Mixed-horizon batches: tpc_mpc_mixed.hip; sharded
 // solves over RCCL: tpc_mpc_comm.cpp; the resident single-solve kernel: tpc_mpc_one.hip.)
 #include "tpc_mpc_context.h"
+#include "tpc_mpc_experimental.h"
 
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 
 namespace tpc {
 // per-horizon launchers, one translation unit each (mpc_lane_inst.hip / mpc_wave_inst.hip)
@@ -74,8 +76,11 @@ int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n, int d
     // largest batch the queue takes: 0.65 against 1.00 ms at 32 768 x N = 10, 0.20 against 0.21 at N = 4;
     // without the queue, at 49 152, it loses 1.6 to 1.0)
     const bool paired = dtype == TPC_MPC_F64 && I * H <= kWave / 2;
+    // (the queue's crossover was measured on a 256-CU part; a smaller one -- a CPX partition -- scales it down)
+    const int64_t queue_cross = (kWaveQueueMaxInstances * h->cu_count / 256 < kWaveQueueMaxInstances
+                                     ? kWaveQueueMaxInstances * h->cu_count / 256 : kWaveQueueMaxInstances) + 1;
     const int64_t crossover = I * H > kWave ? lanes * 19 / 64
-                              : ((H >= 20 || paired) ? kWaveQueueMaxInstances + 1 : lanes * 7 / 16);
+                              : ((H >= 20 || paired) ? queue_cross : lanes * 7 / 16);
     return (n >= crossover || !wave_ok) ? lane : TPC_MPC_ALGO_WAVE;
 }
 
@@ -144,6 +149,7 @@ int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n,
     ws->stats = (unsigned long long*)(h->ws_words + 4);
     ws->capacity_bytes = 0;
     ws->ev = h->profiling ? h->ev : nullptr;
+    ws->wave_group = h->opt_wave_group;
     h->ev_valid = h->profiling;
     h->last_algo = algo;
     ws->keys = ws->rank = ws->order = nullptr;
@@ -301,12 +307,16 @@ int tpc_mpc_supported_horizons(int* out, int cap) {
 }
 
 const char* tpc_mpc_build_info(void) {
-    // assembled from what each LANE translation unit recorded about its own build (csrc/Makefile)
-    static thread_local char info[512];
-    std::snprintf(info, sizeof(info),
-                  "libtpc_mpc abi %d gfx950; lane units: h4[%s] h5[%s] h10[%s] h20[%s] h30[%s] h40[%s]",
-                  TPC_MPC_ABI_VERSION, lane_build_h4(), lane_build_h5(), lane_build_h10(), lane_build_h20(),
-                  lane_build_h30(), lane_build_h40());
+    // assembled once from what each LANE translation unit recorded about its own build (csrc/Makefile);
+    // static storage: valid for the process lifetime, as the header promises
+    static char info[512];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        std::snprintf(info, sizeof(info),
+                      "libtpc_mpc abi %d gfx950; lane units: h4[%s] h5[%s] h10[%s] h20[%s] h30[%s] h40[%s]",
+                      TPC_MPC_ABI_VERSION, lane_build_h4(), lane_build_h5(), lane_build_h10(), lane_build_h20(),
+                      lane_build_h30(), lane_build_h40());
+    });
     return info;
 }
 
@@ -406,7 +416,8 @@ int tpc_mpc_solve_batch_compact(tpc_mpc_handle h, const tpc_mpc_params* p, int64
         HIP_TRY(h, hipSetDevice(h->device));
         hipStream_t s = (hipStream_t)stream;
         const int64_t es = (int64_t)esize(p->dtype);
-        rc = stream_order_begin(h, s);
+        StreamOrderScope order(h, s);
+        rc = order.begin();
         if (rc) return rc;
         HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
         if (mem == TPC_MPC_DEVICE) {
@@ -429,7 +440,7 @@ int tpc_mpc_solve_batch_compact(tpc_mpc_handle h, const tpc_mpc_params* p, int64
             if (iters) HIP_TRY(h, hipMemcpyAsync(iters, d_it, n * 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(h, hipStreamSynchronize(s));
         }
-        rc = stream_order_end(h, s);
+        rc = order.end();
         if (rc) return rc;
         return finish_flags(h, flags_out, s);
     });
@@ -468,7 +479,8 @@ int tpc_mpc_solve_batch_general(tpc_mpc_handle h, const tpc_mpc_params* p,
         const int64_t n = io->n;
         const int algo = pick_algo(h, p->algo, I, H, n, p->dtype);
         if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel exists for the specialised horizons with inputs*horizon <= 64 only; use LANE or AUTO");
-        rc = stream_order_begin(h, s);
+        StreamOrderScope order(h, s);
+        rc = order.begin();
         if (rc) return rc;
 
         GeneralArgs a;
@@ -528,7 +540,7 @@ int tpc_mpc_solve_batch_general(tpc_mpc_handle h, const tpc_mpc_params* p,
             if (io->iters) HIP_TRY(h, hipMemcpyAsync(io->iters, a.iters, n * 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(h, hipStreamSynchronize(s));
         }
-        rc = stream_order_end(h, s);
+        rc = order.end();
         if (rc) return rc;
         return finish_flags(h, flags_out, s);
     });
@@ -555,7 +567,8 @@ int tpc_mpc_rollout(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mpc_gen
         const int64_t n = io->n, ld = io->ld;
         const int algo = pick_algo(h, p->algo, I, H, n, p->dtype);
         if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel exists for the specialised horizons with inputs*horizon <= 64 only; use LANE or AUTO");
-        rc = stream_order_begin(h, s);
+        StreamOrderScope order(h, s);
+        rc = order.begin();
         if (rc) return rc;
         const bool host = mem == TPC_MPC_HOST;
         const hipMemcpyKind in_kind = host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
@@ -644,7 +657,7 @@ int tpc_mpc_rollout(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mpc_gen
                 HIP_TRY(h, copy_rows(iters_out, ld * 4, d_iters, ldw * 4, n * 4, steps, hipMemcpyDeviceToHost, s));
             HIP_TRY(h, hipStreamSynchronize(s));
         }
-        rc = stream_order_end(h, s);
+        rc = order.end();
         if (rc) return rc;
         return finish_flags(h, flags_out, s);
     });
@@ -694,7 +707,8 @@ int tpc_mpc_follow_batch(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mp
         HIP_TRY(h, hipSetDevice(h->device));
         hipStream_t s = (hipStream_t)stream;
         const int64_t n = t->n;
-        rc = stream_order_begin(h, s);
+        StreamOrderScope order(h, s);
+        rc = order.begin();
         if (rc) return rc;
         // v | y_soll | phi_soll (the compact solve's inputs), produced on device
         const int64_t col = pad256(n * 8);
@@ -711,7 +725,7 @@ int tpc_mpc_follow_batch(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mp
         if (rc) return rc;
         e = launch_follow_post(n, target_speed, steering_front, steering_rear, s);
         if (e != hipSuccess) return hip_fail(h, e, "follow_post launch");
-        rc = stream_order_end(h, s);
+        rc = order.end();
         if (rc) return rc;
         return finish_flags(h, flags_out, s);
     });
@@ -738,7 +752,8 @@ int tpc_mpc_follow_batch_horizon(tpc_mpc_handle h, const tpc_mpc_params* p, cons
         const int H = p->horizon, I = 2;
         const int algo = pick_algo(h, p->algo, I, H, n, p->dtype);
         if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel exists for the specialised horizons with inputs*horizon <= 64 only; use LANE or AUTO");
-        rc = stream_order_begin(h, s);
+        StreamOrderScope order(h, s);
+        rc = order.begin();
         if (rc) return rc;
         // general-form batch built on device: A[4] B[4] C[2] Q[2] R[2] lo[2] hi[2] x0[2] targets[2H] u0[2]
         const int64_t ldw = (n + 63) / 64 * 64;
@@ -781,7 +796,7 @@ int tpc_mpc_follow_batch_horizon(tpc_mpc_handle h, const tpc_mpc_params* p, cons
         HIP_TRY(h, hipMemcpyAsync(steering_rear, w + off[9] + ldw * 8, n * 8, hipMemcpyDeviceToDevice, s));
         e = launch_follow_post(n, target_speed, steering_front, steering_rear, s);
         if (e != hipSuccess) return hip_fail(h, e, "follow_post launch");
-        rc = stream_order_end(h, s);
+        rc = order.end();
         if (rc) return rc;
         return finish_flags(h, flags_out, s);
     });
@@ -807,7 +822,7 @@ int tpc_mpc_reserve(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n, int me
     });
 }
 
-int tpc_mpc_set_work_hint(tpc_mpc_handle h, const int32_t* hint, int64_t n, int mem) {
+int tpc_mpc_x_set_work_hint(tpc_mpc_handle h, const int32_t* hint, int64_t n, int mem) {
     return guarded(h, [&]() -> int {
         if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
         h->hint = nullptr;
@@ -819,11 +834,33 @@ int tpc_mpc_set_work_hint(tpc_mpc_handle h, const int32_t* hint, int64_t n, int 
         HIP_TRY(h, hipSetDevice(h->device));
         int rc = ensure(h, &h->hint_own, &h->hint_own_bytes, n * 4);
         if (rc) return rc;
+        // the previous solve may still be reading the old copy: wait for it (its stream-order event), then copy
+        // synchronously -- a DEVICE hint must be complete when this is called
+        if (h->have_last) HIP_TRY(h, hipEventSynchronize(h->done_ev));
         HIP_TRY(h, hipMemcpy(h->hint_own, hint, (size_t)n * 4,
                              mem == TPC_MPC_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice));
         h->hint = (const int32_t*)h->hint_own;
         h->hint_n = n;
         return TPC_MPC_OK;
+    });
+}
+
+int tpc_mpc_set_option(tpc_mpc_handle h, int option, int64_t value) {
+    return guarded(h, [&]() -> int {
+        if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+        switch (option) {
+            case TPC_MPC_OPT_WAVE_GROUP:
+                if (value != 0 && value != 1 && value != 2 && value != 4)
+                    return fail(h, TPC_MPC_ERR_BAD_ARG, "TPC_MPC_OPT_WAVE_GROUP takes 0, 1, 2 or 4");
+                h->opt_wave_group = (int)value;
+                return TPC_MPC_OK;
+            case TPC_MPC_OPT_MAILBOX_HOST:
+                HIP_TRY(h, hipSetDevice(h->device));
+                one_shot_destroy(h);   // the next solve_one sets its mailbox up again, where this option says
+                h->opt_mailbox_host = value != 0;
+                return TPC_MPC_OK;
+        }
+        return fail(h, TPC_MPC_ERR_BAD_ARG, "unknown option %d", option);
     });
 }
 

@@ -86,6 +86,19 @@ int rccl_fail(tpc_mpc_context* h, Rccl* r, ncclResult_t e, const char* what) {
         if (e__ != ncclSuccess) return rccl_fail(h, r, e__, #call);   \
     } while (0)
 
+// ncclGroupStart .. ncclGroupEnd around a set of collectives.  The group is closed on EVERY path out of the
+// scope: a call that fails in between must not leave the thread's group depth above zero, or every later
+// collective of the thread would be queued and never launched (and the other ranks would wait for ever).
+// The first error is the one reported.
+struct GroupScope {
+    Rccl* r;
+    bool open = false;
+    explicit GroupScope(Rccl* rr) : r(rr) {}
+    ncclResult_t begin() { const ncclResult_t e = r->GroupStart(); open = e == ncclSuccess; return e; }
+    ncclResult_t end() { open = false; return r->GroupEnd(); }
+    ~GroupScope() { if (open) (void)r->GroupEnd(); }
+};
+
 }  // namespace
 
 void comm_destroy(tpc_mpc_context* h) {
@@ -127,10 +140,9 @@ int tpc_mpc_comm_init_rank(tpc_mpc_handle h, const void* id, size_t len, int ran
         if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
         if (world < 1 || rank < 0 || rank >= world) return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= rank < world");
         comm_destroy(h);
-        // a world of one needs no communicator -- unless the caller insists (TPC_MPC_FORCE_RCCL=1, or 2 for the ragged form of the gather: lets a
-        // one-GPU box exercise the RCCL calls themselves, which is how tests/test_abi_gpu.py uses it)
-        const char* force = std::getenv("TPC_MPC_FORCE_RCCL");
-        if (world == 1 && !(force && (force[0] == '1' || force[0] == '2'))) return TPC_MPC_OK;
+        // a world of one needs no communicator -- unless a test asked for one (tpc_mpc_comm_test_mode: lets a
+        // one-GPU box exercise the RCCL calls themselves)
+        if (world == 1 && !h->comm_test_force) return TPC_MPC_OK;
         if (!id || len < TPC_MPC_COMM_ID_BYTES) return fail(h, TPC_MPC_ERR_BAD_ARG, "id must hold %d bytes", TPC_MPC_COMM_ID_BYTES);
         Rccl* r = rccl();
         if (!r) return fail(h, TPC_MPC_ERR_COMM, "RCCL is not available in this process: %s", g_rccl.why);
@@ -144,6 +156,15 @@ int tpc_mpc_comm_init_rank(tpc_mpc_handle h, const void* id, size_t len, int ran
         c->rank = rank;
         c->world = world;
         h->comm = c;
+        return TPC_MPC_OK;
+    });
+}
+
+int tpc_mpc_comm_test_mode(tpc_mpc_handle h, int force_communicator, int force_ragged) {
+    return guarded(h, [&]() -> int {
+        if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+        h->comm_test_force = force_communicator != 0;
+        h->comm_test_ragged = force_ragged != 0;
         return TPC_MPC_OK;
     });
 }
@@ -202,7 +223,8 @@ int tpc_mpc_solve_batch_compact_sharded(tpc_mpc_handle h, const tpc_mpc_params* 
         const int64_t es = (int64_t)esize(p->dtype);
         char* front = (char*)steering_front_all;
         char* rear = (char*)steering_rear_all;
-        rc = stream_order_begin(h, s);
+        StreamOrderScope order(h, s);
+        rc = order.begin();
         if (rc) return rc;
         HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
         // this rank's block is solved straight into its slot of the full-size outputs
@@ -216,9 +238,9 @@ int tpc_mpc_solve_batch_compact_sharded(tpc_mpc_handle h, const tpc_mpc_params* 
             if (!r) return fail(h, TPC_MPC_ERR_COMM, "RCCL is not available in this process: %s", g_rccl.why);
             const ncclDataType_t dt = p->dtype == TPC_MPC_F64 ? ncclFloat64 : ncclFloat32;
             ncclComm_t c = h->comm->comm;
-            RCCL_TRY(h, r, r->GroupStart());
-            const char* force = std::getenv("TPC_MPC_FORCE_RCCL");   // '2': take the ragged form whatever the sizes (tests)
-            if (n_total % world == 0 && !(force && force[0] == '2')) {
+            GroupScope group(r);
+            RCCL_TRY(h, r, group.begin());
+            if (n_total % world == 0 && !h->comm_test_ragged) {
                 // equal blocks: two in-place all-gathers (each rank's send buffer IS its slot of the receive buffer)
                 RCCL_TRY(h, r, r->AllGather(front + first * es, front, (size_t)count, dt, c, s));
                 RCCL_TRY(h, r, r->AllGather(rear + first * es, rear, (size_t)count, dt, c, s));
@@ -232,9 +254,9 @@ int tpc_mpc_solve_batch_compact_sharded(tpc_mpc_handle h, const tpc_mpc_params* 
                     RCCL_TRY(h, r, r->Broadcast(rear + qf * es, rear + qf * es, (size_t)qc, dt, q, c, s));
                 }
             }
-            RCCL_TRY(h, r, r->GroupEnd());
+            RCCL_TRY(h, r, group.end());
         }
-        rc = stream_order_end(h, s);
+        rc = order.end();
         if (rc) return rc;
         return finish_flags(h, flags_out, s);
     });

@@ -64,6 +64,10 @@ struct tpc_mpc_context {
     bool have_last = false;
     // sharded solves (tpc_mpc_comm.cpp); null = a world of one
     tpc::Comm* comm = nullptr;
+    bool comm_test_force = false, comm_test_ragged = false;   // tpc_mpc_comm_test_mode
+    // tpc_mpc_set_option
+    int opt_wave_group = 0;          // 0 auto, 1 / 2 / 4 instances per wavefront (fp64 WAVE)
+    bool opt_mailbox_host = false;   // solve_one's request lines in pinned host memory
 };
 
 namespace tpc {
@@ -130,6 +134,18 @@ int check_compact_model(tpc_mpc_context* h, const tpc_mpc_params* p);
 int stream_order_begin(tpc_mpc_context* h, hipStream_t s);
 int stream_order_end(tpc_mpc_context* h, hipStream_t s);
 int finish_flags(tpc_mpc_context* h, uint32_t* flags_out, hipStream_t s);
+// stream_order_begin .. stream_order_end around everything an entry point enqueues.  The event behind the
+// work is recorded on EVERY path out of the scope -- an error return in the middle leaves copies, memsets or
+// kernels of this call on the stream, and the next solve (possibly on another stream) must still wait for them.
+struct StreamOrderScope {
+    tpc_mpc_context* h;
+    hipStream_t s;
+    bool armed = false;
+    StreamOrderScope(tpc_mpc_context* hh, hipStream_t ss) : h(hh), s(ss) {}
+    int begin() { const int rc = stream_order_begin(h, s); armed = rc == 0; return rc; }
+    int end() { armed = false; return stream_order_end(h, s); }
+    ~StreamOrderScope() { if (armed) (void)stream_order_end(h, s); }
+};
 // n instances of the compact form, arrays in DEVICE memory, launches only (no flag reset, no
 // stream-order bookkeeping, no synchronisation): the core of every compact entry point.
 int compact_launch(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy,

@@ -1,0 +1,25 @@
+/* Experimental entry points of libtpc_mpc.so that are NOT part of the drop-in boundary (include/tpc_mpc.h):
+ * exported for this repository's own measurements and tests, may change or go. */
+#ifndef TPC_MPC_EXPERIMENTAL_H
+#define TPC_MPC_EXPERIMENTAL_H
+
+#include "../../include/tpc_mpc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Queue-order hint.  Instances of a batch need between a few and several thousand iterations (mpc.h:271,
+ * :310) and a batch finishes when its slowest lane does, so the LANE families -- and the WAVE kernels over
+ * their work queue -- start the instances expected to run longest first; their own estimate is dlib's lambda
+ * (mpc.h:116-123).  hint[k] = expected iteration count of instance k replaces that estimate for the NEXT
+ * compact / general batch solve of this handle with the same n (copied into the handle by this call, forgotten
+ * after one solve; NULL clears).  It never changes a result, only which lane solves which instance when.
+ * Measured (scripts/hint_gain.py): exact counts of the same instances buy 7 % at N = 20; counts one control
+ * cycle old, inputs moved by 0.5 % of their range, buy nothing -- which is why this is not in the public header. */
+int tpc_mpc_x_set_work_hint(tpc_mpc_handle h, const int32_t* hint, int64_t n, int mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

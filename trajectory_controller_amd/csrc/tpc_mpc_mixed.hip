@@ -98,6 +98,10 @@ int run_mixed(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const int3
     T *gv = (T*)g, *gdy = (T*)(g + col), *gdphi = (T*)(g + 2 * col), *gfront = (T*)(g + 3 * col), *grear = (T*)(g + 4 * col);
     int32_t* giters = (int32_t*)(g + 5 * col);
 
+    // a pending queue-order hint was given for some batch of n instances, not for a bin that happens to have
+    // that size: forgotten here
+    h->hint = nullptr;
+    h->hint_n = 0;
     MixedBins bins;
     int hz[kBinsMax];
     bins.nb = tpc_mpc_supported_horizons(hz, kBinsMax - 1);
@@ -172,7 +176,8 @@ extern "C" int tpc_mpc_solve_batch_compact_mixed(tpc_mpc_handle h, const tpc_mpc
         const int64_t col = pad256(n * es), icol = pad256(n * 4);
         const int64_t bin_bytes = 256 + 2 * icol + 5 * col + icol;   // run_mixed's scratch
         const int64_t host_bytes = mem == TPC_MPC_HOST ? 5 * col + 2 * icol : 0;   // v dy dphi front rear | hz iters
-        rc = stream_order_begin(h, s);
+        StreamOrderScope order(h, s);
+        rc = order.begin();
         if (rc) return rc;
         rc = ensure(h, &h->mix, &h->mix_bytes, bin_bytes + host_bytes);
         if (rc) return rc;
@@ -205,7 +210,7 @@ extern "C" int tpc_mpc_solve_batch_compact_mixed(tpc_mpc_handle h, const tpc_mpc
             if (iters) HIP_TRY(h, hipMemcpyAsync(iters, d_iters, n * 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(h, hipStreamSynchronize(s));
         }
-        rc = stream_order_end(h, s);
+        rc = order.end();
         if (rc) return rc;
         return finish_flags(h, flags_out, s);
     });

@@ -168,7 +168,10 @@ int stop_kernel(tpc_mpc_context* h, OneShot* o) {
         volatile uint64_t* rq = request_lines(h);
         const uint64_t seq = ++o->seq;
         rq[kW_HorizonQuit] = 1ull << 32;
-        __atomic_thread_fence(__ATOMIC_RELEASE);
+        // the flag before the numbers, for real: a release fence orders nothing among write-combined BAR
+        // stores, the store fence drains them (as one_shot_solve does)
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        publish_request();
         rq[kW_Seq0] = seq; rq[kW_Seq1] = seq; rq[kW_Seq2] = seq;
         publish_request();
         HIP_TRY(h, hipStreamSynchronize(o->stream));   // bounded: quit flag, idle timeout, poll cap
@@ -195,13 +198,14 @@ int launch_path(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double dy
     // (a stream of its own: the resident wave occupies the other one for as long as it lives)
     OneShot* o = h->one;
     if (!o->launch_stream) HIP_TRY(h, hipStreamCreateWithFlags(&o->launch_stream, hipStreamNonBlocking));
-    int rc = stream_order_begin(h, o->launch_stream);
+    StreamOrderScope order(h, o->launch_stream);
+        int rc = order.begin();
     if (rc) return rc;
     h->collect_flags = false;
     rc = compact_launch(h, &q, 1, dp, dp + es, dp + 2 * es, dp + 3 * es, dp + 4 * es, nullptr, o->launch_stream);
     h->collect_flags = true;
     if (rc) return rc;
-    rc = stream_order_end(h, o->launch_stream);
+    rc = order.end();
     if (rc) return rc;
     bool done = false;
     const auto t0 = std::chrono::steady_clock::now();
@@ -245,11 +249,10 @@ int one_shot_configure(tpc_mpc_context* h, int64_t idle_us) {
         h->one = new (std::nothrow) OneShot;
         if (!h->one) return fail(h, TPC_MPC_ERR_ALLOC, "out of host memory");
         // Request lines in device memory, if the CPU can write it: every byte of VRAM sits behind the PCIe BAR
-        // ("large BAR"), and a fine-grained allocation is mapped for the host as well.  TPC_MPC_MAILBOX=host
+        // ("large BAR"), and a fine-grained allocation is mapped for the host as well.  TPC_MPC_OPT_MAILBOX_HOST
         // keeps them in the pinned block (the fallback on a part without a large BAR).
         int large_bar = 0;
-        const char* where = getenv("TPC_MPC_MAILBOX");
-        if (!(where && std::strcmp(where, "host") == 0) &&
+        if (!h->opt_mailbox_host &&
             hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, h->device) == hipSuccess && large_bar) {
             void* p = nullptr;
             if (hipExtMallocWithFlags(&p, 256, hipDeviceMallocFinegrained) == hipSuccess) {
@@ -322,8 +325,15 @@ int one_shot_solve(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double
             if (rc) return rc;
         }
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
-            o->disabled = true;   // never spin for ever: fall back to ordinary launches for this handle
-            return fail(h, TPC_MPC_ERR_HIP, "the resident solve_one kernel did not answer within 2 s");
+            // Never spin for ever.  The wave may still be alive and working on this very request: it is told to
+            // leave and WAITED FOR (bounded: quit flag, idle timeout, poll cap) before anything else happens, so
+            // that no late answer of it can ever be taken for the answer to a later request; the handle then
+            // solves through ordinary launches, starting with this request.
+            o->disabled = true;
+            int rc = stop_kernel(h, o);
+            if (rc) return rc;
+            if (m[kW_Front] != kSentinel && m[kW_Rear] != kSentinel) break;   // it did answer in the end
+            return launch_path(h, p, v, dy, dphi, front, rear);
         }
     }
     uint64_t fb = m[kW_Front], rb = m[kW_Rear];

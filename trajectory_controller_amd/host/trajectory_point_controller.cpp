@@ -1,10 +1,11 @@
-// Module shim: behaviour of TrajectoryPointController::cycle() for the tobiMPC back-end
-// (reference: src/trajectory_point_follower.cpp:8-126, :277-299, :392-476) with the QP solved by
+// Module shim: TrajectoryPointController::cycle() with the tobiMPC back-end
+// (reference: src/trajectory_point_follower.cpp:8-126, :227-299, :392-476) and the QP solved by
 // libtpc_mpc.so.  Written from the reference's observable behaviour, without dlib.
-// Only the path SURVEY.md section 8 puts in scope is here.  The host-side glue around it -- drive-mode
-// IDLE handling (:35-62), the PID back-end (:214-225), the turn indicators (:227-276) and the
-// andromeda back-end (:127-213, source not vendored) -- stays in the reference's own cycle(); a
-// maintainer applies the three edits of INTEGRATION.md to that file instead of using this one.
+// The whole cycle() of the reference is here -- drive-mode IDLE state (:35-52), default state (:54-61),
+// the tobiMPC branch (:64-126), turn indicators (:227-241), crossing rule (:277-283), putState (:286) --
+// except its two other back-ends: mikMPC (:127-213) calls call_andromeda() from a submodule that is not
+// vendored, and the PID back-end (:214-225) is outside this build's scope; both
+// are refused with an error, never emulated.
 #include "trajectory_point_controller.h"
 
 #include <cmath>
@@ -51,6 +52,21 @@ void TrajectoryPointController::configsChanged() {
 
 bool TrajectoryPointController::cycle() {
     using street_environment::CarCommand;
+    auto phx = getService<phoenix_CC2016_service::Phoenix_CC2016Service>("PHOENIX_SERVICE");
+
+    // drive mode IDLE: a priority-100 stand-still state, removed again once the mode is left (reference :35-52)
+    if (phx->driveMode() == phoenix_CC2016_service::CCDriveMode::IDLE) {
+        CarCommand::State idle;
+        if (CarCommand::State* prev = car->getState("IDLE")) idle = *prev;
+        idle.state = CarCommand::StateType::IDLE;
+        idle.priority = 100;
+        idle.name = "IDLE";
+        idle.steering_front = idle.steering_rear = idle.targetSpeed = 0;
+        car->putState(idle);
+        return true;
+    }
+    car->removeState("IDLE");
+
     CarCommand::State state;
     if (CarCommand::State* prev = car->getState("DEFAULT")) state = *prev;   // reference :55-61
     state.priority = 10;
@@ -65,7 +81,7 @@ bool TrajectoryPointController::cycle() {
     }
     if (!cycleTobiMpc(state)) return false;
 
-    applyCrossingRule(state);
+    applyIndicatorsAndCrossing(state);
     car->putState(state);   // reference :286
     return true;
 }
@@ -112,9 +128,23 @@ bool TrajectoryPointController::cycleTobiMpc(street_environment::CarCommand::Sta
     return true;
 }
 
-// reference :277-283: probably standing at a crossing -- no steering
-void TrajectoryPointController::applyCrossingRule(street_environment::CarCommand::State& state) {
-    if (state.targetSpeed < 0.5) state.steering_front = state.steering_rear = 0;
+// reference :227-241 and :277-283: the indicators are reset every cycle and set when the trajectory changes
+// side ahead; below 0.5 m/s (probably standing at a crossing) no steering and no indicators
+void TrajectoryPointController::applyIndicatorsAndCrossing(street_environment::CarCommand::State& state) {
+    state.indicatorLeft = state.indicatorRight = false;
+    if (!trajectory->empty()) {   // (the reference reads at(0) unguarded; an empty trajectory has no side to change)
+        const bool startsRight = trajectory->at(0).isRight();
+        for (const street_environment::TrajectoryPoint& p : *trajectory)
+            if (p.isRight() != startsRight) {
+                state.indicatorLeft = startsRight;
+                state.indicatorRight = !startsRight;
+                break;
+            }
+    }
+    if (state.targetSpeed < 0.5) {
+        state.indicatorLeft = state.indicatorRight = false;
+        state.steering_front = state.steering_rear = 0;
+    }
 }
 
 // reference :301-389.  The dlib controller of the reference is replaced by one C-ABI call; the model

@@ -38,7 +38,7 @@ public:
 
 private:
     bool cycleTobiMpc(street_environment::CarCommand::State& state);
-    void applyCrossingRule(street_environment::CarCommand::State& state);
+    void applyIndicatorsAndCrossing(street_environment::CarCommand::State& state);
 
     lms::math::LookupTable<float, lms::math::LookupTableOrder::ASC> m_mpcLookupVelocity;
     lms::math::LookupTable<float, lms::math::LookupTableOrder::ASC> m_trajectoryPointDistanceLookup;

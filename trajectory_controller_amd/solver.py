@@ -105,6 +105,10 @@ class MpcSolver:
 
     solve_one = mpc_controller_tobi
 
+    def set_option(self, option: int, value: int):
+        """tpc_mpc_set_option: capi.OPT_WAVE_GROUP (0 auto, 1, 2, 4), capi.OPT_MAILBOX_HOST (0 / 1)."""
+        self._check(self._lib.tpc_mpc_set_option(self._h, int(option), int(value)))
+
     def set_resident(self, idle_timeout_us: int = 20000):
         """solve_one's resident wavefront: idle timeout in microseconds, <= 0 turns it off
         (tpc_mpc_set_resident)."""
@@ -123,22 +127,23 @@ class MpcSolver:
         self._check(self._lib.tpc_mpc_reserve(self._h, C.byref(p), int(n), capi.HOST if host else capi.DEVICE))
 
     def set_work_hint(self, hint):
-        """Queue-order hint for the next batch solve of the same size (tpc_mpc_set_work_hint):
+        """Queue-order hint for the next batch solve of the same size (experimental: tpc_mpc_x_set_work_hint,
+        csrc/tpc_mpc_experimental.h):
         per-instance iteration-count estimates, typically the `iters` of the previous cycle.
         int32 numpy array (copied) or CUDA tensor (read by the next solve; keep it alive until
         then).  None clears.  Never changes a result, only the order lanes pick instances up."""
         if hint is None:
-            self._check(self._lib.tpc_mpc_set_work_hint(self._h, None, 0, capi.HOST))
+            self._check(self._lib.tpc_mpc_x_set_work_hint(self._h, None, 0, capi.HOST))
             self._hint_ref = None
         elif _is_torch(hint):
             import torch
             if not (hint.is_cuda and hint.dtype == torch.int32 and hint.is_contiguous()):
                 raise ValueError("a device hint must be a contiguous int32 CUDA tensor")
             self._hint_ref = hint
-            self._check(self._lib.tpc_mpc_set_work_hint(self._h, hint.data_ptr(), hint.numel(), capi.DEVICE))
+            self._check(self._lib.tpc_mpc_x_set_work_hint(self._h, hint.data_ptr(), hint.numel(), capi.DEVICE))
         else:
             h = np.ascontiguousarray(hint, dtype=np.int32)
-            self._check(self._lib.tpc_mpc_set_work_hint(self._h, h.ctypes.data, h.shape[0], capi.HOST))
+            self._check(self._lib.tpc_mpc_x_set_work_hint(self._h, h.ctypes.data, h.shape[0], capi.HOST))
 
     def solve_batch_compact(self, v, delta_y, delta_phi, want_iters: bool = False,
                             want_flags: bool = True, out=None, **over):
@@ -227,6 +232,10 @@ class MpcSolver:
         if rc != capi.OK:
             raise capi.TpcMpcError(rc, lib.tpc_mpc_last_error(None).decode())
         return bytes(buf)
+
+    def comm_test_mode(self, force_communicator: bool, force_ragged: bool = False):
+        """Test hook (tpc_mpc_comm_test_mode): a real one-rank communicator / the ragged exchange on one GPU."""
+        self._check(self._lib.tpc_mpc_comm_test_mode(self._h, int(force_communicator), int(force_ragged)))
 
     def comm_init(self, comm_id: bytes, rank: int, world: int):
         """Join the job's RCCL communicator as `rank` of `world` (tpc_mpc_comm_init_rank)."""

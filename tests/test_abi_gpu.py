@@ -176,7 +176,7 @@ def test_build_info_names_the_schedulers(torch_cuda):
     from trajectory_controller_amd import MpcSolver
     info = MpcSolver.build_info()
     print(info)
-    assert "abi 2" in info and all(f"h{h}[sched=default]" in info for h in (4, 5, 10, 20, 30, 40))
+    assert "abi 3" in info and all(f"h{h}[sched=default]" in info for h in (4, 5, 10, 20, 30, 40))
 
 
 # ---------------------------------------------------------------------------------------------

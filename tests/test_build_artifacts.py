@@ -1,12 +1,12 @@
 """The shipped library, inspected statically (no GPU): which kernels touch scratch (spill) memory inside an
-innermost loop.  Background: one build of the two-variables-per-lane WAVE kernel ran out of
-AGPRs, kept a dword of a Hessian entry in scratch and reloaded it inside its iteration loops -- and returned wrong
-controls for one instance in nine, while every scratch-free build of the same source agrees with dlib to 1e-13
-(caught by test_wave_queue_vs_oracle[40] on the GPU).  The cause was not found (another build that spills
-inside its loops is correct, so the spill is a marker of that build, not the bug), so the kernels the BASELINE configs
-run -- the compact-form WAVE kernels and the resident single-solve kernels -- must not spill inside a loop; it would
-also be a performance bug there.  (The LANE fp64 N = 40 kernels spill in their loop by design and are checked bit for
-bit against dlib; general-form WAVE kernels that do are listed, not refused.)"""
+innermost loop.  Background ("a build that was wrong"): one build of the two-variables-per-lane WAVE
+kernel ran out of AGPRs, kept a dword of a Hessian entry in scratch and reloaded it inside its iteration loops --
+and returned wrong controls for one instance in nine, while every scratch-free build of the same source agrees with
+dlib to 1e-13 (caught by test_wave_queue_vs_oracle[40] on the GPU).  The cause was never pinned to an instruction, so
+its precondition is removed instead: NO kernel of the WAVE family -- compact or general form, plain, queue, grouped,
+the queue-order kernel, the resident single-solve kernels -- and no projected-gradient kernel of the LANE_FMA family
+may access scratch inside a loop.  (The bit-exact LANE kernels at N = 40, and the coordinate-descent kernels at
+N = 40, do spill in their loops; they are checked bit for bit against dlib / the model on the GPU and are listed.)"""
 import os
 import sys
 
@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 LIB = os.path.join(ROOT, "trajectory_controller_amd", "lib", "libtpc_mpc.so")
 
+MUST_BE_CLEAN = ("wave_", "one_shot_kernel", "ub_pg_kernel")
+
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"), reason="needs llvm-objdump")
 def test_no_scratch_inside_wave_loops():
@@ -23,8 +25,11 @@ def test_no_scratch_inside_wave_loops():
     if not os.path.exists(LIB):
         __graft_entry__.build()
     import check_loop_scratch
-    bad = check_loop_scratch.offenders(LIB, ["wave_kernel", "wave_queue_kernel", "one_shot_kernel"])
-    must_be_clean = [name for name, _ in bad if "CompactModel" in name or "one_shot_kernel" in name]
+    bad = check_loop_scratch.offenders(LIB, [])
+    refused = [name for name, _ in bad if any(tag in name for tag in MUST_BE_CLEAN)]
     for name, n in bad:
         print(f"{n} scratch accesses inside an innermost loop: {name}")
-    assert not must_be_clean, must_be_clean
+    assert not refused, refused
+    # the listed rest is exactly the N = 40 fp64 kernels known to spill (a new name here wants a look)
+    assert all("Li40E" in name and ("lane_" in name or "ub_cd_kernel" in name) or "lane_cd_kernel" in name
+               for name, _ in bad), [name for name, _ in bad]

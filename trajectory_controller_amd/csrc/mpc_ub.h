@@ -197,7 +197,9 @@ template <typename T, int H> struct UbPlan {
     // 0.237 / 0.260 / 0.963 ms per 262 144 instances against 0.195 / 0.236 / 0.929 with one; N = 20 with v in
     // LDS or with the forward pass regenerated: 6.9-7.7 ms against 5.35): a second wave adds no issue slots
     // to a stream of 3-operand fp64 instructions, and halves the instances per lane of the persistent grid.
-    static constexpr int occ_default = D ? 1 : ((6 * H * words <= 120) ? 2 : 1);
+    // fp32 (measured per horizon, 262 144 instances, one / two waves per SIMD): N = 4: 0.194 / 0.257 ms, N = 5:
+    // 0.241 / 0.260, N = 10: 0.943 / 0.788, N = 20: 5.58 / 5.26, N = 30: 18.4 / 19.5 -- two only at N = 10 and 20.
+    static constexpr int occ_default = D ? 1 : ((H == 10 || H == 20) ? 2 : 1);
     static constexpr int occ = TPC_UB_OCC > 0 ? TPC_UB_OCC : occ_default;
     // forward pass checkpointed (even steps kept, odd steps recomputed in the backward pass): in AGPRs where
     // x and w together exceed the VGPRs (fp64, H >= 30); TPC_UB_CKPT=1: in VGPRs (A/B at H = 20)

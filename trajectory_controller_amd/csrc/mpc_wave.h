@@ -890,13 +890,17 @@ TPC_DEV void wave2_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s
     }
     my_r[0] = active ? m.R(0) : (T)0;
     my_r[1] = active ? m.R(1) : (T)0;
-    const T lambda = wave_sum_all<NL>((my_qd[0] + my_r[0]) + (my_qd[1] + my_r[1]));
-    const T lo[2] = {m.lo(0), m.lo(1)}, hi[2] = {m.hi(0), m.hi(1)};
+    // Everything below that is the same in all lanes -- one instance per wavefront: its bounds, and whatever follows
+    // from the Hessian's trace -- is handed to the scalar registers (a register move, the value unchanged): the two
+    // Hessian rows and the state leave the general model's kernel no vector register to spare, and what did not fit
+    // was reloaded from scratch inside the iteration loops.
+    const T lambda = wave_uniform(wave_sum_all<NL>((my_qd[0] + my_r[0]) + (my_qd[1] + my_r[1])));
+    const T lo[2] = {wave_uniform(m.lo(0)), wave_uniform(m.lo(1))}, hi[2] = {wave_uniform(m.hi(0)), wave_uniform(m.hi(1))};
     const T eps = (T)kn.eps;
     const T my_rqd[2] = {(T)1 / my_qd[0], (T)1 / my_qd[1]};
-    const T inv_lambda = (T)1.0 / lambda;
+    const T inv_lambda = wave_uniform((T)1.0 / lambda);
     const T sq = tsqrt(lambda);
-    const T beta = (sq - (T)1) / (sq + (T)1);
+    const T beta = wave_uniform((sq - (T)1) / (sq + (T)1));
 
     T u[2], v[2];
 #pragma unroll
@@ -1113,9 +1117,15 @@ TPC_DEV void wave_solve_any(const Args& g, const Knobs& kn, int64_t k, T* s_w, T
 #ifndef TPC_WAVE_MIN_WAVES
 #define TPC_WAVE_MIN_WAVES 2
 #endif
-template <typename T, int I, int H> constexpr int wave_min_waves() { return wave_two_per_lane<I, H>() ? 1 : TPC_WAVE_MIN_WAVES; }
+// (the general model's 60-variable fp64 kernels -- a Hessian row of 120 registers beside the per-instance model --
+// do not fit 256 registers without spilling inside their loops: they get the whole file, one wavefront per SIMD)
+template <typename T, int I, int H, class Model = void> constexpr int wave_min_waves() {
+    constexpr bool big_general = sizeof(T) == 8 && I * H > 48 && !std::is_same<Model, CompactModel<T>>::value &&
+                                 !std::is_same<Model, void>::value;
+    return (wave_two_per_lane<I, H>() || big_general) ? 1 : TPC_WAVE_MIN_WAVES;
+}
 template <typename T, int I, int H, class Model, class Args>
-__global__ __launch_bounds__((waves_per_block<T, I, H>() * kWave)) __attribute__((amdgpu_waves_per_eu(wave_min_waves<T, I, H>())))
+__global__ __launch_bounds__((waves_per_block<T, I, H>() * kWave)) __attribute__((amdgpu_waves_per_eu(wave_min_waves<T, I, H, Model>())))
 void wave_kernel(Args g, Knobs kn) {
     constexpr int WPB = waves_per_block<T, I, H>();
     __shared__ __attribute__((aligned(16))) T s_w[WPB][wave_lt_lds<T, I, H>()];
@@ -1180,8 +1190,16 @@ __global__ __launch_bounds__(kOrderThreads) void wave_order_kernel(Args g, uint3
                     float lf;
                     if constexpr (std::is_same<Model, CompactModel<T>>::value)
                         lf = (float)tabs(m.a);   // one batch-wide Q, R, T, l: lambda grows with |T v|, which orders the same
-                    else
-                        lf = (float)ctor_lambda_qdiag<T, I, H>(m, [](int, int, T) {});
+                    else {
+                        // a sort key only: the trace bound in fp32 on an fp32 copy of the model (half the registers of
+                        // the fp64 recurrence, which spilled inside this loop)
+                        GeneralModel<float, I> mf;
+                        mf.a00 = (float)m.a00; mf.a01 = (float)m.a01; mf.a10 = (float)m.a10; mf.a11 = (float)m.a11;
+#pragma unroll
+                        for (int jj = 0; jj < I; ++jj) { mf.b[0][jj] = (float)m.b[0][jj]; mf.b[1][jj] = (float)m.b[1][jj]; mf.r[jj] = (float)m.r[jj]; }
+                        mf.q0 = (float)m.q0; mf.q1 = (float)m.q1;
+                        lf = ctor_lambda_qdiag<float, I, H>(mf, [](int, int, float) {});
+                    }
                     key[j] = (lf > 0.0f && lf < __builtin_inff()) ? (uint32_t)__float_as_int(lf) : 0u;
                 }
                 lo = key[j] < lo ? key[j] : lo;
@@ -1265,7 +1283,7 @@ void wave_pair_queue_kernel(Args g, Knobs kn, const uint32_t* __restrict__ order
 // asks for its next position when the set-up of the current instance is done, just before its iteration loops
 // (see wave_solve: any earlier and the in-order wait counter makes the set-up's own loads wait for the ticket).
 template <typename T, int I, int H, class Model, class Args>
-__global__ __launch_bounds__((waves_per_block<T, I, H>() * kWave)) __attribute__((amdgpu_waves_per_eu(wave_min_waves<T, I, H>())))
+__global__ __launch_bounds__((waves_per_block<T, I, H>() * kWave)) __attribute__((amdgpu_waves_per_eu(wave_min_waves<T, I, H, Model>())))
 void wave_queue_kernel(Args g, Knobs kn, const uint32_t* __restrict__ order, uint32_t* tickets) {
     constexpr int WPB = waves_per_block<T, I, H>();
     __shared__ __attribute__((aligned(16))) T s_w[WPB][wave_lt_lds<T, I, H>()];

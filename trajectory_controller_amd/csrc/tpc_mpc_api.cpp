@@ -79,7 +79,11 @@ int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n, int d
     // (the queue's crossover was measured on a 256-CU part; a smaller one -- a CPX partition -- scales it down)
     const int64_t queue_cross = (kWaveQueueMaxInstances * h->cu_count / 256 < kWaveQueueMaxInstances
                                      ? kWaveQueueMaxInstances * h->cu_count / 256 : kWaveQueueMaxInstances) + 1;
-    const int64_t crossover = I * H > kWave ? lanes * 19 / 64
+    // (N = 40, two inputs: a LANE pass lasts as long as its slowest instance whatever the batch -- 10 000 iterations of
+    // 5.1 us in the bit-exact family, 2.9 us in LANE_FMA: 51 / 29.5 ms -- and the two-variables-per-lane WAVE kernel
+    // takes 2.6 us per instance: 42 ms at 16 384.  So WAVE up to 19 456 instances against LANE, 11 264 against LANE_FMA.)
+    const int64_t two_per_lane_cross = fma_ok ? lanes * 11 / 64 : lanes * 19 / 64;
+    const int64_t crossover = I * H > kWave ? two_per_lane_cross
                               : ((H >= 20 || paired) ? queue_cross : lanes * 7 / 16);
     return (n >= crossover || !wave_ok) ? lane : TPC_MPC_ALGO_WAVE;
 }
@@ -271,6 +275,26 @@ int reserve_lane_workspace(tpc_mpc_context* h, int H, int dtype, int64_t n) {
     return rc;
 }
 
+int context_new(int device, int cu_count, tpc_mpc_context** out) {
+    tpc_mpc_context* h = new (std::nothrow) tpc_mpc_context;
+    if (!h) return fail(nullptr, TPC_MPC_ERR_ALLOC, "out of host memory");
+    h->device = device;
+    h->cu_count = cu_count;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->ws_words, 64);
+    if (e == hipSuccess) e = hipMemset(h->ws_words, 0, 64);
+    if (e == hipSuccess) e = hipHostMalloc(&h->pin_host, 512, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&h->pin_dev, h->pin_host, 0);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->done_ev, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        (void)tpc_mpc_destroy(h);
+        return fail(nullptr, TPC_MPC_ERR_HIP, "create: %s", hipGetErrorString(e));
+    }
+    std::memset(h->pin_host, 0, 512);
+    *out = h;
+    return TPC_MPC_OK;
+}
+
 int compact_launch(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy,
                    const void* dphi, void* front, void* rear, int32_t* iters, hipStream_t s) {
     const int algo = pick_algo(h, p->algo, 2, p->horizon, n, p->dtype, fma_usable(p));
@@ -357,23 +381,7 @@ int tpc_mpc_create(int device, tpc_mpc_handle* out) {
         if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return fail(nullptr, TPC_MPC_ERR_NO_DEVICE, "device is %s, this library carries gfx950 code only",
                         prop.gcnArchName);
-        tpc_mpc_context* h = new (std::nothrow) tpc_mpc_context;
-        if (!h) return fail(nullptr, TPC_MPC_ERR_ALLOC, "out of host memory");
-        h->device = device;
-        h->cu_count = prop.multiProcessorCount;
-        e = hipSetDevice(device);
-        if (e == hipSuccess) e = hipMalloc((void**)&h->ws_words, 64);
-        if (e == hipSuccess) e = hipMemset(h->ws_words, 0, 64);
-        if (e == hipSuccess) e = hipHostMalloc(&h->pin_host, 512, hipHostMallocMapped | hipHostMallocCoherent);
-        if (e == hipSuccess) e = hipHostGetDevicePointer(&h->pin_dev, h->pin_host, 0);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->done_ev, hipEventDisableTiming);
-        if (e != hipSuccess) {
-            (void)tpc_mpc_destroy(h);
-            return fail(nullptr, TPC_MPC_ERR_HIP, "create: %s", hipGetErrorString(e));
-        }
-        std::memset(h->pin_host, 0, 512);
-        *out = h;
-        return TPC_MPC_OK;
+        return context_new(device, prop.multiProcessorCount, out);
     });
 }
 
@@ -383,6 +391,12 @@ int tpc_mpc_destroy(tpc_mpc_handle h) {
         (void)hipSetDevice(h->device);
         one_shot_destroy(h);   // stops the resident kernel before its mailbox goes away
         comm_destroy(h);
+        for (int i = 0; i < tpc_mpc_context::kMaxKids; ++i) {
+            if (h->kid_stream[i]) { (void)hipStreamSynchronize(h->kid_stream[i]); (void)hipStreamDestroy(h->kid_stream[i]); }
+            if (h->kid_done[i]) (void)hipEventDestroy(h->kid_done[i]);
+            if (h->kids[i]) (void)tpc_mpc_destroy(h->kids[i]);
+        }
+        if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
         if (h->ws_state) (void)hipFree(h->ws_state);
         if (h->ws_words) (void)hipFree(h->ws_words);
         if (h->stage) (void)hipFree(h->stage);

@@ -16,7 +16,9 @@
 #include "mpc_internal.h"
 
 namespace tpc {
-struct OneShot;   // tpc_mpc_one.hip: the resident single-solve kernel's host side
+struct OneShot;   // a handle's device-side state for `device` (what tpc_mpc_create makes); the caller has checked the device
+int context_new(int device, int cu_count, tpc_mpc_context** out);
+// tpc_mpc_one.hip: the resident single-solve kernel's host side
 struct Comm;      // tpc_mpc_comm.cpp: RCCL communicator of a sharded solve
 }  // namespace tpc
 
@@ -65,6 +67,13 @@ struct tpc_mpc_context {
     // sharded solves (tpc_mpc_comm.cpp); null = a world of one
     tpc::Comm* comm = nullptr;
     bool comm_test_force = false, comm_test_ragged = false;   // tpc_mpc_comm_test_mode
+    // mixed-horizon batches run their bins concurrently: one child handle (scratch of its own) and one stream
+    // per bin, forked from and joined back into the caller's stream (tpc_mpc_mixed.hip)
+    static constexpr int kMaxKids = 8;
+    tpc_mpc_context* kids[kMaxKids] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t kid_stream[kMaxKids] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t kid_done[kMaxKids] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr;
     // tpc_mpc_set_option
     int opt_wave_group = 0;          // 0 auto, 1 / 2 / 4 instances per wavefront (fp64 WAVE)
     bool opt_mailbox_host = false;   // solve_one's request lines in pinned host memory
@@ -153,6 +162,8 @@ int compact_launch(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const
 // scratch of the LANE family for (H, dtype, n), without launching (grows the handle's workspace)
 int reserve_lane_workspace(tpc_mpc_context* h, int H, int dtype, int64_t n);
 
+// a handle's device-side state for `device` (what tpc_mpc_create makes); the caller has checked the device
+int context_new(int device, int cu_count, tpc_mpc_context** out);
 // tpc_mpc_one.hip
 int one_shot_solve(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double dy, double dphi, double* front,
                    double* rear);

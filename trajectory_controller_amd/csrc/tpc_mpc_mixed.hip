@@ -85,6 +85,11 @@ __global__ __launch_bounds__(256) void mixed_scatter_kernel(int64_t n, const uin
     if (iters) iters[k] = giters[pos];
 }
 
+__global__ void mixed_or_flags_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src) {
+    const uint32_t f = *src;
+    if (f) atomicOr(dst, f);
+}
+
 template <typename T>
 int run_mixed(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const int32_t* d_hz, const T* d_v, const T* d_dy,
               const T* d_dphi, T* d_front, T* d_rear, int32_t* d_iters, char* scratch, hipStream_t s) {
@@ -123,21 +128,46 @@ int run_mixed(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const int3
     hipLaunchKernelGGL((mixed_gather_kernel<T>), dim3(grid), dim3(256), 0, s, d_hz, n, bins, (const uint32_t*)slot,
                        (const uint32_t*)offsets, d_v, d_dy, d_dphi, gv, gdy, gdphi, perm);
     HIP_TRY(h, hipGetLastError());
-    // size the solver scratch for every bin BEFORE the first launch: growing it frees device memory,
-    // and a free must not meet an earlier bin's kernels in flight
-    for (int i = 0; i < bins.nb; ++i)
-        if (hc[i]) {
-            int rc = reserve_lane_workspace(h, bins.horizon[i], p->dtype, hc[i]);
-            if (rc) return rc;
-        }
-    for (int i = 0; i < bins.nb; ++i) {
+    // (every bin's scratch belongs to its own child handle and is grown by that bin's launch, before that bin's
+    // kernels; growing frees and allocates device memory, which synchronises the device: only ever on a handle's
+    // first batches)
+    // The bins are independent batches, and a LANE pass over a bin smaller than the chip lasts as long as its
+    // slowest instance on a fraction of the SIMDs (N = 40: 29 ms on a quarter of them at 16 384 instances): they
+    // run CONCURRENTLY, each on a child handle (scratch, ticket and flag word of its own) and a stream of its own,
+    // forked from the caller's stream here and joined back into it below; longest horizon first.
+    int live = 0;
+    for (int i = 0; i < bins.nb; ++i) live += hc[i] ? 1 : 0;
+    if (!h->fork_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+    HIP_TRY(h, hipEventRecord(h->fork_ev, s));
+    for (int i = bins.nb - 1; i >= 0; --i) {
         if (!hc[i]) continue;
         tpc_mpc_params q = *p;
         q.horizon = bins.horizon[i];
         const int64_t o = ho[i];
-        int rc = compact_launch(h, &q, hc[i], gv + o, gdy + o, gdphi + o, gfront + o, grear + o,
-                                d_iters ? giters + o : nullptr, s);
-        if (rc) return rc;
+        if (live == 1) {   // nothing to overlap with: the handle itself, on the caller's stream
+            int rc = compact_launch(h, &q, hc[i], gv + o, gdy + o, gdphi + o, gfront + o, grear + o,
+                                    d_iters ? giters + o : nullptr, s);
+            if (rc) return rc;
+            continue;
+        }
+        if (!h->kids[i]) {
+            int rc = context_new(h->device, h->cu_count, &h->kids[i]);
+            if (rc) return fail(h, rc, "mixed batch: child handle: %s", g_create_error);
+            HIP_TRY(h, hipStreamCreateWithFlags(&h->kid_stream[i], hipStreamNonBlocking));
+            HIP_TRY(h, hipEventCreateWithFlags(&h->kid_done[i], hipEventDisableTiming));
+        }
+        tpc_mpc_context* kid = h->kids[i];
+        kid->opt_wave_group = h->opt_wave_group;
+        hipStream_t ks = h->kid_stream[i];
+        HIP_TRY(h, hipStreamWaitEvent(ks, h->fork_ev, 0));
+        HIP_TRY(h, hipMemsetAsync(kid->ws_words + 1, 0, sizeof(uint32_t), ks));
+        int rc = compact_launch(kid, &q, hc[i], gv + o, gdy + o, gdphi + o, gfront + o, grear + o,
+                                d_iters ? giters + o : nullptr, ks);
+        if (rc) return fail(h, rc, "mixed batch, horizon %d: %s", q.horizon, kid->err);
+        hipLaunchKernelGGL(mixed_or_flags_kernel, dim3(1), dim3(1), 0, ks, h->ws_words + 1, (const uint32_t*)(kid->ws_words + 1));
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(h->kid_done[i], ks));
+        HIP_TRY(h, hipStreamWaitEvent(s, h->kid_done[i], 0));
     }
     hipLaunchKernelGGL((mixed_scatter_kernel<T>), dim3(grid), dim3(256), 0, s, n, (const uint32_t*)perm, (const T*)gfront,
                        (const T*)grear, (const int32_t*)giters, d_front, d_rear, d_iters);

@@ -39,15 +39,17 @@ void solve_one(T v, T ty, T tphi, const T* q, const T* r, double step, double wh
     // ---- coordinate descent (mpc.h:319-335)
     const unsigned long cd_iters = smo_iters < max_iter ? smo_iters : max_iter;
     for (unsigned long it = 0; it < cd_iters && !stopped; ++it) {
+        constexpr bool RVC = Reverse<T, H>::value;   // the forward pass regenerated in the backward sweep
         T Z, Y;
         m.fwd_init(Z, Y);
         for (int i = 0; i < H; ++i) { m.fwd(Z, Y, x[2 * i], x[2 * i + 1]); wz[i] = Z; wy[i] = Y; }
         T n0, n1;
-        m.bwd_last(n0, n1, wz[H - 1], wy[H - 1]);
+        m.bwd_last(n0, n1, Z, Y);
         for (int i = H - 1; i >= 0; --i) {
-            if (i < H - 1) m.bwd(n0, n1, wz[i], wy[i]);
+            if (i < H - 1) m.bwd(n0, n1, RVC ? Z : wz[i], RVC ? Y : wy[i]);
             dd[2 * i] = m.df0(n1, x[2 * i]);
             dd[2 * i + 1] = m.df1(n0, n1, x[2 * i + 1]);
+            if (RVC && i > 0) m.rev(Z, Y, x[2 * i], x[2 * i + 1]);
         }
         T max_df = (T)0;
         int best = 0;

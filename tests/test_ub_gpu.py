@@ -117,6 +117,29 @@ def test_ub_other_bounds(torch_cuda, model, oracle, lo, hi, fast):
     assert np.array_equal(it, oit) and max(np.abs(f - of).max(), np.abs(r - orr).max()) <= UB_ATOL
 
 
+@pytest.mark.parametrize("H,n", [(30, 400), (40, 300)])
+def test_ub_exact_build_long_horizons(torch_cuda, model, oracle, H, n):
+    """The exact-stop-test build of the projected-gradient kernel at N = 30 / 40 (a box that does not contain the
+    start point fails the fast test's screen): the N = 40 one reloads spilled values inside its loop (listed by
+    tests/test_build_artifacts.py), so it is held to the model bit for bit here."""
+    from trajectory_controller_amd.synth import compact_inputs
+    lo, hi = (0.02, -0.35), (0.3, -0.05)
+    v, dy, dphi = compact_inputs(H, n, first=4100)
+    of, orr, oit = oracle.solve_compact(H, v, dy, dphi, lo=lo, hi=hi, nthreads=8)
+    mf, mr, mit, _ = model.solve_compact(H, v, dy, dphi, lo=lo, hi=hi, nthreads=8, fast_stop=False)
+    with _solver(H, lower=lo, upper=hi) as s:
+        f, r, it = _run(torch_cuda, s, v, dy, dphi)
+    assert np.array_equal(it, mit) and bits_equal(f, mf) and bits_equal(r, mr)
+    assert np.array_equal(it, oit) and max(np.abs(f - of).max(), np.abs(r - orr).max()) <= UB_ATOL
+    # ... and through many projected-gradient iterations: an eps the screen refuses, ended by the iteration cap
+    mf, mr, mit, _ = model.solve_compact(H, v, dy, dphi, eps=1e-12, max_iter=700, nthreads=8, fast_stop=False)
+    of, orr, oit = oracle.solve_compact(H, v, dy, dphi, eps=1e-12, max_iter=700, nthreads=8)
+    with _solver(H, eps=1e-12, max_iter=700) as s:
+        f, r, it = _run(torch_cuda, s, v, dy, dphi)
+    assert np.array_equal(it, mit) and bits_equal(f, mf) and bits_equal(r, mr)
+    assert it.max() == 700 and max(np.abs(f - of).max(), np.abs(r - orr).max()) <= 1e-7
+
+
 def test_ub_knobs_edges_and_exact_build(torch_cuda, model, oracle):
     torch = torch_cuda
     from trajectory_controller_amd import FLAG_MAX_ITER, FLAG_NONFINITE

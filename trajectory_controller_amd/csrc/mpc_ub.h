@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void ub_cd_kernel(Compact
     const bool nonfinite = m.nonfinite_inputs(ty, tphi);
     const T q0 = (T)g.q[0], q1 = (T)g.q[1], r0 = (T)g.r[0], r1 = (T)g.r[1];
 
-    T x[2 * H], w[2 * H];
+    T x[2 * H], w[ub::Reverse<T, H>::value ? 1 : 2 * H];
 #pragma unroll
     for (int i = 0; i < H; ++i) { x[2 * i] = m.xz0; x[2 * i + 1] = m.xz1; }
     const T lambda = ub::ctor_lambda_qdiag<T, H>(m.a, m.c, q0, q1, r0, r1, [&](int i, int j, T val) {
@@ -94,36 +94,43 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void ub_cd_kernel(Compact
 #pragma unroll 1
     for (uint32_t it = 0; it < cd_iters; ++it) {
         if (__ballot(!stopped) == 0ull) break;
-        // gradient (mpc.h:275-283 in unit coordinates): w <- (Z, Y) forward, then df backward
+        // gradient (mpc.h:275-283 in the family's coordinates) fused with the arg-max scan: forward pass, then one
+        // backward sweep that forms df[i] and offers it to the running arg-max at once, so no gradient is ever
+        // stored.  dlib scans i then j ascending with a strict '>' (mpc.h:289-309): the lowest index among equal
+        // maxima wins; this sweep runs i and j DESCENDING with '>=', which picks the same one.  Where the family
+        // regenerates the forward pass (ub::Reverse) nothing of it is kept either.
+        constexpr bool RV = ub::Reverse<T, H>::value;
         T Z, Y;
         m.fwd_init(Z, Y);
 #pragma unroll
         for (int i = 0; i < H; ++i) {
             m.fwd(Z, Y, x[2 * i], x[2 * i + 1]);
-            w[2 * i] = Z; w[2 * i + 1] = Y;
+            if constexpr (!RV) { w[2 * i] = Z; w[2 * i + 1] = Y; }
         }
         T n0, n1;
         m.bwd_last(n0, n1, Z, Y);
-#pragma unroll
-        for (int i = H - 1; i >= 0; --i) {
-            if (i < H - 1) m.bwd(n0, n1, w[2 * i], w[2 * i + 1]);
-            w[2 * i] = m.df0(n1, x[2 * i]);
-            w[2 * i + 1] = m.df1(n0, n1, x[2 * i + 1]);
-        }
-        // arg-max |df| over free variables, i then j, strict '>' (mpc.h:289-309), as selects
         T max_df = (T)0, best_x = (T)0;
         int best = 0, best_sign = 0;
 #pragma unroll
-        for (int q = 0; q < 2 * H; ++q) {
-            const T xx = x[q], dd = w[q];
-            const T up = (xx <= m.bl(q & 1)) ? (T)0 : dd;
-            const T dn = (xx >= m.bh(q & 1)) ? (T)0 : -dd;
-            const T mag = tmax(up, dn);
-            const bool better = mag > max_df;
-            max_df = tmax(max_df, mag);
-            best = better ? q : best;
-            best_sign = better ? sign_word(dd) : best_sign;
-            best_x = better ? xx : best_x;
+        for (int i = H - 1; i >= 0; --i) {
+            if (i < H - 1) {
+                if constexpr (RV) m.bwd(n0, n1, Z, Y); else m.bwd(n0, n1, w[2 * i], w[2 * i + 1]);
+            }
+#pragma unroll
+            for (int j = 1; j >= 0; --j) {
+                const int q = 2 * i + j;
+                const T xx = x[q];
+                const T dd = j == 0 ? m.df0(n1, xx) : m.df1(n0, n1, xx);
+                const T up = (xx <= m.bl(j)) ? (T)0 : dd;
+                const T dn = (xx >= m.bh(j)) ? (T)0 : -dd;
+                const T mag = tmax(up, dn);
+                const bool better = mag >= max_df && mag > (T)0;   // (a zero never displaces the initial "none")
+                max_df = tmax(max_df, mag);
+                best = better ? q : best;
+                best_sign = better ? sign_word(dd) : best_sign;
+                best_x = better ? xx : best_x;
+            }
+            if constexpr (RV) { if (i > 0) m.rev(Z, Y, x[2 * i], x[2 * i + 1]); }
         }
         if (!stopped && max_df < eps) stopped = true;           // mpc.h:310-311
         if (!stopped) {
@@ -192,7 +199,7 @@ template <typename T, int H> struct UbPlan {
     static constexpr int words = D ? 2 : 1;
     // everything in registers: 6H values
     static constexpr bool reverse = ub::Reverse<T, H>::value;   // no stored forward pass (mpc_ub_model.h)
-    static constexpr bool regs = 6 * H * words <= 200 || !D || reverse;
+    static constexpr bool regs = 6 * H * words <= 200 || !D || (reverse && 4 * H * words <= 200);
     // waves per SIMD.  fp64: ONE at every horizon -- two were measured slower wherever they fit (N = 4 / 5 / 10:
     // 0.237 / 0.260 / 0.963 ms per 262 144 instances against 0.195 / 0.236 / 0.929 with one; N = 20 with v in
     // LDS or with the forward pass regenerated: 6.9-7.7 ms against 5.35): a second wave adds no issue slots
@@ -210,8 +217,15 @@ template <typename T, int H> struct UbPlan {
     static constexpr bool ckpt = ckpt_agpr;
 #endif
     // steps of v in VGPRs (the rest in LDS)
-    static constexpr int kv_default = regs ? H : (H == 20 ? 16 : 8);
+    // (N = 30 / 40 with the forward pass regenerated, kernel time per 262 144 instances at KV = 0 / 8 / 16:
+    // 24.3 / 22.7 / 22.9 ms and 58.9 / 55.5 / 54.0 ms on the box where the checkpointed plan took 23.7 and 55.9)
+    static constexpr int kv_default = regs ? H : (H == 20 ? 16 : (H == 30 ? 8 : 16));
     static constexpr int kv = regs ? H : (TPC_UB_KV >= 0 ? TPC_UB_KV : kv_default);
+#ifdef TPC_UB_SCHED_BARRIER
+    static constexpr bool step_barrier = TPC_UB_SCHED_BARRIER != 0;
+#else
+    static constexpr bool step_barrier = H - kv >= 8;
+#endif
 };
 #ifdef TPC_UB_EXIT_EVERY_STOP
 template <typename T, int H> struct UbExitEveryStop { static constexpr bool value = TPC_UB_EXIT_EVERY_STOP != 0; };
@@ -389,9 +403,10 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
                     pv[nxt][j] = v_get(2 * (i - 1) + j);
                 });
             }
-#ifdef TPC_UB_SCHED_BARRIER   // (A/B: pins the prefetch at the top of its step; measured 5 % slower here)
-            __builtin_amdgcn_sched_barrier(0);
-#endif
+            // pins each step's prefetch of v at the top of its step.  Without it the compiler hoists EVERY step's
+            // LDS read to the top of the iteration -- harmless with four steps in LDS (N = 20: 5 % faster without),
+            // ~700 register moves per iteration with thirty or forty
+            if constexpr (P::step_barrier) __builtin_amdgcn_sched_barrier(0);
             if constexpr (CK) {
                 if constexpr (i < H - 1) {
                     if constexpr (i % 2 == 1) {

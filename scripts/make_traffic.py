@@ -10,16 +10,21 @@ MI355X_MICROARCH.md (HBM) asks:
 Kernels with no calibration of their own get k = 1 and say so."""
 import csv, json, os, sys
 src = sys.argv[1] if len(sys.argv) > 1 else "profiles"
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 CONFIGS = {   # tag -> (kernel in the csv, bench key, k, note)
-    "headline": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_f64_H20_n262144", 1, "strided record reads: k=1 (calibrated)"),
-    "fp32": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_f32_H20_n262144", 1, "strided record reads: k=1"),
+    "headline": ("tpc::ub_pg_kernel<fast>", "ub_pg_kernel_f64_H20_n262144", 1, "strided record reads: k=1 (as calibrated on the LANE kernel's identical access pattern)"),
+    "bitexact": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_f64_H20_n262144", 1, "strided record reads: k=1 (calibrated)"),
+    "fp32": ("tpc::ub_pg_kernel<fast>", "ub_pg_kernel_f32_H20_n262144", 1, "strided record reads: k=1"),
     "config2": ("tpc::wave_pair_queue_kernel", "wave_kernel_f64_H10_n4096", 1, "broadcast loads of 3 scalars per wavefront + the queue order: uncalibrated, k=1"),
-    "h30": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_f64_H30_n262144", 1, "strided record reads: k=1"),
-    "h40": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_f64_H40_n262144", 1, "strided record reads: k=1"),
+    "h30": ("tpc::ub_pg_kernel<fast>", "ub_pg_kernel_f64_H30_n262144", 1, "strided record reads: k=1"),
+    "h40": ("tpc::ub_pg_kernel<fast>", "ub_pg_kernel_f64_H40_n262144", 1, "strided record reads: k=1"),
     "general": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_general_I2_f64_H20_n262144", 1, "strided record reads + SoA model loads: k=1"),
 }
-out = {"_how": __doc__.strip(), "_raw_KiB": {}}
+import hashlib
+LIB = os.path.join("trajectory_controller_amd", "lib", "libtpc_mpc.so")
+out = {"_how": __doc__.strip(), "_raw_KiB": {},
+       # bench.py reports a figure from this file only when it runs THIS binary
+       "_library_sha256": hashlib.sha256(open(LIB, "rb").read()).hexdigest() if os.path.exists(LIB) else None}
 for tag, (kern, key, k, note) in CONFIGS.items():
     f = os.path.join(src, f"{rnd}_{tag}_pmc.csv")
     if not os.path.exists(f):
@@ -31,8 +36,8 @@ for tag, (kern, key, k, note) in CONFIGS.items():
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         out[key] = int((k * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
         out["_raw_KiB"][key] = {"FETCH_SIZE": vals["FETCH_SIZE"], "WRITE_SIZE": vals["WRITE_SIZE"], "read_correction": k, "note": note}
-    # the CD kernel of the headline run documents the k = 2 calibration
-    if tag == "headline":
+    # the CD kernel of the bit-exact run documents the k = 2 calibration
+    if tag == "bitexact":
         cd = {}
         for row in csv.reader(l for l in open(f) if not l.startswith("#")):
             if len(row) == 4 and row[0] == "tpc::lane_cd_kernel":

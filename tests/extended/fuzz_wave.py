@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Randomised differential run on the GPU box: WAVE fp64 (both mask forms, one to four 16-lane rows of
-variables, every horizon it exists for) against the CPU oracle with random weights, bounds, step size, wheelbase, eps
-and iteration caps.  The WAVE family is not bit-exact (different summation order, FMA, a reciprocal
-instead of a division), so this counts what matters for it: instances whose ITERATION COUNT differs
-from dlib's (a decision flipped somewhere) and the largest |du| among the others.
-    python tests/extended/fuzz_wave.py [sets] [n]"""
+"""Randomised differential run on the GPU box: a tolerance-grade fp64 family -- WAVE (both mask forms, one to four
+16-lane rows of variables, every horizon it exists for; the default) or, with ALGO=lane_fma, LANE_FMA (both stop-test
+builds, both bound forms) -- against the CPU oracle with random weights, bounds, step size, wheelbase, eps and
+iteration caps.  These families are not bit-exact (different operation order, FMA, a reciprocal instead of a
+division), so this counts what matters for them: instances whose ITERATION COUNT differs from dlib's (a decision
+flipped somewhere) and the largest |du| among the others.
+    [ALGO=wave|lane_fma] python tests/extended/fuzz_wave.py [sets] [n]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -18,6 +19,7 @@ rng = np.random.default_rng(int(os.environ.get("SEED", "20261004")))
 sets = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 threads = int(os.environ.get("THREADS", "16"))
+algo = os.environ.get("ALGO", "wave")
 flips = total = 0
 worst = worst_cut = 0.0
 for s_i in range(sets):
@@ -35,7 +37,7 @@ for s_i in range(sets):
     v, dy, dphi = compact_inputs(H, m, first=int(rng.integers(0, 1 << 30)))
     of, orr, oit = orc.solve_compact(H, v, dy, dphi, weights=w, T=T, l=l, lo=lo, hi=hi, eps=eps,
                                      max_iter=cap, smo_iters=smo, nthreads=threads)
-    with MpcSolver(horizon=H, algo="wave", weight_y=w[0], weight_phi=w[1], weight_steering_front=w[2],
+    with MpcSolver(horizon=H, algo=algo, weight_y=w[0], weight_phi=w[1], weight_steering_front=w[2],
                    weight_steering_rear=w[3], lower=lo, upper=hi, step_size=T, wheelbase=l, eps=eps,
                    max_iter=cap, smo_iters=smo) as s:
         f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
@@ -55,6 +57,6 @@ for s_i in range(sets):
     print(f"set {s_i:3d} H={H:2d} n={m:5d} bounds kind {kind} eps {eps:.1e} cap {cap:5d} smo {smo:3d}: "
           f"iteration counts differ on {int((~same).sum())}, max|du| converged {err[done].max() if done.any() else 0:.2e}"
           f", cut off by the cap ({int(cut.sum())}) {err[cut].max() if cut.any() else 0:.2e}", flush=True)
-print(f"{sets} parameter sets, {total} instances: iteration counts differ on {flips} ({flips / total:.2e}); "
+print(f"{algo}: {sets} parameter sets, {total} instances: iteration counts differ on {flips} ({flips / total:.2e}); "
       f"max |du| among the converged rest {worst:.2e}, among those cut off by the cap {worst_cut:.2e}")
 sys.exit(1 if worst > 1e-7 or flips > 1e-4 * total else 0)

@@ -338,20 +338,23 @@ def test_full_size_properties(torch_cuda, algo):
     assert 950 < it.mean() < 1100
 
 
-def test_lane_wave_agree_4096(torch_cuda):
-    """BASELINE config 2: batch 4096, N=10, fp64 -- both kernel families, same answers."""
+def test_config2_all_families_vs_oracle(torch_cuda, oracle):
+    """BASELINE config 2 at its exact size -- batch 4096, N=10, fp64 -- every kernel family against the ORACLE:
+    identical iteration counts; LANE bit for bit, WAVE (what AUTO runs here) and LANE_FMA within 1e-9."""
     from trajectory_controller_amd.synth import compact_inputs
     torch = torch_cuda
     v, dy, dphi = compact_inputs(10, 4096)
+    of, orr, oit = oracle.solve_compact(10, v, dy, dphi, nthreads=8)
     tv, ty, tp = _dev(torch, v, dy, dphi)
-    out = {}
-    for algo in ("lane", "wave"):
+    for algo in ("lane", "wave", "lane_fma", "auto"):
         with _solver(10, algo) as s:
             f, r, it = s.solve_batch_compact(tv, ty, tp, want_iters=True)
-            out[algo] = (f.cpu().numpy(), r.cpu().numpy(), it.cpu().numpy())
-    assert np.array_equal(out["lane"][2], out["wave"][2])
-    assert np.abs(out["lane"][0] - out["wave"][0]).max() <= WAVE_ATOL
-    assert np.abs(out["lane"][1] - out["wave"][1]).max() <= WAVE_ATOL
+            f, r, it = f.cpu().numpy(), r.cpu().numpy(), it.cpu().numpy()
+        assert np.array_equal(it, oit), algo
+        if algo == "lane":
+            assert bits_equal(f, of) and bits_equal(r, orr)
+        else:
+            assert max(np.abs(f - of).max(), np.abs(r - orr).max()) <= WAVE_ATOL, algo
 
 
 @pytest.mark.parametrize("algo", ["lane", "wave"])
@@ -371,6 +374,27 @@ def test_fp32_tolerance_sweep(torch_cuda, algo):
         assert np.all(np.isfinite(f)) and np.all(np.isfinite(r))
         assert np.median(err) < 1e-3
         assert hist[1e-2] > 0.5
+
+
+@pytest.mark.parametrize("H,n", [(5, 4096), (10, 4096), (20, 2048)])
+def test_wave_fp32_vs_float_typed_oracle(torch_cuda, oracle32, H, n):
+    """WAVE in fp32 against the float-typed restatement (dlib's operation sequence typed float; dlib itself is
+    fp64-only, so this pins nothing to the reference -- "parity unpinned" for fp32 -- but it is the one statement fp32
+    admits): the WAVE kernels sum in a different order and use FMAs, so the comparison is a tolerance one -- the
+    fraction of equal iteration counts and the error distribution, both bounded."""
+    from trajectory_controller_amd.synth import compact_inputs
+    torch = torch_cuda
+    v, dy, dphi = (a.astype(np.float32) for a in compact_inputs(H, n, first=52000))
+    of, orr, oit = oracle32.solve_compact(H, v, dy, dphi, nthreads=8)
+    tv, ty, tp = _dev(torch, v, dy, dphi)
+    with _solver(H, "wave", dtype="f32") as s:
+        f, r, it = s.solve_batch_compact(tv, ty, tp, want_iters=True)
+        f, r, it = f.cpu().numpy(), r.cpu().numpy(), it.cpu().numpy()
+    same = float(np.mean(it == oit))
+    err = np.maximum(np.abs(f - of), np.abs(r - orr))
+    print(f"WAVE fp32 H={H}: equal iteration counts {same:.4f}; |du| median {np.median(err):.2e} p99 {np.quantile(err, 0.99):.2e} max {err.max():.2e}")
+    floor = {5: 0.9, 10: 0.8, 20: 0.4}[H]
+    assert same >= floor and np.median(err) <= 2e-5 and np.quantile(err, 0.99) <= 5e-3
 
 
 def test_mixed_horizons_65536(torch_cuda, oracle):

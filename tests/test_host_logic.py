@@ -77,6 +77,10 @@ def test_product_never_imports_oracle():
                         continue
                     assert not re.search(r"(from|import)\s+oracle\b", s), (f, s)
                     assert "liboracle" not in s and "mpc_oracle" not in s, (f, s)
+                    # ... nor the CPU model of the LANE_FMA arithmetic (tests/model/): it includes the product's
+                    # header, never the other way round
+                    assert not re.search(r"(from|import)\s+tests\b", s), (f, s)
+                    assert "libub_model" not in s and "ub_model.cpp" not in s and "ub_model_solve" not in s, (f, s)
 
 
 def test_no_gpu_means_loud_failure():

@@ -410,7 +410,7 @@ def test_mixed_horizons_65536(torch_cuda, oracle):
     tv, ty, tp = _dev(torch, v[perm], dy[perm], dphi[perm])
     with _solver(20, "lane") as s:
         f, r, it = s.solve_batch_compact_mixed(hz[perm], tv, ty, tp, want_iters=True)
-    with _solver(20, "auto") as s:   # 16 384 per horizon: AUTO picks WAVE for N = 5, 10, 20 and LANE_FMA for N = 40; the four bins run concurrently
+    with _solver(20, "auto") as s:   # 16 384 per horizon: AUTO picks WAVE for every bin (N = 40: the prefix-sum form); the four bins run concurrently
         fa, ra = s.solve_batch_compact_mixed(hz[perm], tv, ty, tp)
     assert float((fa - f).abs().max()) <= WAVE_ATOL and float((ra - r).abs().max()) <= WAVE_ATOL
     inv = np.argsort(perm)

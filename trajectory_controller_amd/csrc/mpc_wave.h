@@ -836,6 +836,99 @@ TPC_DEV void wave_pair_solve(const Args& g, const Knobs& kn, const int64_t (&ks)
 #define TPC_WAVES_PER_BLOCK 4
 #endif
 constexpr int kWavesPerBlock = TPC_WAVES_PER_BLOCK;
+
+// ---- the compact model's gradient by prefix sums (one horizon step per lane) --------------------------------
+// The dense form above spends 2 (2H)^2 flops per iteration on a Hessian whose structure is a double integrator
+// (A = [1 a; 0 1]): at N = 40 that is 12 800 flops for 1 824 algorithmic ones, 0.75 us per iteration, and a Hessian
+// row in LDS that leaves a CU four wavefronts.  With lane i = horizon step i the two recurrences of mpc.h:275-281
+// are SCANS over the lanes of affine maps with a constant matrix:
+//   forward   [M0; M1][i] = A [M0; M1][i-1] + (a u1, c u0 - c u1)[i]          A^k   = [1 ka; 0 1]
+//   backward  [N0; N1][i] = trans(A) [N0; N1][i+1] + (q0 M0, q1 M1)[i]        trans(A)^k = [1 0; ka 1]
+// so "combine with the segment k lanes away" is one fma and two adds on values moved by DPP (row_shr / row_shl
+// inside a 16-lane row, row_bcast:15 / :31 forward across rows, a lane read backward across rows): 6 steps per
+// scan instead of 2H dependent ones, no Hessian, no LDS, ~40 registers -- the layout of wave2_solve (lane = step,
+// both inputs in the lane) with its gradient replaced.  Every step is exact in the same sense as the sequential
+// recurrence (sums of same-kind terms, no cancelling differences); the association differs, like everything in
+// this family.  df = MM + trans(B) N + R u as in dlib (mpc.h:283), MM from the compact linear term.
+// (From N = 40.  At N = 30 the dense one-variable-per-lane kernel is still ahead: 2.25 against 2.55 ms per 4 096
+// instances, 6.9 against 7.5 per 16 384.  At N = 40: 4.7 / 4.7 / 15.0 ms per 2 048 / 4 096 / 16 384 instances against
+// 7.8 / 13.0 / 42 with the Hessian rows -- 0.47 us per iteration instead of 0.75, and eight wavefronts per CU.)
+#ifndef TPC_WAVE_SCAN_MIN_H
+#define TPC_WAVE_SCAN_MIN_H 40
+#endif
+template <typename T, int I, int H, class Model> constexpr bool wave_scan() {
+    return sizeof(T) == 8 && I == 2 && std::is_same<Model, CompactModel<T>>::value && H >= TPC_WAVE_SCAN_MIN_H &&
+           H > 16 && H <= 48;
+}
+struct ScanConsts {   // per lane, set up once per instance
+    double ka1, ka2, ka4, ka8;   // k a (wave-uniform)
+    double m15, m31;             // (distance to lane 15 / 31 of the previous row / half) a
+    double w1, d1, w0, d0;       // backward across rows: row 1 <- lane 32, row 0 <- lane 16 (weights 1/0, distance a)
+    double q0a, q1a;             // Q on active lanes, 0 beyond the horizon
+};
+template <int H> TPC_DEV ScanConsts scan_consts(double a, double q0, double q1, int lane) {
+    ScanConsts k;
+    k.ka1 = a; k.ka2 = 2.0 * a; k.ka4 = 4.0 * a; k.ka8 = 8.0 * a;
+    k.m15 = (double)((lane & 15) + 1) * a;
+    k.m31 = (double)((lane & 31) + 1) * a;
+    const bool r1 = lane >= 16 && lane < 32, r0 = lane < 16;
+    k.w1 = r1 ? 1.0 : 0.0; k.d1 = r1 ? (double)(32 - lane) * a : 0.0;
+    k.w0 = r0 ? 1.0 : 0.0; k.d0 = r0 ? (double)(16 - lane) * a : 0.0;
+    k.q0a = lane < H ? q0 : 0.0; k.q1a = lane < H ? q1 : 0.0;
+    return k;
+}
+// df[0], df[1] of this lane's horizon step from its controls u[0], u[1] (inactive lanes: u = 0)
+template <int H> TPC_DEV void scan_gradient(const ScanConsts& k, double a, double c, const double* r, const double* g,
+                                            const double* u, double* df) {
+    // forward: inclusive prefix of the affine maps
+    double pz = a * u[1];
+    double py = tfma(c, u[0], -(c * u[1]));
+    auto fwd = [&](auto ctrl, double ka) {
+        constexpr int C = decltype(ctrl)::value;
+        const double ys = dpp_shr0<C>(py), zs = dpp_shr0<C>(pz);
+        pz = pz + tfma(ka, ys, zs);
+        py = py + ys;
+    };
+    fwd(std::integral_constant<int, 0x111>{}, k.ka1);   // row_shr:1
+    fwd(std::integral_constant<int, 0x112>{}, k.ka2);
+    fwd(std::integral_constant<int, 0x114>{}, k.ka4);
+    fwd(std::integral_constant<int, 0x118>{}, k.ka8);
+    {   // rows 1, 3 <- lane 15 of the row before
+        const double ys = dpp_mov<0x142, 0xa>(0.0, py), zs = dpp_mov<0x142, 0xa>(0.0, pz);
+        pz = pz + tfma(k.m15, ys, zs);
+        py = py + ys;
+    }
+    if constexpr (H > 32) {   // rows 2, 3 <- lane 31
+        const double ys = dpp_mov<0x143, 0xc>(0.0, py), zs = dpp_mov<0x143, 0xc>(0.0, pz);
+        pz = pz + tfma(k.m31, ys, zs);
+        py = py + ys;
+    }
+    // backward: inclusive suffix of the affine maps over (q0 M0, q1 M1), zero beyond the horizon
+    double n0 = k.q0a * pz, n1 = k.q1a * py;
+    auto bwd = [&](auto ctrl, double ka) {
+        constexpr int C = decltype(ctrl)::value;
+        const double s0 = dpp_shr0<C>(n0), s1 = dpp_shr0<C>(n1);
+        n1 = n1 + tfma(ka, s0, s1);
+        n0 = n0 + s0;
+    };
+    bwd(std::integral_constant<int, 0x101>{}, k.ka1);   // row_shl:1
+    bwd(std::integral_constant<int, 0x102>{}, k.ka2);
+    bwd(std::integral_constant<int, 0x104>{}, k.ka4);
+    bwd(std::integral_constant<int, 0x108>{}, k.ka8);
+    if constexpr (H > 32) {   // row 1 <- the total of row 2 (its first lane)
+        const double t0 = read_lane(n0, 32), t1 = read_lane(n1, 32);
+        n1 = tfma(k.w1, t1, tfma(k.d1, t0, n1));
+        n0 = tfma(k.w1, t0, n0);
+    }
+    {   // row 0 <- the total of everything behind it (first lane of row 1, just completed)
+        const double t0 = read_lane(n0, 16), t1 = read_lane(n1, 16);
+        n1 = tfma(k.w0, t1, tfma(k.d0, t0, n1));
+        n0 = tfma(k.w0, t0, n0);
+    }
+    df[0] = tfma(c, n1, tfma(r[0], u[0], g[0]));                    // mpc.h:283: MM + trans(B) N + R u
+    df[1] = tfma(a, n0, tfma(-c, n1, tfma(r[1], u[1], g[1])));
+}
+
 // ---- two decision variables per lane ------------------------------------------------------------------------
 // Horizons whose I*H exceeds the wavefront (N = 40 with two inputs: 80 variables).  Lane i owns BOTH inputs of
 // horizon step i: two Hessian rows (4H doubles: 320 registers at H = 40, one wavefront per SIMD), two controls,
@@ -850,7 +943,8 @@ TPC_DEV void wave2_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s
     constexpr int I = 2, NL = H;
     // fp64 at H = 40: two rows are 320 registers, VALU operands must be architectural VGPRs (256) -- the second
     // row lives in LDS as [step][lane][2] (one ds_read_b128 per source step and iteration)
-    constexpr bool R1L = wave2_row_in_lds<T, H>();
+    constexpr bool SCAN = wave_scan<T, I, H, Model>();   // the gradient by prefix sums: no Hessian rows at all
+    constexpr bool R1L = wave2_row_in_lds<T, H>() && !SCAN;
     static_assert(NL <= kWave && NL > 16, "one horizon step per lane, more than one row of lanes");
     const int lane = threadIdx.x & (kWave - 1);
     const bool active = lane < NL;
@@ -861,8 +955,8 @@ TPC_DEV void wave2_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s
     const bool nonfinite = m.nonfinite();
     const bool badmodel = m.invalid();
 
-    T row[R1L ? 1 : 2][2 * H];
-    T my_qd[2], my_g[2] = {(T)0, (T)0}, my_r[2];
+    T row[(R1L || SCAN) ? 1 : 2][SCAN ? 1 : 2 * H];
+    T my_qd[2] = {(T)0, (T)0}, my_g[2] = {(T)0, (T)0}, my_r[2];
     // the linear term first: its intermediates (identical in all lanes) are parked in LDS, and where the second
     // Hessian row goes to LDS they borrow its place before it is written (40 KB per wavefront is a quarter of the
     // CU's LDS exactly: a vector of its own beside it would cost the CU its fourth wavefront)
@@ -873,7 +967,13 @@ TPC_DEV void wave2_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s
         else linear_term_fn<T, I, H>(m, [&](int q, T val) { lt[q] = val; }, [&](int q) { return lt[q]; }, take_g);
         if (!active) my_g[0] = my_g[1] = (T)0;
     }
-    if constexpr (R1L) {
+    T scan_lambda = (T)0;
+    if constexpr (SCAN) {
+        // no Hessian: Q_diag and lambda straight from dlib's constructor recurrence (mpc.h:116-123), every lane
+        // keeping the pair of its own step
+        scan_lambda = ctor_lambda_qdiag<T, I, H>(m, [&](int i, int j, T val) { if (i == qi) my_qd[j] = val; });
+        if (!active) my_qd[0] = my_qd[1] = (T)0;
+    } else if constexpr (R1L) {
         T tmp[2 * H];
         hessian_row<T, I, H>(m, active, qi, 1, tmp);
         my_qd[1] = active ? pick_own<T, 2 * H>(tmp, 2 * qi + 1) : (T)0;
@@ -894,7 +994,10 @@ TPC_DEV void wave2_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s
     // from the Hessian's trace -- is handed to the scalar registers (a register move, the value unchanged): the two
     // Hessian rows and the state leave the general model's kernel no vector register to spare, and what did not fit
     // was reloaded from scratch inside the iteration loops.
-    const T lambda = wave_uniform(wave_sum_all<NL>((my_qd[0] + my_r[0]) + (my_qd[1] + my_r[1])));
+    T lambda_v;
+    if constexpr (SCAN) lambda_v = scan_lambda;
+    else lambda_v = wave_sum_all<NL>((my_qd[0] + my_r[0]) + (my_qd[1] + my_r[1]));
+    const T lambda = wave_uniform(lambda_v);
     const T lo[2] = {wave_uniform(m.lo(0)), wave_uniform(m.lo(1))}, hi[2] = {wave_uniform(m.hi(0)), wave_uniform(m.hi(1))};
     const T eps = (T)kn.eps;
     const T my_rqd[2] = {(T)1 / my_qd[0], (T)1 / my_qd[1]};
@@ -920,8 +1023,21 @@ TPC_DEV void wave2_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s
     T huge_r = kHuge;
     asm volatile("" : "+v"(huge_r));
 
+    [[maybe_unused]] ScanConsts sk;
+    [[maybe_unused]] double scan_a = 0, scan_c = 0;
+    if constexpr (SCAN) {
+        scan_a = wave_uniform((double)m.a); scan_c = wave_uniform((double)m.c);
+        sk = scan_consts<H>(scan_a, (double)m.q0, (double)m.q1, lane);
+    }
     // df[e] = sum over source steps l and source inputs e2 of row[e][2 l + e2] * u[e2] of lane l, + R u + g
     auto gradient_of = [&](const T* uu, T* df) {
+        if constexpr (SCAN) {
+            const double r2[2] = {(double)my_r[0], (double)my_r[1]}, g2[2] = {(double)my_g[0], (double)my_g[1]};
+            const double u2[2] = {(double)uu[0], (double)uu[1]};
+            double d2[2];
+            scan_gradient<H>(sk, scan_a, scan_c, r2, g2, u2, d2);
+            df[0] = (T)d2[0]; df[1] = (T)d2[1];
+        } else {
         T x[2][4];
 #pragma unroll
         for (int e2 = 0; e2 < 2; ++e2) {
@@ -968,6 +1084,7 @@ TPC_DEV void wave2_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s
             });
             df[0] = a0 + a1;
             df[1] = b0 + b1;
+        }
         }
     };
 
@@ -1096,17 +1213,19 @@ TPC_DEV void wave2_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s
 // one instance by the calling wavefront, whichever layout its size needs
 template <int I, int H> constexpr bool wave_two_per_lane() { return I * H > kWave; }
 // LDS a wavefront needs beside s_w (T elements): the second Hessian row of the two-per-lane fp64 kernels
-template <typename T, int I, int H> constexpr int wave_row_lds() {
-    if constexpr (I * H > kWave) return wave2_row_in_lds<T, H>() ? 2 * H * kWave : 1;
+template <typename T, int I, int H, class Model = void> constexpr int wave_row_lds() {
+    if constexpr (wave_scan<T, I, H, Model>()) return 1;   // (no Hessian at all)
+    else if constexpr (I * H > kWave) return wave2_row_in_lds<T, H>() ? 2 * H * kWave : 1;
     else return 1;
 }
 // LDS for the linear term's intermediates (T elements): none of its own where the row's place is borrowed
-template <typename T, int I, int H> constexpr int wave_lt_lds() { return wave_row_lds<T, I, H>() > 1 ? 1 : 2 * H; }
+template <typename T, int I, int H, class Model = void> constexpr int wave_lt_lds() { return wave_row_lds<T, I, H, Model>() > 1 ? 1 : 2 * H; }
 // (one where a wavefront parks a Hessian row in LDS: 40 KB each, and a workgroup's static LDS ends at 64 KB)
-template <typename T, int I, int H> constexpr int waves_per_block() { return wave_row_lds<T, I, H>() > 1 ? 1 : kWavesPerBlock; }
+template <typename T, int I, int H, class Model = void> constexpr int waves_per_block() { return wave_row_lds<T, I, H, Model>() > 1 ? 1 : kWavesPerBlock; }
 template <typename T, int I, int H, class Model, class Args, class Hook = NoHook>
 TPC_DEV void wave_solve_any(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s_row1, Hook before_loops = Hook{}) {
-    if constexpr (I * H <= kWave) wave_solve<T, I, H, Model, Args, Hook>(g, kn, k, s_w, before_loops);
+    if constexpr (wave_scan<T, I, H, Model>()) wave2_solve<T, H, Model, Args, Hook>(g, kn, k, s_w, s_row1, before_loops);
+    else if constexpr (I * H <= kWave) wave_solve<T, I, H, Model, Args, Hook>(g, kn, k, s_w, before_loops);
     else wave2_solve<T, H, Model, Args, Hook>(g, kn, k, s_w, s_row1, before_loops);
 }
 
@@ -1122,14 +1241,15 @@ TPC_DEV void wave_solve_any(const Args& g, const Knobs& kn, int64_t k, T* s_w, T
 template <typename T, int I, int H, class Model = void> constexpr int wave_min_waves() {
     constexpr bool big_general = sizeof(T) == 8 && I * H > 48 && !std::is_same<Model, CompactModel<T>>::value &&
                                  !std::is_same<Model, void>::value;
+    if (wave_scan<T, I, H, Model>()) return TPC_WAVE_MIN_WAVES;   // ~40 registers: no reason for less
     return (wave_two_per_lane<I, H>() || big_general) ? 1 : TPC_WAVE_MIN_WAVES;
 }
 template <typename T, int I, int H, class Model, class Args>
-__global__ __launch_bounds__((waves_per_block<T, I, H>() * kWave)) __attribute__((amdgpu_waves_per_eu(wave_min_waves<T, I, H, Model>())))
+__global__ __launch_bounds__((waves_per_block<T, I, H, Model>() * kWave)) __attribute__((amdgpu_waves_per_eu(wave_min_waves<T, I, H, Model>())))
 void wave_kernel(Args g, Knobs kn) {
-    constexpr int WPB = waves_per_block<T, I, H>();
-    __shared__ __attribute__((aligned(16))) T s_w[WPB][wave_lt_lds<T, I, H>()];
-    __shared__ __attribute__((aligned(16))) T s_row1[WPB][wave_row_lds<T, I, H>()];
+    constexpr int WPB = waves_per_block<T, I, H, Model>();
+    __shared__ __attribute__((aligned(16))) T s_w[WPB][wave_lt_lds<T, I, H, Model>()];
+    __shared__ __attribute__((aligned(16))) T s_row1[WPB][wave_row_lds<T, I, H, Model>()];
     const int w = threadIdx.x / kWave;
     const int64_t k = (int64_t)blockIdx.x * WPB + w;
     if (k < g.n) wave_solve_any<T, I, H, Model, Args>(g, kn, k, s_w[w], s_row1[w]);
@@ -1150,7 +1270,9 @@ void wave_kernel(Args g, Knobs kn) {
 #define TPC_QUEUE_WG_PER_CU 2
 #endif
 constexpr int kQueueWorkgroupsPerCu = TPC_QUEUE_WG_PER_CU;   // (one where a lane holds two variables: 380 registers per lane)
-template <int I, int H> constexpr int queue_waves_per_cu() { return (wave_two_per_lane<I, H>() ? 1 : kQueueWorkgroupsPerCu) * kWavesPerBlock; }
+template <int I, int H, typename T = void, class Model = void> constexpr int queue_waves_per_cu() {
+    return ((wave_two_per_lane<I, H>() && !wave_scan<T, I, H, Model>()) ? 1 : kQueueWorkgroupsPerCu) * kWavesPerBlock;
+}
 #ifndef TPC_QUEUE_MIN_H
 #define TPC_QUEUE_MIN_H 10
 #endif
@@ -1283,11 +1405,11 @@ void wave_pair_queue_kernel(Args g, Knobs kn, const uint32_t* __restrict__ order
 // asks for its next position when the set-up of the current instance is done, just before its iteration loops
 // (see wave_solve: any earlier and the in-order wait counter makes the set-up's own loads wait for the ticket).
 template <typename T, int I, int H, class Model, class Args>
-__global__ __launch_bounds__((waves_per_block<T, I, H>() * kWave)) __attribute__((amdgpu_waves_per_eu(wave_min_waves<T, I, H, Model>())))
+__global__ __launch_bounds__((waves_per_block<T, I, H, Model>() * kWave)) __attribute__((amdgpu_waves_per_eu(wave_min_waves<T, I, H, Model>())))
 void wave_queue_kernel(Args g, Knobs kn, const uint32_t* __restrict__ order, uint32_t* tickets) {
-    constexpr int WPB = waves_per_block<T, I, H>();
-    __shared__ __attribute__((aligned(16))) T s_w[WPB][wave_lt_lds<T, I, H>()];
-    __shared__ __attribute__((aligned(16))) T s_row1[WPB][wave_row_lds<T, I, H>()];
+    constexpr int WPB = waves_per_block<T, I, H, Model>();
+    __shared__ __attribute__((aligned(16))) T s_w[WPB][wave_lt_lds<T, I, H, Model>()];
+    __shared__ __attribute__((aligned(16))) T s_row1[WPB][wave_row_lds<T, I, H, Model>()];
     const int w = threadIdx.x / kWave;
     const uint32_t n = (uint32_t)g.n;
     const uint32_t waves = gridDim.x * WPB, wid = blockIdx.x * WPB + w;

@@ -38,8 +38,8 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
         if (a.n > 0x7fffffffll) return hipErrorInvalidValue;
         if (ws.ev) (void)hipEventRecord(ws.ev[0], s);
         // more instances than the persistent grid holds: wavefronts over a longest-first queue (mpc_wave.h)
-        constexpr int wpb = waves_per_block<T, I, kH>();
-        const int64_t slots = (int64_t)cu_count() * queue_waves_per_cu<I, kH>();
+        constexpr int wpb = waves_per_block<T, I, kH, Model>();
+        const int64_t slots = (int64_t)cu_count() * queue_waves_per_cu<I, kH, T, Model>();
         // (not for the general form with two variables per lane: its fp64 queue kernel -- the model's registers on
         // top of two Hessian rows -- spills into scratch inside the loops; the plain launch below does not)
         constexpr bool queue_ok = kH >= kQueueMinHorizon &&

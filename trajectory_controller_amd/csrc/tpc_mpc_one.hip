@@ -70,7 +70,7 @@ TPC_DEV void sys_store(uint64_t* p, uint64_t x) {
 template <int H>
 __global__ __launch_bounds__(64) void one_shot_kernel(const uint64_t* req, uint64_t* mail, uint64_t start_seq, uint64_t idle_ticks) {
     __shared__ __attribute__((aligned(16))) double s_w[2 * H];
-    __shared__ __attribute__((aligned(16))) double s_row1[wave_row_lds<double, 2, H>()];   // (N = 40: a Hessian row, mpc_wave.h)
+    __shared__ __attribute__((aligned(16))) double s_row1[wave_row_lds<double, 2, H, CompactModel<double>>()];   // (N = 40: a Hessian row, mpc_wave.h)
     const int lane = threadIdx.x;
     uint64_t seen = start_seq;
     uint64_t idle_since = wall_clock64();   // 100 MHz

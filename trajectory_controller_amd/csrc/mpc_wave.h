@@ -857,35 +857,34 @@ constexpr int kWavesPerBlock = TPC_WAVES_PER_BLOCK;
 #define TPC_WAVE_SCAN_MIN_H 40
 #endif
 template <typename T, int I, int H, class Model> constexpr bool wave_scan() {
-    return sizeof(T) == 8 && I == 2 && std::is_same<Model, CompactModel<T>>::value && H >= TPC_WAVE_SCAN_MIN_H &&
-           H > 16 && H <= 48;
+    return I == 2 && std::is_same<Model, CompactModel<T>>::value && H >= TPC_WAVE_SCAN_MIN_H && H > 16 && H <= 48;
 }
-struct ScanConsts {   // per lane, set up once per instance
-    double ka1, ka2, ka4, ka8;   // k a (wave-uniform)
-    double m15, m31;             // (distance to lane 15 / 31 of the previous row / half) a
-    double w1, d1, w0, d0;       // backward across rows: row 1 <- lane 32, row 0 <- lane 16 (weights 1/0, distance a)
-    double q0a, q1a;             // Q on active lanes, 0 beyond the horizon
+template <typename T> struct ScanConsts {   // per lane, set up once per instance
+    T ka1, ka2, ka4, ka8;   // k a (wave-uniform)
+    T m15, m31;             // (distance to lane 15 / 31 of the previous row / half) a
+    T w1, d1, w0, d0;       // backward across rows: row 1 <- lane 32, row 0 <- lane 16 (weights 1/0, distance a)
+    T q0a, q1a;             // Q on active lanes, 0 beyond the horizon
 };
-template <int H> TPC_DEV ScanConsts scan_consts(double a, double q0, double q1, int lane) {
-    ScanConsts k;
-    k.ka1 = a; k.ka2 = 2.0 * a; k.ka4 = 4.0 * a; k.ka8 = 8.0 * a;
-    k.m15 = (double)((lane & 15) + 1) * a;
-    k.m31 = (double)((lane & 31) + 1) * a;
+template <int H, typename T> TPC_DEV ScanConsts<T> scan_consts(T a, T q0, T q1, int lane) {
+    ScanConsts<T> k;
+    k.ka1 = a; k.ka2 = (T)2 * a; k.ka4 = (T)4 * a; k.ka8 = (T)8 * a;
+    k.m15 = (T)((lane & 15) + 1) * a;
+    k.m31 = (T)((lane & 31) + 1) * a;
     const bool r1 = lane >= 16 && lane < 32, r0 = lane < 16;
-    k.w1 = r1 ? 1.0 : 0.0; k.d1 = r1 ? (double)(32 - lane) * a : 0.0;
-    k.w0 = r0 ? 1.0 : 0.0; k.d0 = r0 ? (double)(16 - lane) * a : 0.0;
-    k.q0a = lane < H ? q0 : 0.0; k.q1a = lane < H ? q1 : 0.0;
+    k.w1 = r1 ? (T)1 : (T)0; k.d1 = r1 ? (T)(32 - lane) * a : (T)0;
+    k.w0 = r0 ? (T)1 : (T)0; k.d0 = r0 ? (T)(16 - lane) * a : (T)0;
+    k.q0a = lane < H ? q0 : (T)0; k.q1a = lane < H ? q1 : (T)0;
     return k;
 }
 // df[0], df[1] of this lane's horizon step from its controls u[0], u[1] (inactive lanes: u = 0)
-template <int H> TPC_DEV void scan_gradient(const ScanConsts& k, double a, double c, const double* r, const double* g,
-                                            const double* u, double* df) {
+template <int H, typename T> TPC_DEV void scan_gradient(const ScanConsts<T>& k, T a, T c, const T* r, const T* g,
+                                                        const T* u, T* df) {
     // forward: inclusive prefix of the affine maps
-    double pz = a * u[1];
-    double py = tfma(c, u[0], -(c * u[1]));
-    auto fwd = [&](auto ctrl, double ka) {
+    T pz = a * u[1];
+    T py = tfma(c, u[0], -(c * u[1]));
+    auto fwd = [&](auto ctrl, T ka) {
         constexpr int C = decltype(ctrl)::value;
-        const double ys = dpp_shr0<C>(py), zs = dpp_shr0<C>(pz);
+        const T ys = dpp_shr0<C>(py), zs = dpp_shr0<C>(pz);
         pz = pz + tfma(ka, ys, zs);
         py = py + ys;
     };
@@ -894,20 +893,20 @@ template <int H> TPC_DEV void scan_gradient(const ScanConsts& k, double a, doubl
     fwd(std::integral_constant<int, 0x114>{}, k.ka4);
     fwd(std::integral_constant<int, 0x118>{}, k.ka8);
     {   // rows 1, 3 <- lane 15 of the row before
-        const double ys = dpp_mov<0x142, 0xa>(0.0, py), zs = dpp_mov<0x142, 0xa>(0.0, pz);
+        const T ys = dpp_mov<0x142, 0xa>((T)0, py), zs = dpp_mov<0x142, 0xa>((T)0, pz);
         pz = pz + tfma(k.m15, ys, zs);
         py = py + ys;
     }
     if constexpr (H > 32) {   // rows 2, 3 <- lane 31
-        const double ys = dpp_mov<0x143, 0xc>(0.0, py), zs = dpp_mov<0x143, 0xc>(0.0, pz);
+        const T ys = dpp_mov<0x143, 0xc>((T)0, py), zs = dpp_mov<0x143, 0xc>((T)0, pz);
         pz = pz + tfma(k.m31, ys, zs);
         py = py + ys;
     }
     // backward: inclusive suffix of the affine maps over (q0 M0, q1 M1), zero beyond the horizon
-    double n0 = k.q0a * pz, n1 = k.q1a * py;
-    auto bwd = [&](auto ctrl, double ka) {
+    T n0 = k.q0a * pz, n1 = k.q1a * py;
+    auto bwd = [&](auto ctrl, T ka) {
         constexpr int C = decltype(ctrl)::value;
-        const double s0 = dpp_shr0<C>(n0), s1 = dpp_shr0<C>(n1);
+        const T s0 = dpp_shr0<C>(n0), s1 = dpp_shr0<C>(n1);
         n1 = n1 + tfma(ka, s0, s1);
         n0 = n0 + s0;
     };
@@ -916,12 +915,12 @@ template <int H> TPC_DEV void scan_gradient(const ScanConsts& k, double a, doubl
     bwd(std::integral_constant<int, 0x104>{}, k.ka4);
     bwd(std::integral_constant<int, 0x108>{}, k.ka8);
     if constexpr (H > 32) {   // row 1 <- the total of row 2 (its first lane)
-        const double t0 = read_lane(n0, 32), t1 = read_lane(n1, 32);
+        const T t0 = read_lane(n0, 32), t1 = read_lane(n1, 32);
         n1 = tfma(k.w1, t1, tfma(k.d1, t0, n1));
         n0 = tfma(k.w1, t0, n0);
     }
     {   // row 0 <- the total of everything behind it (first lane of row 1, just completed)
-        const double t0 = read_lane(n0, 16), t1 = read_lane(n1, 16);
+        const T t0 = read_lane(n0, 16), t1 = read_lane(n1, 16);
         n1 = tfma(k.w0, t1, tfma(k.d0, t0, n1));
         n0 = tfma(k.w0, t0, n0);
     }
@@ -1023,20 +1022,16 @@ TPC_DEV void wave2_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s
     T huge_r = kHuge;
     asm volatile("" : "+v"(huge_r));
 
-    [[maybe_unused]] ScanConsts sk;
-    [[maybe_unused]] double scan_a = 0, scan_c = 0;
+    [[maybe_unused]] ScanConsts<T> sk;
+    [[maybe_unused]] T scan_a = (T)0, scan_c = (T)0;
     if constexpr (SCAN) {
-        scan_a = wave_uniform((double)m.a); scan_c = wave_uniform((double)m.c);
-        sk = scan_consts<H>(scan_a, (double)m.q0, (double)m.q1, lane);
+        scan_a = wave_uniform(m.a); scan_c = wave_uniform(m.c);
+        sk = scan_consts<H, T>(scan_a, m.q0, m.q1, lane);
     }
     // df[e] = sum over source steps l and source inputs e2 of row[e][2 l + e2] * u[e2] of lane l, + R u + g
     auto gradient_of = [&](const T* uu, T* df) {
         if constexpr (SCAN) {
-            const double r2[2] = {(double)my_r[0], (double)my_r[1]}, g2[2] = {(double)my_g[0], (double)my_g[1]};
-            const double u2[2] = {(double)uu[0], (double)uu[1]};
-            double d2[2];
-            scan_gradient<H>(sk, scan_a, scan_c, r2, g2, u2, d2);
-            df[0] = (T)d2[0]; df[1] = (T)d2[1];
+            scan_gradient<H, T>(sk, scan_a, scan_c, my_r, my_g, uu, df);
         } else {
         T x[2][4];
 #pragma unroll

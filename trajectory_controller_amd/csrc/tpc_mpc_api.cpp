@@ -86,8 +86,7 @@ int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n, int d
     // ... and the compact model's WAVE kernel at N = 40 builds its gradient from prefix sums (mpc_wave.h,
     // scan_gradient): 0.92 us per instance through the queue, 15 ms at 16 384 -- ahead of either LANE family up to
     // the largest batch the queue takes.
-    // (fp32 keeps both Hessian rows in registers and no scan form: 11 264 against its LANE_FMA.)
-    const int64_t two_per_lane_cross = fma_ok ? (dtype == TPC_MPC_F64 ? queue_cross : lanes * 11 / 64) : lanes * 19 / 64;
+    const int64_t two_per_lane_cross = fma_ok ? queue_cross : lanes * 19 / 64;
     const int64_t crossover = I * H > kWave ? two_per_lane_cross
                               : ((H >= 20 || paired) ? queue_cross : lanes * 7 / 16);
     return (n >= crossover || !wave_ok) ? lane : TPC_MPC_ALGO_WAVE;

@@ -57,7 +57,8 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
 
 /* Kernel family.
  *   WAVE : one 64-lane wavefront per instance; lane j owns decision variable j and its row of the
- *          dense (I*H)x(I*H) Hessian (two variables per lane where I*H > 64: I = 2, H <= 64), the
+ *          dense (I*H)x(I*H) Hessian (two variables per lane where I*H > 64: I = 2, H <= 64; the
+ *          compact form at N = 40 instead builds its gradient from prefix sums over the lanes), the
  *          controls are exchanged by DPP / lane swaps, reductions by wavefront DPP/ballot.  (fp64
  *          batches of more than one instance per SIMD with I*H <= 32 run two instances per wavefront,
  *          one per 32-lane half, and four -- one per 16-lane row -- with I*H <= 16: same arithmetic per
@@ -81,9 +82,9 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
  *          horizons; requests it cannot take (general form, degenerate bounds, other horizons) run LANE.
  *   AUTO : the fastest family that meets the 1e-6 parity target: WAVE below a measured crossover (on a
  *          256-CU part: 32 768 instances, the largest batch the WAVE work queue takes, in fp64 with
- *          I*H <= 32 and from N = 20 up; about 29 000 in fp32 below N = 20; 19 456 at N = 40 with two
- *          inputs), from there up LANE_FMA for the compact form and LANE for the general form.  A host
- *          that needs dlib's bits asks for LANE. */
+ *          I*H <= 32, from N = 20 up, and for the compact form at N = 40; about 29 000 in fp32 below
+ *          N = 20; 19 456 for the general form at N = 40), from there up LANE_FMA for the compact form
+ *          and LANE for the general form.  A host that needs dlib's bits asks for LANE. */
 typedef enum tpc_mpc_algo {
     TPC_MPC_ALGO_AUTO = 0, TPC_MPC_ALGO_WAVE = 1, TPC_MPC_ALGO_LANE = 2, TPC_MPC_ALGO_LANE_FMA = 3
 } tpc_mpc_algo;

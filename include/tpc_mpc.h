@@ -80,11 +80,12 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
  *          only where dlib's largest gradient component comes within rounding of eps).  Compact form
  *          (solve_batch_compact, _mixed, _sharded, follow_batch) with hi > lo finite, specialised
  *          horizons; requests it cannot take (general form, degenerate bounds, other horizons) run LANE.
- *   AUTO : the fastest family that meets the 1e-6 parity target: WAVE below a measured crossover (on a
- *          256-CU part: 32 768 instances, the largest batch the WAVE work queue takes, in fp64 with
- *          I*H <= 32, from N = 20 up, and for the compact form at N = 40; about 29 000 in fp32 below
- *          N = 20; 19 456 for the general form at N = 40), from there up LANE_FMA for the compact form
- *          and LANE for the general form.  A host that needs dlib's bits asks for LANE. */
+ *   AUTO : the fastest family that meets the 1e-6 parity target: WAVE below a measured crossover, from
+ *          there up LANE_FMA for the compact form and LANE for the general form.  On a 256-CU part the
+ *          crossover lies between 21 504 and 32 768 instances (the largest batch the WAVE work queue takes)
+ *          depending on horizon, dtype and form -- compact form, fp64: 32 768 at N = 4, 5, 30, 40, 28 672 at
+ *          N = 10, 21 504 at N = 20; general form at N = 40: 19 456 -- and scales with the CU count.  A host
+ *          that needs dlib's bits asks for LANE. */
 typedef enum tpc_mpc_algo {
     TPC_MPC_ALGO_AUTO = 0, TPC_MPC_ALGO_WAVE = 1, TPC_MPC_ALGO_LANE = 2, TPC_MPC_ALGO_LANE_FMA = 3
 } tpc_mpc_algo;

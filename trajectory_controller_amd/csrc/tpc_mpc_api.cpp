@@ -87,8 +87,22 @@ int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n, int d
     // scan_gradient): 0.92 us per instance through the queue, 15 ms at 16 384 -- ahead of either LANE family up to
     // the largest batch the queue takes.
     const int64_t two_per_lane_cross = fma_ok ? queue_cross : lanes * 19 / 64;
-    const int64_t crossover = I * H > kWave ? two_per_lane_cross
-                              : ((H >= 20 || paired) ? queue_cross : lanes * 7 / 16);
+    int64_t crossover = I * H > kWave ? two_per_lane_cross
+                        : ((H >= 20 || paired) ? queue_cross : lanes * 7 / 16);
+    if (fma_ok) {
+        // compact form: the other side is LANE_FMA, twice as fast as LANE, so WAVE gives way earlier where the two
+        // meet below the queue's limit (profiles/r03_crossover.txt, kernel times in ms at 16 384 / 24 576 / 32 768
+        // instances, WAVE against LANE_FMA):
+        //   fp64  N=10: .36/.53  .49/.54  .63/.54     N=20: 2.8/3.6  4.1/3.6  5.3/3.7     N=4, 5, 30, 40: WAVE up to 32 768
+        //   fp32  N=4: .10/.14  .14/.15  .17/.15      N=5, 10: .13/.16 .19/.17, .46/.59 .66/.59      N=20, 30, 40: WAVE up to 32 768
+        const bool d = dtype == TPC_MPC_F64;
+        int64_t at = kWaveQueueMaxInstances + 1;
+        if (d && H == 10) at = 28672;
+        if (d && H == 20) at = 21504;
+        if (!d && H == 4) at = 28672;
+        if (!d && (H == 5 || H == 10)) at = 21504;
+        crossover = at * h->cu_count / 256 < at ? at * h->cu_count / 256 : at;
+    }
     return (n >= crossover || !wave_ok) ? lane : TPC_MPC_ALGO_WAVE;
 }
 

@@ -126,6 +126,25 @@ void solve_one(T v, T ty, T tphi, const T* q, const T* r, double step, double wh
     *flags |= f;
 }
 
+// the kernels' own choice of stop-test build: the screen of mpc_ub_model.h on one instance
+template <typename T, int H, bool EQB>
+bool screen_one(T v, T ty, T tphi, const T* q, const T* r, double step, double wheelbase, const T* lo, const T* hi, double eps_d) {
+    Unit<T, EQB> m;
+    m.set_uniform((T)1, q, r, lo, hi);
+    m.set_instance((T)step, (T)wheelbase, v, ty, tphi);
+    const T lambda = ctor_lambda_qdiag<T, H>(m.a, m.c, q[0], q[1], r[0], r[1], [](int, int, T) {});
+    return fast_stop_ok(m, ty, tphi, q[0], q[1], r[0], r[1], (T)eps_d, lambda);
+}
+template <typename T, bool EQB>
+bool screen_dispatch(int H, T v, T ty, T tphi, const T* q, const T* r, double step, double wb, const T* lo, const T* hi, double eps) {
+    switch (H) {
+#define X(h) case h: return screen_one<T, h, EQB>(v, ty, tphi, q, r, step, wb, lo, hi, eps);
+        X(4) X(5) X(10) X(20) X(30) X(40)
+#undef X
+    }
+    return false;
+}
+
 template <typename T, bool EQB>
 int dispatch(int H, T v, T ty, T tphi, const T* q, const T* r, double step, double wb, const T* lo, const T* hi,
              double eps, unsigned long mi, unsigned long smo, bool fast, T* fo, T* re, int* it, unsigned* fl) {
@@ -143,6 +162,12 @@ int batch(int H, long n, int nthreads, const T* v, const T* dy, const T* dphi, c
           T* front, T* rear, int* iters, unsigned* flags_out) {
     const bool eqb = lo[0] == lo[1] && hi[0] == hi[1];
     const T q[2] = {w4[0], w4[1]}, r[2] = {w4[2], w4[3]};
+    if (fast < 0) {   // auto: what the kernels do -- one instance outside the screen sends the batch to the exact build
+        fast = 1;
+        for (long k = 0; k < n && fast; ++k)
+            fast = (eqb ? screen_dispatch<T, true>(H, v[k], dy[k], dphi[k], q, r, step, wb, lo, hi, eps)
+                        : screen_dispatch<T, false>(H, v[k], dy[k], dphi[k], q, r, step, wb, lo, hi, eps)) ? 1 : 0;
+    }
     std::atomic<long> next(0);
     std::atomic<unsigned> flags(0);
     std::atomic<int> rc(0);
@@ -173,7 +198,7 @@ int batch(int H, long n, int nthreads, const T* v, const T* dy, const T* dphi, c
 
 extern "C" {
 // Same argument meaning as mpc_oracle_solve_compact (oracle/mpc_oracle.h); fast_stop selects the
-// stop-test form of the kernels' screened build (1) or dlib's masked form (0).
+// stop-test form of the kernels' screened build (1), dlib's masked form (0), or -1: decided by the kernels' own screen.
 int ub_model_solve_compact_f64(int H, long n, int nthreads, const double* v, const double* dy, const double* dphi,
                                const double* weights4, double T, double l, const double* lo2, const double* hi2,
                                double eps, unsigned long max_iter, unsigned long smo_iters, int fast_stop,

@@ -19,35 +19,6 @@
 
 namespace tpc {
 
-// Screen of the fast stop test (per instance; one failing instance sends the batch through the
-// exact build, like LANE).  Needed: no intermediate can overflow or be NaN, the start point u = 0
-// lies inside the box, and a projected step that vanishes in rounding implies |df| < eps:
-// lambda * s * 2^-50 < eps (mpc_ub_model.h; fp32: finiteness only, its test keeps dlib's mask).
-// fp64 magnitudes with |a|,|c|,|target| <= 1e50, q <= 1e30, r <= 1e100, s,|bound| <= 1e10, H <= 40:
-// |Y| <= 4e61, |Z| <= 2e113, |N0| <= 7e144, |N1| <= 3e196, |df| <= 3e246.
-template <typename T, bool EQB>
-TPC_DEV bool ub_fast_stop_ok(const ub::Unit<T, EQB>& m, T ty, T tphi, T q0, T q1, T r0, T r1, T eps, T lambda) {
-    constexpr bool D = sizeof(T) == 8;
-    constexpr T kAl = (T)(D ? 1e50 : 1e3), kQ = (T)(D ? 1e30 : 1e3), kR = (T)(D ? 1e100 : 1e10);
-    constexpr T kS = (T)(D ? 1e10 : 1e2), kEpsLo = (T)(D ? 1e-60 : 1e-10), kEpsHi = (T)(D ? 1e30 : 1e10);
-    const T smax = tmax(m.s0, m.s1);
-    bool ok = tabs(m.a) <= kAl && tabs(m.c) <= kAl && tabs(ty) <= kAl && tabs(tphi) <= kAl;
-    ok = ok && tabs(q0) <= kQ && tabs(q1) <= kQ && tabs(r0) <= kR && tabs(r1) <= kR;
-    ok = ok && eps >= kEpsLo && eps <= kEpsHi;
-    if constexpr (ub::Unit<T, EQB>::kUnitBox) {
-        ok = ok && smax <= kS && tabs(m.lo0) <= kS && tabs(m.lo1) <= kS && tabs(m.hi0) <= kS && tabs(m.hi1) <= kS;
-        ok = ok && m.xz0 >= (T)0 && m.xz0 <= (T)1 && m.xz1 >= (T)0 && m.xz1 <= (T)1;
-        ok = ok && lambda * smax * (T)0x1p-50 < eps;
-    } else {
-        // dlib's coordinates (fp32): the start point 0 strictly inside the box, and a gap of one ulp off a
-        // bound, times 2^100, beyond every admissible eps: |bound| >= 1e-10
-        constexpr T kBmin = (T)1e-10;
-        ok = ok && m.bl0 <= -kBmin && m.bl1 <= -kBmin && m.bh0 >= kBmin && m.bh1 >= kBmin;
-        ok = ok && m.bl0 >= -kS && m.bl1 >= -kS && m.bh0 <= kS && m.bh1 <= kS && lambda <= (T)1e30;
-    }
-    return ok;
-}
-
 template <typename T, bool EQB> TPC_DEV void ub_set_uniform(ub::Unit<T, EQB>& m, T gscale, const CompactArgs& g) {
     const T q[2] = {(T)g.q[0], (T)g.q[1]}, r[2] = {(T)g.r[0], (T)g.r[1]};
     const T lo[2] = {(T)g.lo[0], (T)g.lo[1]}, hi[2] = {(T)g.hi[0], (T)g.hi[1]};
@@ -84,7 +55,7 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void ub_cd_kernel(Compact
     });
     const T eps = (T)kn.eps;
     {
-        const unsigned long long failing = __ballot(!ub_fast_stop_ok(m, ty, tphi, q0, q1, r0, r1, eps, lambda));
+        const unsigned long long failing = __ballot(!ub::fast_stop_ok(m, ty, tphi, q0, q1, r0, r1, eps, lambda));
         if (failing != 0ull && lane == __ffsll((long long)failing) - 1) atomicOr(&stats[2], 1ull);
     }
     const uint32_t cd_iters = kn.smo_iters < kn.max_iter ? kn.smo_iters : kn.max_iter;
@@ -428,7 +399,14 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
             } else {
                 if constexpr (i < H - 1) m.bwd(n0, n1, w_getz(i), w_gety(i));
             }
-            [[maybe_unused]] const T xo0 = x[2 * i], xo1 = x[2 * i + 1];
+            // RV: (Z, Y) of step i-1 from those of step i and x[i] -- BEFORE x[i] is updated below, so that the old
+            // x[i] is dead when the new one is defined and the two can share a register (no copy at the back edge)
+            if constexpr (RV && i > 0) {
+                m.rev(Z, Y, x[2 * i], x[2 * i + 1]);
+#ifndef TPC_UB_NO_RV_PIN
+                asm volatile("" : "+v"(Z), "+v"(Y));   // (keeps the regeneration here: LLVM would sink it past the update)
+#endif
+            }
             T vn[2], st[2];
             static_for<2>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
@@ -472,7 +450,6 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
                     v_put(2 * i + j, vn[j]);
                 });
             }
-            if constexpr (RV && i > 0) m.rev(Z, Y, xo0, xo1);
         });
         T max_df = acc[0];
 #pragma unroll

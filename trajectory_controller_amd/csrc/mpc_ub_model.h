@@ -187,6 +187,36 @@ template <typename T, bool EQB, bool UBOX = UnitBox<T>::value> struct Unit {
     TPC_HD T gap_hi(int j, T x, T huge) const { return fma_(-huge, x, bh(j) * huge); }
 };
 
+// Screen of the fast stop test (per instance; one failing instance sends the batch through the
+// exact build, like LANE).  Needed: no intermediate can overflow or be NaN, the start point u = 0
+// lies inside the box, and a projected step that vanishes in rounding implies |df| < eps:
+// lambda * s * 2^-50 < eps (mpc_ub_model.h; fp32: finiteness only, its test keeps dlib's mask).
+// fp64 magnitudes with |a|,|c|,|target| <= 1e50, q <= 1e30, r <= 1e100, s,|bound| <= 1e10, H <= 40:
+// |Y| <= 4e61, |Z| <= 2e113, |N0| <= 7e144, |N1| <= 3e196, |df| <= 3e246.
+template <typename T, bool EQB>
+TPC_HD bool fast_stop_ok(const Unit<T, EQB>& m, T ty, T tphi, T q0, T q1, T r0, T r1, T eps, T lambda) {
+    constexpr bool D = sizeof(T) == 8;
+    constexpr T kAl = (T)(D ? 1e50 : 1e3), kQ = (T)(D ? 1e30 : 1e3), kR = (T)(D ? 1e100 : 1e10);
+    constexpr T kS = (T)(D ? 1e10 : 1e2), kEpsLo = (T)(D ? 1e-60 : 1e-10), kEpsHi = (T)(D ? 1e30 : 1e10);
+    const T smax = max_(m.s0, m.s1);
+    bool ok = abs_(m.a) <= kAl && abs_(m.c) <= kAl && abs_(ty) <= kAl && abs_(tphi) <= kAl;
+    ok = ok && abs_(q0) <= kQ && abs_(q1) <= kQ && abs_(r0) <= kR && abs_(r1) <= kR;
+    ok = ok && eps >= kEpsLo && eps <= kEpsHi;
+    if (Unit<T, EQB>::kUnitBox) {
+        ok = ok && smax <= kS && abs_(m.lo0) <= kS && abs_(m.lo1) <= kS && abs_(m.hi0) <= kS && abs_(m.hi1) <= kS;
+        ok = ok && m.xz0 >= (T)0 && m.xz0 <= (T)1 && m.xz1 >= (T)0 && m.xz1 <= (T)1;
+        ok = ok && lambda * smax * (T)0x1p-50 < eps;
+    } else {
+        // dlib's coordinates (fp32): the start point 0 strictly inside the box, and a gap of one ulp off a
+        // bound, times 2^100, beyond every admissible eps: |bound| >= 1e-10
+        constexpr T kBmin = (T)1e-10;
+        ok = ok && m.bl0 <= -kBmin && m.bl1 <= -kBmin && m.bh0 >= kBmin && m.bh1 >= kBmin;
+        ok = ok && m.bl0 >= -kS && m.bl1 >= -kS && m.bh0 <= kS && m.bh1 <= kS && lambda <= (T)1e30;
+    }
+    return ok;
+}
+
+
 // Which (dtype, horizon) regenerate the forward pass in the backward sweep instead of keeping it: part of
 // the family's arithmetic, so it lives here where kernels and model both see it.
 // fp64 at N = 30 and 40: x alone takes 120 / 160 of the 256 registers a VALU instruction can name, and a kept

@@ -23,8 +23,8 @@ the average over the timed region of the library's events around each kernel (la
 handle), "kernel_ms_serial" the same measured right after the timed region with one batch in flight.
 A one-GPU run with the default one batch in flight also times the same K steps with two in flight and
 reports that figure under "pipelined" (value, ms_per_step, alu_frac), next to `value`.
-The default one-GPU run also times BASELINE config 2 (4 096 instances, N = 10, the WAVE family) and reports it
-under "config2".
+The default one-GPU run also times BASELINE config 2 (4 096 instances, N = 10, the WAVE family) and config 5
+(65 536 instances of mixed horizons through one call) and reports them under "config2" and "config5".
 
 `value` is measured in fp64, the only dtype that meets the 1e-6 parity target (SURVEY.md section 0
 fact 3), through AUTO, i.e. the LANE_FMA family (unit-box coordinates, fused multiply-adds: dlib's
@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-batches-in-flight leg")
     ap.add_argument("--no-config2", action="store_true", help="skip the BASELINE config 2 leg (4 096 x N=10, WAVE)")
     ap.add_argument("--no-bit-exact", action="store_true", help="skip the bit-exact LANE family leg")
+    ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE config 5 leg (65 536 mixed horizons)")
     return ap.parse_args()
 
 
@@ -465,6 +466,27 @@ def main():
                 d2 = time.perf_counter() - t1
             out["config2"] = {"workload": "batch 4096, N=10, fp64, WAVE family", "value": 4096 * 50 / d2,
                               "unit": "solves/s", "ms_per_step": d2 / 50 * 1e3}
+        if world == 1 and not a.no_config5 and a.dtype == "f64" and n == 262144 and H == 20:
+            # BASELINE config 5 beside the headline: 65 536 instances split evenly over N in {5, 10, 20, 40}, interleaved,
+            # ONE tpc_mpc_solve_batch_compact_mixed call per step (binned on the device, the bins run concurrently)
+            Hs, per = (5, 10, 20, 40), 16384
+            parts = [compact_inputs(Hh, per) for Hh in Hs]
+            mv, my, mp = (np.concatenate([pp[c] for pp in parts]) for c in range(3))
+            hz = np.repeat(np.array(Hs, dtype=np.int32), per)
+            perm = np.random.default_rng(3).permutation(len(hz))
+            c5 = {"workload": "batch 65536 mixed over N in {5,10,20,40}, one call", "unit": "ms per batch"}
+            for dt_name, dt_t in (("f64", torch.float64), ("f32", torch.float32)):
+                xv, xy, xp = (torch.from_numpy(z[perm]).to(dev, dtype=dt_t) for z in (mv, my, mp))
+                with MpcSolver(horizon=20, device=local_rank, dtype=dt_name) as sm:
+                    sm.solve_batch_compact_mixed(hz[perm], xv, xy, xp)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(5):
+                        sm.solve_batch_compact_mixed(hz[perm], xv, xy, xp)
+                    torch.cuda.synchronize()
+                    c5[dt_name] = (time.perf_counter() - t1) / 5 * 1e3
+            c5["solves_per_s_f64"] = len(hz) / (c5["f64"] * 1e-3)
+            out["config5"] = c5
         print(json.dumps(out), flush=True)
     for sv in solvers:
         sv.close()

@@ -14,7 +14,7 @@ tdt = torch.float64 if dtype == "f64" else torch.float32
 v = torch.full((n,), 3.9, dtype=tdt, device="cuda")
 dy = torch.full((n,), 0.45, dtype=tdt, device="cuda")
 dphi = torch.full((n,), -0.55, dtype=tdt, device="cuda")
-s = MpcSolver(horizon=H, dtype=dtype, algo="lane")
+s = MpcSolver(horizon=H, dtype=dtype, algo=(sys.argv[4] if len(sys.argv) > 4 else "lane"))
 s.set_profiling(True)
 for rep in range(3):
     f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)

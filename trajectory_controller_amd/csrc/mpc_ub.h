@@ -156,9 +156,10 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void ub_cd_kernel(Compact
 //
 // State of one instance: x (2H), the forward pass (Z, Y per step: 2H), dlib's momentum v (2H).
 // Where it lives (UbPlan): x always in VGPRs; the forward pass in VGPRs, or -- where x and it do
-// not both fit the 256 a VALU instruction can name -- checkpointed on the even steps in AGPRs
-// (odd steps recomputed in the backward pass, FusedCkpt in mpc_lane.h); v in VGPRs for the first KV
-// steps, in LDS beyond ([var][lane] columns, fetched one step ahead).
+// not both fit the 256 a VALU instruction can name (fp64, N >= 30) -- not kept at all: the backward sweep
+// regenerates each step's (Z, Y) from the next one's (ub::Reverse; a checkpointed plan, even steps in AGPRs or
+// VGPRs, remains as an A/B switch); v in VGPRs for the first KV steps, in LDS beyond ([var][lane] columns,
+// fetched one step ahead).
 #ifndef TPC_UB_OCC
 #define TPC_UB_OCC 0
 #endif

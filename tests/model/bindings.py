@@ -42,6 +42,10 @@ class UbModel:
         self.fn.argtypes = [C.c_int, C.c_long, C.c_int, rp, rp, rp, rp, C.c_double, C.c_double, rp, rp,
                             C.c_double, C.c_ulong, C.c_ulong, C.c_int, rp, rp, C.POINTER(C.c_int),
                             C.POINTER(C.c_uint)]
+        self.gen = getattr(self.lib, f"ub_model_solve_general_{dtype}")
+        self.gen.restype = C.c_int
+        self.gen.argtypes = [C.c_int, C.c_int, C.c_long, C.c_int, rp, rp, rp, rp, rp, rp, rp, rp, rp,
+                             C.c_double, C.c_ulong, C.c_ulong, C.c_int, rp, C.POINTER(C.c_int), C.POINTER(C.c_uint)]
 
     def solve_compact(self, H, v, dy, dphi, weights=DEFAULT_WEIGHTS, T=0.1, l=0.21,
                       lo=(-ALPHA_MAX, -ALPHA_MAX), hi=(ALPHA_MAX, ALPHA_MAX), eps=0.01, max_iter=10000,
@@ -60,3 +64,21 @@ class UbModel:
         if rc != 0:
             raise ValueError(f"ub model: unsupported H={H}")
         return front, rear, iters, flags.value
+
+    def solve_general(self, I, H, A, B, Cc, Q, R, lo, hi, x0, targets, eps=0.01, max_iter=10000, smo_iters=50,
+                      nthreads=1, fast_stop=None):
+        """General form, cold start (AoS arrays like oracle.solve_general): returns (u0[n,I], iters[n], flags)."""
+        a = lambda z, shape: np.ascontiguousarray(z, dtype=self.np).reshape(shape)
+        p = lambda z: z.ctypes.data_as(self._rp)
+        A = a(A, (-1, 4)); n = A.shape[0]
+        B, Cc, Q, R = a(B, (n, 2 * I)), a(Cc, (n, 2)), a(Q, (n, 2)), a(R, (n, I))
+        lo, hi, x0, targets = a(lo, (n, I)), a(hi, (n, I)), a(x0, (n, 2)), a(targets, (n, H, 2))
+        u0 = np.empty((n, I), dtype=self.np)
+        iters = np.empty(n, dtype=np.int32)
+        flags = C.c_uint(0)
+        rc = self.gen(I, H, n, nthreads, p(A), p(B), p(Cc), p(Q), p(R), p(lo), p(hi), p(x0), p(targets), eps, max_iter,
+                      smo_iters, -1 if fast_stop is None else (1 if fast_stop else 0), p(u0),
+                      iters.ctypes.data_as(C.POINTER(C.c_int)), C.byref(flags))
+        if rc != 0:
+            raise ValueError(f"ub model: unsupported I={I} H={H}")
+        return u0, iters, flags.value

@@ -227,3 +227,129 @@ def test_ub_fp32_full_batch_tolerance(torch_cuda, oracle32):
     print(f"fp32 LANE_FMA vs float-typed restatement: equal iteration counts {same:.4f}, "
           f"median |du| {np.median(err):.2e}, p99 {np.quantile(err, 0.99):.2e}, max {err.max():.2e}")
     assert same >= 0.5 and np.median(err) <= 1e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# general model (csrc/mpc_ubg.h): per-instance A, B, C, Q, R, bounds, x0 and per-step targets, N <= 20, cold start
+
+GNAMES = ["A", "B", "C", "Q", "R", "lo", "hi", "x0", "targets"]
+
+
+def _soa(a):
+    a = np.asarray(a)
+    return np.ascontiguousarray(a.reshape(a.shape[0], -1).T)
+
+
+def _run_general(torch, s, g, I, dtype=None):
+    dev = [torch.from_numpy(_soa(g[k])).to("cuda:0", dtype=dtype) for k in GNAMES]
+    s.set_profiling(True)
+    u0, it = s.solve_batch_general(*dev, inputs=I, want_iters=True)
+    torch.cuda.synchronize()
+    assert s.last_kernel_times()[2] == LANE_FMA          # the family under test ran, not LANE
+    return u0.cpu().numpy().T, it.cpu().numpy()
+
+
+@pytest.mark.parametrize("I", [1, 2])
+@pytest.mark.parametrize("H,n", [(4, 4000), (5, 4000), (10, 3000), (20, 2000)])
+def test_ubg_bits_vs_model_f64(torch_cuda, model, I, H, n):
+    from trajectory_controller_amd.synth import general_inputs
+    g = general_inputs(H, n, I=I, first=710000)
+    mu0, mit, _ = model.solve_general(I, H, *[g[k] for k in GNAMES], nthreads=8)
+    with _solver(H) as s:
+        u0, it = _run_general(torch_cuda, s, g, I)
+    assert np.array_equal(it, mit)
+    assert bits_equal(u0, mu0)
+
+
+@pytest.mark.parametrize("I", [1, 2])
+@pytest.mark.parametrize("H,n", [(4, 4000), (10, 3000), (20, 2000)])
+def test_ubg_bits_vs_model_f32(torch_cuda, model32, I, H, n):
+    from trajectory_controller_amd.synth import general_inputs
+    torch = torch_cuda
+    g = {k: a.astype(np.float32) for k, a in general_inputs(H, n, I=I, first=710000).items()}
+    mu0, mit, _ = model32.solve_general(I, H, *[g[k] for k in GNAMES], nthreads=8)
+    with _solver(H, dtype="f32") as s:
+        u0, it = _run_general(torch, s, g, I)
+    assert np.array_equal(it, mit)
+    assert bits_equal32(u0, mu0)
+
+
+@pytest.mark.parametrize("I", [1, 2])
+@pytest.mark.parametrize("H", [4, 5, 10, 20])
+def test_ubg_golden(torch_cuda, I, H):
+    """Real-dlib golden vectors of the general form: <= 1e-9."""
+    g = load_golden(f"general_I{I}_H{H}.npz")
+    with _solver(H) as s:
+        u0, it = _run_general(torch_cuda, s, g, I)
+        assert s.last_flags == 0
+    assert np.abs(u0 - g["u0"]).max() <= UB_ATOL
+
+
+@pytest.mark.parametrize("I,H,n", [(1, 4, 4096), (2, 10, 4096), (1, 20, 2000), (2, 20, 3000)])
+def test_ubg_vs_oracle_iters(torch_cuda, oracle, I, H, n):
+    """Fresh seeded inputs against the pinned oracle: identical iteration counts, |du| <= 1e-9, and a control dlib
+    leaves on a bound is on it bit for bit."""
+    from trajectory_controller_amd.synth import general_inputs
+    g = general_inputs(H, n, I=I, first=90000)
+    ou0, _, oit = oracle.solve_general(I, H, *[g[k] for k in GNAMES], nthreads=8)
+    with _solver(H) as s:
+        u0, it = _run_general(torch_cuda, s, g, I)
+    assert np.array_equal(it, oit)
+    assert np.abs(u0 - ou0).max() <= UB_ATOL
+    assert np.array_equal((ou0 == g["lo"]) | (ou0 == g["hi"]), (u0 == g["lo"]) | (u0 == g["hi"]))
+
+
+@pytest.mark.parametrize("I,H", [(1, 10), (2, 10), (2, 20)])
+def test_ubg_hostile_instances_take_the_exact_build(torch_cuda, model, oracle, I, H):
+    """Pinned and one-sided boxes, a dead input column (Q_diag == 0), Q == 0, large targets: the screen sends the batch
+    through the exact stop test; bits equal the model's, iteration counts equal dlib's."""
+    from trajectory_controller_amd.synth import general_inputs
+    from test_ub_model import hostile_general
+    g = hostile_general(general_inputs(H, 440, I=I, first=8100), I)
+    ou0, _, oit = oracle.solve_general(I, H, *[g[k] for k in GNAMES], nthreads=8)
+    mu0, mit, _ = model.solve_general(I, H, *[g[k] for k in GNAMES], nthreads=8)
+    with _solver(H) as s:
+        u0, it = _run_general(torch_cuda, s, g, I)
+        assert s.last_flags == 0
+    assert np.array_equal(it, mit) and bits_equal(u0, mu0)
+    assert np.array_equal(it, oit) and np.abs(u0 - ou0).max() <= UB_ATOL
+
+
+def test_ubg_flags_phase_boundaries_and_state_requests(torch_cuda, model, oracle):
+    """Models outside dlib's requires clause and non-finite inputs are flagged and left unsolved like LANE does; the
+    coordinate-descent / projected-gradient boundary (smo_iters, max_iter) follows dlib; a caller that hands the controller
+    state in runs the bit-exact LANE family instead (this family starts cold)."""
+    from trajectory_controller_amd.synth import general_inputs
+    torch = torch_cuda
+    I, H, n = 2, 10, 1200
+    g = general_inputs(H, n, I=I, first=123)
+    for smo, cap in ((0, 10000), (3, 10000), (50, 50), (50, 57), (7, 5)):
+        ou0, _, oit = oracle.solve_general(I, H, *[g[k] for k in GNAMES], smo_iters=smo, max_iter=cap, nthreads=8)
+        mu0, mit, _ = model.solve_general(I, H, *[g[k] for k in GNAMES], smo_iters=smo, max_iter=cap, nthreads=8)
+        with _solver(H, smo_iters=smo, max_iter=cap) as s:
+            u0, it = _run_general(torch, s, g, I)
+        assert np.array_equal(it, mit) and bits_equal(u0, mu0), (smo, cap)
+        assert np.array_equal(it, oit), (smo, cap)
+        assert np.abs(u0 - ou0).max() <= (UB_ATOL if cap >= 10000 else 1e-6), (smo, cap)
+    bad = {k: a.copy() for k, a in g.items()}
+    bad["R"][5, 0] = 0.0          # min(R) > 0 violated
+    bad["hi"][9, 1] = -1.0        # upper < lower
+    bad["x0"][17, 0] = np.nan
+    with _solver(H) as s:
+        u0, it = _run_general(torch, s, bad, I)
+        assert s.last_flags & 0x4 and s.last_flags & 0x1
+    assert np.all(u0[[5, 9]] == 0) and np.all(it[[5, 9]] == 0)
+    keep = np.ones(n, bool); keep[[5, 9, 17]] = False
+    mu0, mit, _ = model.solve_general(I, H, *[g[k] for k in GNAMES], nthreads=8, fast_stop=False)
+    assert bits_equal(u0[keep], mu0[keep]) and np.array_equal(it[keep], mit[keep])
+    # controller state requested: LANE runs, bit-exact against the oracle
+    cin = np.zeros((n, H, I))
+    ou0, cout, oit = oracle.solve_general(I, H, *[g[k] for k in GNAMES], controls_in=cin, nthreads=8)
+    dev = [torch.from_numpy(_soa(g[k])).to("cuda:0") for k in GNAMES]
+    ctl = torch.from_numpy(_soa(cin)).to("cuda:0")
+    with _solver(H) as s:
+        s.set_profiling(True)
+        u0, it = s.solve_batch_general(*dev, controls=ctl, inputs=I, want_iters=True)
+        torch.cuda.synchronize()
+        assert s.last_kernel_times()[2] == 2            # LANE
+    assert bits_equal(u0.cpu().numpy().T, ou0) and np.array_equal(it.cpu().numpy(), oit)

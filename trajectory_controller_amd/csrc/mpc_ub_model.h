@@ -43,8 +43,12 @@
 
 #if defined(__HIPCC__)
 #define TPC_HD __host__ __device__ __forceinline__
+#define TPC_UNROLL _Pragma("unroll")
+#define TPC_NOUNROLL _Pragma("unroll 1")
 #else
 #define TPC_HD inline
+#define TPC_UNROLL
+#define TPC_NOUNROLL
 #endif
 
 namespace tpc {

@@ -21,6 +21,10 @@ namespace tpc {
     const char* lane_build_h##h();
 TPC_DECL_H(4) TPC_DECL_H(5) TPC_DECL_H(10) TPC_DECL_H(20) TPC_DECL_H(30) TPC_DECL_H(40)
 #undef TPC_DECL_H
+// LANE_FMA for the general model (mpc_ubg_inst.hip): N <= 20
+#define TPC_DECL_H(h) hipError_t ub_general_h##h(int, int, const GeneralArgs&, const Knobs&, const Workspace&, hipStream_t);
+TPC_DECL_H(4) TPC_DECL_H(5) TPC_DECL_H(10) TPC_DECL_H(20)
+#undef TPC_DECL_H
 
 thread_local char g_create_error[kTpcErrLen] = "";
 }  // namespace tpc
@@ -61,8 +65,10 @@ const int32_t* take_hint(tpc_mpc_context* h, int64_t n) {
 // wins at 32 768, the largest batch its work queue takes (5.4 against 6.9 ms), and loses without the queue beyond.
 // The WAVE kernel maps one decision variable to one lane, so it exists for I*H <= 64 only.
 // Returns the kernel family to run, or -1 when WAVE was demanded for a shape it cannot take.
-// `fma_ok`: the request is one the LANE_FMA family takes (compact form, usable bounds: fma_usable()).
-int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n, int dtype, bool fma_ok = false) {
+// `fma_ok`: the request is one the LANE_FMA family takes (compact form with usable bounds: fma_usable(); general form:
+// fma_general_usable()); `compact`: the compact form (its WAVE / LANE_FMA crossovers were measured separately).
+int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n, int dtype, bool fma_ok = false,
+              bool compact = true) {
     if (!horizon_specialised(H)) return algo == TPC_MPC_ALGO_WAVE ? -1 : kAlgoGeneric;
     const bool wave_ok = I * H <= kWave || (I == 2 && H <= kWave);   // (two variables per lane past 64)
     const int lane = fma_ok ? TPC_MPC_ALGO_LANE_FMA : TPC_MPC_ALGO_LANE;   // the throughput family of AUTO
@@ -86,10 +92,10 @@ int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n, int d
     // ... and the compact model's WAVE kernel at N = 40 builds its gradient from prefix sums (mpc_wave.h,
     // scan_gradient): 0.92 us per instance through the queue, 15 ms at 16 384 -- ahead of either LANE family up to
     // the largest batch the queue takes.
-    const int64_t two_per_lane_cross = fma_ok ? queue_cross : lanes * 19 / 64;
+    const int64_t two_per_lane_cross = (fma_ok && compact) ? queue_cross : lanes * 19 / 64;
     int64_t crossover = I * H > kWave ? two_per_lane_cross
                         : ((H >= 20 || paired) ? queue_cross : lanes * 7 / 16);
-    if (fma_ok) {
+    if (fma_ok && compact) {
         // compact form: the other side is LANE_FMA, twice as fast as LANE, so WAVE gives way earlier where the two
         // meet below the queue's limit (profiles/r03_crossover.txt, kernel times in ms at 16 384 / 24 576 / 32 768
         // instances, WAVE against LANE_FMA):
@@ -112,6 +118,11 @@ bool fma_usable(const tpc_mpc_params* p) {
     for (int j = 0; j < 2; ++j)
         if (!(std::isfinite(p->lower[j]) && std::isfinite(p->upper[j]) && p->upper[j] > p->lower[j])) return false;
     return true;
+}
+
+// General form: the LANE_FMA kernels exist for N <= 20 and start cold (the controller state in or out is LANE's).
+bool fma_general_usable(int H, const void* controls, const void* v) {
+    return (H == 4 || H == 5 || H == 10 || H == 20) && !controls && !v;
 }
 
 int64_t lane_rec_len(int H, int dtype) {
@@ -156,6 +167,14 @@ hipError_t dispatch_compact(int algo, int H, int dtype, const CompactArgs& a, co
 hipError_t dispatch_general(int algo, int I, int H, int dtype, const GeneralArgs& a, const Knobs& k,
                             const Workspace& ws, hipStream_t s) {
     if (algo == kAlgoGeneric) return generic_launch(ws, s, [&] { return generic_general(dtype, I, H, a, k, ws.state, s); });
+    if (algo == TPC_MPC_ALGO_LANE_FMA) {
+        switch (H) {
+#define X(h) case h: return ub_general_h##h(dtype, I, a, k, ws, s);
+            X(4) X(5) X(10) X(20)
+#undef X
+        }
+        return hipErrorInvalidValue;
+    }
     switch (H) {
 #define X(h) case h: return algo == TPC_MPC_ALGO_LANE ? lane_general_h##h(dtype, I, a, k, ws, s) \
                                                        : wave_general_h##h(dtype, I, a, k, ws, s);
@@ -509,7 +528,7 @@ int tpc_mpc_solve_batch_general(tpc_mpc_handle h, const tpc_mpc_params* p,
         const int64_t es = (int64_t)esize(p->dtype);
         const int I = io->inputs, H = p->horizon;
         const int64_t n = io->n;
-        const int algo = pick_algo(h, p->algo, I, H, n, p->dtype);
+        const int algo = pick_algo(h, p->algo, I, H, n, p->dtype, fma_general_usable(H, io->controls_inout, io->v_inout), false);
         if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel exists for the specialised horizons with inputs*horizon <= 64 only; use LANE or AUTO");
         StreamOrderScope order(h, s);
         rc = order.begin();
@@ -782,7 +801,7 @@ int tpc_mpc_follow_batch_horizon(tpc_mpc_handle h, const tpc_mpc_params* p, cons
         hipStream_t s = (hipStream_t)stream;
         const int64_t n = t->n;
         const int H = p->horizon, I = 2;
-        const int algo = pick_algo(h, p->algo, I, H, n, p->dtype);
+        const int algo = pick_algo(h, p->algo, I, H, n, p->dtype, fma_general_usable(H, nullptr, nullptr), false);
         if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel exists for the specialised horizons with inputs*horizon <= 64 only; use LANE or AUTO");
         StreamOrderScope order(h, s);
         rc = order.begin();

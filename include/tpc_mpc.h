@@ -78,10 +78,14 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
  *          the same decisions as dlib on quantities that differ by rounding: max |du| vs dlib ~2e-13 at
  *          N = 20, ~1e-12 at N = 40, iteration counts identical on the BASELINE workloads (they can differ
  *          only where dlib's largest gradient component comes within rounding of eps).  Compact form
- *          (solve_batch_compact, _mixed, _sharded, follow_batch) with hi > lo finite, specialised
- *          horizons; requests it cannot take (general form, degenerate bounds, other horizons) run LANE.
+ *          (solve_batch_compact, _mixed, _sharded) with hi > lo finite, specialised horizons.  General
+ *          form (solve_batch_general without controls_inout / v_inout, follow_batch) at N = 4, 5, 10, 20:
+ *          the same arithmetic in dlib's own coordinates (per-instance bounds may be pinned or infinite)
+ *          with the linear term kept, scaled, as dlib keeps it: 1.2 - 1.5x LANE.  Requests it cannot
+ *          take (controller state in or out, general form at N = 30 / 40, degenerate compact bounds, other
+ *          horizons) run LANE.
  *   AUTO : the fastest family that meets the 1e-6 parity target: WAVE below a measured crossover, from
- *          there up LANE_FMA for the compact form and LANE for the general form.  On a 256-CU part the
+ *          there up LANE_FMA where it exists (above) and LANE elsewhere.  On a 256-CU part the
  *          crossover lies between 21 504 and 32 768 instances (the largest batch the WAVE work queue takes)
  *          depending on horizon, dtype and form -- compact form, fp64: 32 768 at N = 4, 5, 30, 40, 28 672 at
  *          N = 10, 21 504 at N = 20; general form at N = 40: 19 456 -- and scales with the CU count.  A host

@@ -283,6 +283,10 @@ struct CompactModel {
         const T step = (T)g.step;
         a = step * vk;
         c = step * vk / (T)g.wheelbase;
+        load_targets_and_uniforms(g);
+    }
+    // everything but a and c (a resident wave keeps those while v, step and wheelbase repeat: WaveKeep, mpc_wave.h)
+    TPC_DEV void load_targets_and_uniforms(const OneArgs& g) {
         ty = (T)g.dy;
         tphi = (T)g.dphi;
         q0 = (T)g.q[0]; q1 = (T)g.q[1]; r0 = (T)g.r[0]; r1 = (T)g.r[1];

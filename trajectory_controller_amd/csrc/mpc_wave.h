@@ -350,13 +350,25 @@ template <typename T, int LEN> TPC_DEV T pick_own(const T* a, int idx) {
 
 struct NoHook { TPC_DEV void operator()() const {} };
 
+// What wave_solve's set-up derives from the MODEL alone (v and the parameters; not the targets): this lane's Hessian
+// row, Q_diag, lambda and the constants made from them.  A resident wavefront (tpc_mpc_one.hip) keeps one across
+// requests and sets `hit` when a request repeats the previous one's model, which skips ~300 of the ~450
+// instructions before the first iteration; batch kernels use a throw-away one (hit = false folds away).
+template <typename T, int H> struct WaveKeep {
+    bool hit = false;   // wave-uniform
+    T row[2 * H];
+    T a, c;             // compact model: step * v, step * v / wheelbase
+    T my_qd, lambda, my_rqd, inv_lambda, beta;
+};
+struct NoKeep {};
+
 // One instance solved by the calling wavefront (all 64 lanes must call it together).
 // s_w: 2*H values of LDS private to the wavefront, 16-byte aligned.
 // before_loops(): called once, after the set-up has consumed everything it loads and before the iteration loops --
 // the place for a memory operation whose result is wanted after the solve (the work queue's next ticket: the
 // wait counter is in-order, so issued any earlier it is waited for together with the model's own loads).
-template <typename T, int I, int H, class Model, class Args, class Hook = NoHook>
-TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, Hook before_loops = Hook{}) {
+template <typename T, int I, int H, class Model, class Args, class Hook = NoHook, class Keep = NoKeep>
+TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, Hook before_loops = Hook{}, Keep* keep = nullptr) {
     constexpr int N = I * H;
     static_assert(N <= kWave, "WAVE kernel: one variable per lane");
     const int lane = threadIdx.x & (kWave - 1);
@@ -364,16 +376,31 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, Hook 
     const int qi = active ? lane / I : 0, qj = active ? lane % I : 0;
     const int slot = 2 * qi + qj;
 
+    constexpr bool KEEP = !std::is_same<Keep, NoKeep>::value;
+    WaveKeep<T, H> scratch_keep;
+    WaveKeep<T, H>* kp = &scratch_keep;
+    if constexpr (KEEP) kp = keep;
+    const bool hit = KEEP && kp->hit;
+
     Model m;
-    m.load(g, k);   // every lane reads the same instance: broadcast loads
+    if constexpr (KEEP && std::is_same<Model, CompactModel<T>>::value) {
+        m.load_targets_and_uniforms(g);
+        if (hit) { m.a = kp->a; m.c = kp->c; }
+        else { m.load(g, k); kp->a = m.a; kp->c = m.c; }
+    } else {
+        m.load(g, k);   // every lane reads the same instance: broadcast loads
+    }
     const bool nonfinite = m.nonfinite();
     const bool badmodel = m.invalid();   // dlib's requires clause broken: return the start point
 
     // ---- prologue: this lane's Hessian row, Q_diag, linear-term element, lambda
-    T row[2 * H];
-    T my_qd = (T)0, my_g = (T)0;
-    hessian_row<T, I, H>(m, active, qi, qj, row);
-    my_qd = active ? pick_own<T, 2 * H>(row, slot) : (T)0;   // dlib's Q_diag of this lane's variable (mpc.h:118-121)
+    T* const row = kp->row;
+    T my_g = (T)0;
+    if (!hit) {
+        hessian_row<T, I, H>(m, active, qi, qj, row);
+        kp->my_qd = active ? pick_own<T, 2 * H>(row, slot) : (T)0;   // dlib's Q_diag of this lane's variable (mpc.h:118-121)
+    }
+    const T my_qd = kp->my_qd;
     // the entries of the row in variable order: the row itself for two inputs, every second slot of it for one
     T kq_one[I == 2 ? 1 : N];
     const T* kq = row;
@@ -383,7 +410,8 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, Hook 
         kq = kq_one;
     }
     const T my_r = active ? m.R(qj) : (T)0;
-    const T lambda = wave_sum_all<N>(my_qd + my_r);   // trace of the Hessian (idle lanes hold 0 + 0)
+    if (!hit) kp->lambda = wave_sum_all<N>(my_qd + my_r);   // trace of the Hessian (idle lanes hold 0 + 0)
+    const T lambda = kp->lambda;
     // every lane computes the same linear term.  The compact model needs no intermediates (its own
     // linear_term: one target for all steps); a short general horizon keeps them in registers; a long
     // one parks them -- identical in all lanes -- in one small LDS vector instead of 2H registers per lane
@@ -403,10 +431,13 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, Hook 
     // here instead of a ~13-instruction dependent division chain in every coordinate-descent
     // iteration (the product differs from the quotient by an ulp at most: within this family's
     // tolerance, like its FMA dot product)
-    const T my_rqd = (T)1 / my_qd;
-    const T inv_lambda = (T)1.0 / lambda;                 // mpc.h:342
-    const T sq = tsqrt(lambda);
-    const T beta = (sq - (T)1) / (sq + (T)1);             // mpc.h:343
+    if (!hit) {
+        kp->my_rqd = (T)1 / my_qd;
+        kp->inv_lambda = (T)1.0 / lambda;                 // mpc.h:342
+        const T sq = tsqrt(lambda);
+        kp->beta = (sq - (T)1) / (sq + (T)1);             // mpc.h:343
+    }
+    const T my_rqd = kp->my_rqd, inv_lambda = kp->inv_lambda, beta = kp->beta;
 
     T u = active ? WaveIO<T, I, H, Args>::init_u(g, k, qi, qj) : (T)0;
     T v = active ? WaveIO<T, I, H, Args>::init_v(g, k, qi, qj) : (T)0;
@@ -1217,10 +1248,12 @@ template <typename T, int I, int H, class Model = void> constexpr int wave_row_l
 template <typename T, int I, int H, class Model = void> constexpr int wave_lt_lds() { return wave_row_lds<T, I, H, Model>() > 1 ? 1 : 2 * H; }
 // (one where a wavefront parks a Hessian row in LDS: 40 KB each, and a workgroup's static LDS ends at 64 KB)
 template <typename T, int I, int H, class Model = void> constexpr int waves_per_block() { return wave_row_lds<T, I, H, Model>() > 1 ? 1 : kWavesPerBlock; }
-template <typename T, int I, int H, class Model, class Args, class Hook = NoHook>
-TPC_DEV void wave_solve_any(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s_row1, Hook before_loops = Hook{}) {
+// (`keep`: a resident wave's WaveKeep, used by the one-variable-per-lane layout only)
+template <typename T, int I, int H, class Model, class Args, class Hook = NoHook, class Keep = NoKeep>
+TPC_DEV void wave_solve_any(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s_row1, Hook before_loops = Hook{},
+                            Keep* keep = nullptr) {
     if constexpr (wave_scan<T, I, H, Model>()) wave2_solve<T, H, Model, Args, Hook>(g, kn, k, s_w, s_row1, before_loops);
-    else if constexpr (I * H <= kWave) wave_solve<T, I, H, Model, Args, Hook>(g, kn, k, s_w, before_loops);
+    else if constexpr (I * H <= kWave) wave_solve<T, I, H, Model, Args, Hook, Keep>(g, kn, k, s_w, before_loops, keep);
     else wave2_solve<T, H, Model, Args, Hook>(g, kn, k, s_w, s_row1, before_loops);
 }
 

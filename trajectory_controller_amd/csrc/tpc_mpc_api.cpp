@@ -506,7 +506,7 @@ int tpc_mpc_solve_one(tpc_mpc_handle h, const tpc_mpc_params* p, double v, doubl
         if (rc) return rc;
         rc = check_compact_model(h, p);
         if (rc) return rc;
-        HIP_TRY(h, hipSetDevice(h->device));
+        // (no HIP call on the resident path: the parts of one_shot_solve that launch or wait select the device themselves)
         return one_shot_solve(h, p, v, delta_y, delta_phi, steering_front, steering_rear);
     });
 }

@@ -30,6 +30,7 @@
 #include "tpc_mpc_context.h"
 
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -117,14 +118,29 @@ __global__ __launch_bounds__(64) void one_shot_kernel(const uint64_t* req, uint6
             const uint64_t its = field(kW_Iters);
             kn.max_iter = (uint32_t)its;
             kn.smo_iters = (uint32_t)(its >> 32);
+#ifdef TPC_ONE_TIMING   // diagnostic build only (scripts/latency.sh timing): where a solve's time goes, in shader clocks
+            const uint64_t t_seen = clock64();
+            uint64_t t_loops = 0;
+            auto stamp = [&]() { t_loops = clock64(); };
+#else
+            NoHook stamp;
+#endif
             if constexpr (kKeep) {
                 keep.hit = kept && __ballot(((kModelWords >> lane) & 1ull) != 0ull && word != kept_word) == 0ull;
-                wave_solve_any<double, 2, H, CompactModel<double>, OneArgs, NoHook, WaveKeep<double, H>>(g, kn, 0, s_w, s_row1, NoHook{}, &keep);
+                wave_solve_any<double, 2, H, CompactModel<double>, OneArgs, decltype(stamp), WaveKeep<double, H>>(g, kn, 0, s_w, s_row1, stamp, &keep);
                 kept_word = word;
                 kept = true;
             } else {
-                wave_solve_any<double, 2, H, CompactModel<double>, OneArgs>(g, kn, 0, s_w, s_row1);
+                wave_solve_any<double, 2, H, CompactModel<double>, OneArgs, decltype(stamp)>(g, kn, 0, s_w, s_row1, stamp);
             }
+#ifdef TPC_ONE_TIMING
+            const uint64_t t_done = clock64();
+            if (lane == 0) {
+                sys_store(mail + 27, sys_load(mail + 27) + (t_loops - t_seen));
+                sys_store(mail + 28, sys_load(mail + 28) + (t_done - t_loops));
+                sys_store(mail + 29, sys_load(mail + 29) + 1);
+            }
+#endif
         } else if (lane < 2) {
             sys_store(mail + kW_Front + lane, 0x7ff8000000000badull);   // the host never asks this
         }
@@ -162,6 +178,7 @@ inline void publish_request() {
 }
 
 int start_kernel(tpc_mpc_context* h, OneShot* o, int horizon, uint64_t start_seq) {
+    HIP_TRY(h, hipSetDevice(h->device));
     volatile uint64_t* m = mailbox(h);
     m[kW_Alive] = 1;
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
@@ -184,6 +201,7 @@ int start_kernel(tpc_mpc_context* h, OneShot* o, int horizon, uint64_t start_seq
 int stop_kernel(tpc_mpc_context* h, OneShot* o) {
     volatile uint64_t* m = mailbox(h);
     if (o->stream && m[kW_Alive]) {
+        HIP_TRY(h, hipSetDevice(h->device));
         volatile uint64_t* rq = request_lines(h);
         const uint64_t seq = ++o->seq;
         rq[kW_HorizonQuit] = 1ull << 32;
@@ -200,6 +218,7 @@ int stop_kernel(tpc_mpc_context* h, OneShot* o) {
 
 // The pre-resident path: one WAVE/LANE launch through the handle's mapped block, polled the same way.
 int launch_path(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double dy, double dphi, double* front, double* rear) {
+    HIP_TRY(h, hipSetDevice(h->device));
     tpc_mpc_params q = *p;
     // one instance: one wavefront, where a WAVE kernel exists; AUTO sorts out the other horizons itself
     const size_t es = esize(q.dtype);
@@ -249,6 +268,13 @@ int launch_path(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double dy
 void one_shot_destroy(tpc_mpc_context* h) {
     if (!h || !h->one) return;
     OneShot* o = h->one;
+#ifdef TPC_ONE_TIMING
+    {
+        volatile uint64_t* m = mailbox(h);
+        if (m[29]) fprintf(stderr, "[one timing] %llu solves: request seen -> loops %.0f clocks, loops -> result stored %.0f clocks\n",
+                           (unsigned long long)m[29], (double)m[27] / m[29], (double)m[28] / m[29]);
+    }
+#endif
     if (o->stream) {
         (void)stop_kernel(h, o);
         (void)hipStreamSynchronize(o->stream);
@@ -264,6 +290,7 @@ void one_shot_destroy(tpc_mpc_context* h) {
 }
 
 int one_shot_configure(tpc_mpc_context* h, int64_t idle_us) {
+    HIP_TRY(h, hipSetDevice(h->device));
     if (!h->one) {
         h->one = new (std::nothrow) OneShot;
         if (!h->one) return fail(h, TPC_MPC_ERR_ALLOC, "out of host memory");
@@ -305,7 +332,10 @@ int one_shot_solve(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double
     const bool resident_ok = !o->disabled && p->dtype == TPC_MPC_F64 && p->algo != TPC_MPC_ALGO_LANE &&
                              (H == 4 || H == 5 || H == 10 || H == 20 || H == 30 || H == 40);
     if (!resident_ok) return launch_path(h, p, v, dy, dphi, front, rear);
-    if (!o->stream) HIP_TRY(h, hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking));
+    if (!o->stream) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking));
+    }
     volatile uint64_t* m = mailbox(h);
     if (o->horizon != p->horizon && o->horizon != 0) {   // the resident wave serves another horizon: swap it
         int rc = stop_kernel(h, o);

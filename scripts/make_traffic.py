@@ -19,6 +19,7 @@ CONFIGS = {   # tag -> (kernel in the csv, bench key, k, note)
     "h30": ("tpc::ub_pg_kernel<fast>", "ub_pg_kernel_f64_H30_n262144", 1, "strided record reads: k=1"),
     "h40": ("tpc::ub_pg_kernel<fast>", "ub_pg_kernel_f64_H40_n262144", 1, "strided record reads: k=1"),
     "general": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_general_I2_f64_H20_n262144", 1, "strided record reads + SoA model loads: k=1"),
+    "generalfma": ("tpc::ubg_pg_kernel<fast>", "ubg_pg_kernel_general_I2_f64_H20_n262144", 1, "strided record reads + SoA model loads: k=1"),
 }
 import hashlib
 LIB = os.path.join("trajectory_controller_amd", "lib", "libtpc_mpc.so")

@@ -13,7 +13,7 @@ def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     head = name.split("(")[0].strip()
     base = head.split("<")[0]
-    if "lane_pg_fused_kernel" in base or "ub_pg_kernel" in base:
+    if "lane_pg_fused_kernel" in base or "ub_pg_kernel" in base or "ubg_pg_kernel" in base:
         args = head[len(base):]
         base += "<fast>" if args.rstrip(">").rstrip().endswith("true") else "<exact>"
     return base

@@ -26,16 +26,53 @@ template <typename T, bool EQB> TPC_DEV void ub_set_uniform(ub::Unit<T, EQB>& m,
 }
 
 // ------------------------------------------------------------------------------------------------
-// Phase 1: coordinate descent, 64 instances per wave in lockstep (see lane_cd_kernel).  Only the
-// reciprocals 1 / (Q_diag s) sit in LDS ([var][lane], read at the arg-max's index).
+// Phase 1: coordinate descent, 64 instances per wave in lockstep (see lane_cd_kernel).  In LDS ([var][lane]): the
+// reciprocals 1 / (Q_diag s), read at the arg-max's index, and -- where it fits a workgroup's 64 KB -- x itself (UbCdPlan).
+//
+// One iteration is a forward pass and a backward sweep that forms df[i] and offers it to the running arg-max at once
+// (no gradient is stored).  dlib scans i then j ascending with a strict '>' (mpc.h:289-309): the lowest index among
+// equal maxima wins; the sweep runs i and j DESCENDING with '>=', which picks the same one.  Two builds of the sweep:
+//   exact   dlib's mask by compare and select (mpc.h:298-299), the running maximum, its index, sign and x: 15
+//           instructions per variable, half of them halves of 64-bit selects;
+//   fast    (every lane of the wavefront passed the screen of the select-free stop test, ub::fast_stop_ok) the mask as
+//           arithmetic: g_lo / g_hi are 0 exactly on the bound and beyond every |df| off it (unit box: ldexp(x, 1900)
+//           and ldexp(1 - x, 1900), which cannot underflow to 0 for any x > 0; dlib's coordinates: the gap times 2^100
+//           as in ub_pg_kernel), mm = max(min(df, g_lo), -g_hi) is df where dlib counts it and 0 where it does not, and
+//           ONE signed value tracks the arg-max: better = |mm| >= |best|, best = better ? mm : best.  Same decisions,
+//           same x: both builds are bit-identical wherever the screen holds (the GPU tests hold them to the CPU model,
+//           which implements dlib's mask).
+// The winner's x comes from the LDS copy by index, and its update goes there; where registers are short (fp64, N >= 20)
+// the passes read x from LDS too and no register copy exists -- the 120-instruction select chain that wrote one
+// element of a register array, and ~240 AGPR moves per iteration, are gone.
+template <typename T, int H> struct UbCdPlan {
+    // x[2H][64] beside s_iqd[2H][64] within a workgroup's 64 KB of static LDS
+    static constexpr bool mirror = 2 * (2 * H * kWave * (int)sizeof(T)) <= 64 * 1024;
+#ifdef TPC_UB_CD_XLDS
+    static constexpr bool x_in_lds = mirror && TPC_UB_CD_XLDS != 0;
+#else
+    static constexpr bool x_in_lds = mirror && sizeof(T) == 8 && H >= 20;
+#endif
+#ifdef TPC_UB_CD_FAST
+    static constexpr bool fast = TPC_UB_CD_FAST != 0;
+#else
+    static constexpr bool fast = true;
+#endif
+};
+
+TPC_DEV double cd_ldexp(double x, int e) { return __builtin_ldexp(x, e); }
+TPC_DEV float cd_ldexp(float x, int e) { return __builtin_ldexpf(x, e); }
+
 template <typename T, int H, bool EQB>
 __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void ub_cd_kernel(CompactArgs g, Knobs kn, T* __restrict__ recs,
                                                                          uint32_t* __restrict__ keys,
                                                                          uint32_t* __restrict__ key_rank,
                                                                          uint32_t* __restrict__ key_hist,
                                                                          unsigned long long* __restrict__ stats) {
+    using P = UbCdPlan<T, H>;
     constexpr int RL = LaneRec<T, H>::kLen;
+    constexpr bool MIRROR = P::mirror, XL = P::x_in_lds;
     __shared__ T s_iqd[2 * H][kWave];
+    __shared__ T s_x[MIRROR ? 2 * H : 1][kWave];
     const int lane = threadIdx.x;
     const int64_t k = (int64_t)blockIdx.x * kWave + lane;
     if (k >= g.n) return;
@@ -47,79 +84,111 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void ub_cd_kernel(Compact
     const bool nonfinite = m.nonfinite_inputs(ty, tphi);
     const T q0 = (T)g.q[0], q1 = (T)g.q[1], r0 = (T)g.r[0], r1 = (T)g.r[1];
 
-    T x[2 * H], w[ub::Reverse<T, H>::value ? 1 : 2 * H];
+    T x[XL ? 1 : 2 * H], w[ub::Reverse<T, H>::value ? 1 : 2 * H];
+    auto X = [&](int q) -> T { if constexpr (XL) return s_x[q][lane]; else return x[q]; };
 #pragma unroll
-    for (int i = 0; i < H; ++i) { x[2 * i] = m.xz0; x[2 * i + 1] = m.xz1; }
+    for (int q = 0; q < 2 * H; ++q) {
+        if constexpr (!XL) x[q] = m.xz(q & 1);
+        if constexpr (MIRROR) s_x[q][lane] = m.xz(q & 1);
+    }
     const T lambda = ub::ctor_lambda_qdiag<T, H>(m.a, m.c, q0, q1, r0, r1, [&](int i, int j, T val) {
         s_iqd[2 * i + j][lane] = val != (T)0 ? (T)1 / (val * m.s(j)) : (T)0;   // mpc.h:322: a zero Q_diag never updates
     });
     const T eps = (T)kn.eps;
-    {
-        const unsigned long long failing = __ballot(!ub::fast_stop_ok(m, ty, tphi, q0, q1, r0, r1, eps, lambda));
-        if (failing != 0ull && lane == __ffsll((long long)failing) - 1) atomicOr(&stats[2], 1ull);
-    }
+    const bool screen_ok = ub::fast_stop_ok(m, ty, tphi, q0, q1, r0, r1, eps, lambda);
+    const unsigned long long failing = __ballot(!screen_ok);
+    if (failing != 0ull && lane == __ffsll((long long)failing) - 1) atomicOr(&stats[2], 1ull);
     const uint32_t cd_iters = kn.smo_iters < kn.max_iter ? kn.smo_iters : kn.max_iter;
     uint32_t iter = 0;
     bool stopped = nonfinite;
     bool vinit = false;
-#pragma unroll 1
-    for (uint32_t it = 0; it < cd_iters; ++it) {
-        if (__ballot(!stopped) == 0ull) break;
-        // gradient (mpc.h:275-283 in the family's coordinates) fused with the arg-max scan: forward pass, then one
-        // backward sweep that forms df[i] and offers it to the running arg-max at once, so no gradient is ever
-        // stored.  dlib scans i then j ascending with a strict '>' (mpc.h:289-309): the lowest index among equal
-        // maxima wins; this sweep runs i and j DESCENDING with '>=', which picks the same one.  Where the family
-        // regenerates the forward pass (ub::Reverse) nothing of it is kept either.
+    constexpr T kHuge = (T)(sizeof(T) == 8 ? 0x1p600 : 0x1p100);
+    T huge = kHuge;
+    asm volatile("" : "+v"(huge));
+
+    auto iteration = [&](auto fast_tag, uint32_t it) {
+        constexpr bool F = decltype(fast_tag)::value;
         constexpr bool RV = ub::Reverse<T, H>::value;
         T Z, Y;
         m.fwd_init(Z, Y);
 #pragma unroll
         for (int i = 0; i < H; ++i) {
-            m.fwd(Z, Y, x[2 * i], x[2 * i + 1]);
+            m.fwd(Z, Y, X(2 * i), X(2 * i + 1));
             if constexpr (!RV) { w[2 * i] = Z; w[2 * i + 1] = Y; }
         }
         T n0, n1;
         m.bwd_last(n0, n1, Z, Y);
-        T max_df = (T)0, best_x = (T)0;
+        T max_df = (T)0, best_x = (T)0, best_mm = (T)0;
         int best = 0, best_sign = 0;
 #pragma unroll
         for (int i = H - 1; i >= 0; --i) {
             if (i < H - 1) {
                 if constexpr (RV) m.bwd(n0, n1, Z, Y); else m.bwd(n0, n1, w[2 * i], w[2 * i + 1]);
             }
+            const T xi[2] = {X(2 * i), X(2 * i + 1)};
 #pragma unroll
             for (int j = 1; j >= 0; --j) {
                 const int q = 2 * i + j;
-                const T xx = x[q];
+                const T xx = xi[j];
                 const T dd = j == 0 ? m.df0(n1, xx) : m.df1(n0, n1, xx);
-                const T up = (xx <= m.bl(j)) ? (T)0 : dd;
-                const T dn = (xx >= m.bh(j)) ? (T)0 : -dd;
-                const T mag = tmax(up, dn);
-                const bool better = mag >= max_df && mag > (T)0;   // (a zero never displaces the initial "none")
-                max_df = tmax(max_df, mag);
-                best = better ? q : best;
-                best_sign = better ? sign_word(dd) : best_sign;
-                best_x = better ? xx : best_x;
+                if constexpr (F) {
+                    T g_lo, g_hi;
+                    if constexpr (ub::Unit<T, EQB>::kUnitBox) { g_lo = cd_ldexp(xx, 1900); g_hi = cd_ldexp((T)1 - xx, 1900); }
+                    else { g_lo = m.gap_lo(j, xx, huge); g_hi = m.gap_hi(j, xx, huge); }
+                    const T mm = tmax(tmin(dd, g_lo), -g_hi);         // df where dlib counts it (mpc.h:298-299), else 0
+                    const bool better = tabs(mm) >= tabs(best_mm);   // (zeros may pass one another: all of them mean 'none')
+                    best_mm = better ? mm : best_mm;
+                    best = better ? q : best;
+                    if constexpr (!MIRROR) best_x = better ? xx : best_x;
+                } else {
+                    const T up = (xx <= m.bl(j)) ? (T)0 : dd;
+                    const T dn = (xx >= m.bh(j)) ? (T)0 : -dd;
+                    const T mag = tmax(up, dn);
+                    const bool better = mag >= max_df && mag > (T)0;   // (a zero never displaces the initial "none")
+                    max_df = tmax(max_df, mag);
+                    best = better ? q : best;
+                    best_sign = better ? sign_word(dd) : best_sign;
+                    if constexpr (!MIRROR) best_x = better ? xx : best_x;
+                }
             }
-            if constexpr (RV) { if (i > 0) m.rev(Z, Y, x[2 * i], x[2 * i + 1]); }
+            if constexpr (RV) { if (i > 0) m.rev(Z, Y, xi[0], xi[1]); }
         }
-        if (!stopped && max_df < eps) stopped = true;           // mpc.h:310-311
-        if (!stopped) {
-            const T best_df = with_sign(max_df, best_sign);
-            const T iq = s_iqd[best][lane];
-            if (iq != (T)0) {                                   // mpc.h:322 (`continue` still counts)
-                const T nx = m.project(ub::fma_(-iq, best_df, best_x), best & 1);   // mpc.h:325-326
+        if constexpr (F) max_df = tabs(best_mm);
+        // (select form, no divergent block: a conditional update of the register copy of x costs a copy of all of it)
+        stopped = stopped || max_df < eps;                      // mpc.h:310-311
+        const bool act = !stopped;
+        T best_df;
+        if constexpr (F) best_df = best_mm; else best_df = with_sign(max_df, best_sign);
+        if constexpr (MIRROR) best_x = s_x[best][lane];
+        const T iq = s_iqd[best][lane];
+        const bool upd = act && iq != (T)0;                     // mpc.h:322 (`continue` still counts)
+        const T nx = m.project(ub::fma_(-iq, best_df, best_x), best & 1);   // mpc.h:325-326
+        if constexpr (MIRROR) { if (upd) s_x[best][lane] = nx; }
+        if constexpr (!XL) {
+            const int sel = upd ? best : -1;
 #pragma unroll
-                for (int q = 0; q < 2 * H; ++q) x[q] = (q == best) ? nx : x[q];
-                vinit = (it + 1 == kn.smo_iters);               // mpc.h:330-334
-            }
-            ++iter;
+            for (int q = 0; q < 2 * H; ++q) x[q] = (q == sel) ? nx : x[q];
+        }
+        vinit = upd ? (it + 1 == kn.smo_iters) : vinit;         // mpc.h:330-334
+        iter += act ? 1u : 0u;
+    };
+    if (P::fast && failing == 0ull) {
+#pragma unroll 1
+        for (uint32_t it = 0; it < cd_iters; ++it) {
+            if (__ballot(!stopped) == 0ull) break;
+            iteration(std::true_type{}, it);
+        }
+    } else {
+#pragma unroll 1
+        for (uint32_t it = 0; it < cd_iters; ++it) {
+            if (__ballot(!stopped) == 0ull) break;
+            iteration(std::false_type{}, it);
         }
     }
 
     T* rec = recs + (int64_t)k * RL;
 #pragma unroll
-    for (int q = 0; q < 2 * H; ++q) rec[q] = x[q];
+    for (int q = 0; q < 2 * H; ++q) rec[q] = X(q);
     rec[2 * H] = lambda;
     uint64_t meta = (uint64_t)iter;
     if (stopped) meta |= kMetaStopped;
@@ -139,8 +208,8 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void ub_cd_kernel(Compact
     else if (key >= 0x7f000000u) key = 0x7effffffu;
     uint32_t f = 0;
     if (finished) {   // complete: published here, the PG kernel's queue ends before these
-        ((T*)g.front)[k] = nonfinite ? (T)0 : m.control(0, x[0]);
-        ((T*)g.rear)[k] = nonfinite ? (T)0 : m.control(1, x[1]);
+        ((T*)g.front)[k] = nonfinite ? (T)0 : m.control(0, X(0));
+        ((T*)g.rear)[k] = nonfinite ? (T)0 : m.control(1, X(1));
         if (g.iters) g.iters[k] = (int32_t)iter;
         if (nonfinite) f |= 0x1u;
         if (!stopped) f |= 0x2u;

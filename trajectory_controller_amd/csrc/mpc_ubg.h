@@ -32,10 +32,10 @@ template <typename T, int I> TPC_DEV void ubg_load(ubg::Gen<T, I>& m, const Gene
 }
 
 // ------------------------------------------------------------------------------------------------
-// Phase 1: coordinate descent (mpc.h:319-335), 64 instances per wave in lockstep.  1 / Q_diag and the linear
-// term MM sit in LDS ([slot][lane], slot = 2 i + j).
+// Phase 1: coordinate descent (mpc.h:319-335), 64 instances per wave in lockstep.  1 / Q_diag, the linear
+// term MM and a copy of u sit in LDS ([slot][lane], slot = 2 i + j; three arrays: two wavefronts per SIMD at most).
 template <typename T, int I, int H>
-__global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void ubg_cd_kernel(GeneralArgs g, Knobs kn, T* __restrict__ recs,
+__global__ __launch_bounds__(64, (CdOcc<T, H>::value > 2 ? 2 : CdOcc<T, H>::value)) void ubg_cd_kernel(GeneralArgs g, Knobs kn, T* __restrict__ recs,
                                                                           uint32_t* __restrict__ keys,
                                                                           uint32_t* __restrict__ key_rank,
                                                                           uint32_t* __restrict__ key_hist,
@@ -43,6 +43,7 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void ubg_cd_kernel(Genera
     constexpr int RL = LaneRec<T, H>::kLen;
     __shared__ T s_rqd[2 * H][kWave];
     __shared__ T s_mm[2 * H][kWave];
+    __shared__ T s_u[2 * H][kWave];
     const int lane = threadIdx.x;
     const int64_t k = (int64_t)blockIdx.x * kWave + lane;
     if (k >= g.n) return;
@@ -54,9 +55,23 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void ubg_cd_kernel(Genera
     const bool badmodel = m.invalid();
     const T* tg = (const T*)g.targets + k;
 
-    T u[2 * H], w[2 * H];
+    // u: a copy in LDS always (the winner is read and written there by index); in registers too, except where they are
+    // short (fp64, N = 20: the passes read the LDS copy)
+    constexpr bool XL = sizeof(T) == 8 && H >= 20;
+    T u[XL ? 2 : 2 * H], w[2 * H];
+    auto U = [&](int q) -> T { if constexpr (XL) return s_u[q][lane]; else return u[q]; };
+    // the I controls of a step as the model's pointer argument
+    T tmp_u[2] = {(T)0, (T)0};
+    auto UP = [&](int q) -> const T* {
+        if constexpr (XL) { tmp_u[0] = s_u[q][lane]; if (I == 2) tmp_u[1] = s_u[q + 1][lane]; return tmp_u; }
+        else return &u[q];
+    };
+    auto UP2 = [&](int q, T* out) { out[0] = U(q); out[1] = I == 2 ? U(q + 1) : (T)0; };
 #pragma unroll
-    for (int q = 0; q < 2 * H; ++q) u[q] = (T)0;
+    for (int q = 0; q < 2 * H; ++q) {
+        if constexpr (!XL) u[q] = (T)0;
+        s_u[q][lane] = (T)0;
+    }
     const T lambda = ubg::ctor_lambda_qdiag<T, I, H>(m, [&](int i, int j, T val) {
         s_rqd[2 * i + j][lane] = val != (T)0 ? (T)1 / val : (T)0;   // mpc.h:322: a zero Q_diag never updates
     });
@@ -68,69 +83,103 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void ubg_cd_kernel(Genera
         [&](int i, int j, T val) { s_mm[2 * i + j][lane] = val; mm_max = tmax(mm_max, tabs(val)); mm_nan = mm_nan || val != val; });
     if (mm_nan) mm_max = (T)__builtin_inf();
     const T eps = (T)kn.eps;
-    {
-        const unsigned long long failing = __ballot(!ubg::fast_stop_ok(m, mm_max, eps, lambda, H));
-        if (failing != 0ull && lane == __ffsll((long long)failing) - 1) atomicOr(&stats[2], 1ull);
-    }
+    const unsigned long long failing = __ballot(!ubg::fast_stop_ok(m, mm_max, eps, lambda, H));
+    if (failing != 0ull && lane == __ffsll((long long)failing) - 1) atomicOr(&stats[2], 1ull);
     const uint32_t cd_iters = kn.smo_iters < kn.max_iter ? kn.smo_iters : kn.max_iter;
     uint32_t iter = 0;
     bool stopped = badmodel;   // (dlib propagates non-finite values through this arithmetic itself: flagged, not screened)
     bool vinit = false;
-#pragma unroll 1
-    for (uint32_t it = 0; it < cd_iters; ++it) {
-        if (__ballot(!stopped) == 0ull) break;
+    constexpr T kHuge = (T)(sizeof(T) == 8 ? 0x1p600 : 0x1p100);
+    T huge = kHuge;
+    asm volatile("" : "+v"(huge));
+    T lo_h[I], hi_h[I];
+#pragma unroll
+    for (int j = 0; j < I; ++j) { lo_h[j] = -(m.lo[j] * huge); hi_h[j] = m.hi[j] * huge; }
+
+    // One iteration, in the two builds of ub_cd_kernel (mpc_ub.h): `fast` where every lane of the wavefront passed the
+    // screen -- dlib's mask as arithmetic on the gaps (u - lower) 2^600 and (upper - u) 2^600, one signed running
+    // arg-max -- else dlib's compares and selects.  Same decisions, same u.
+    auto iteration = [&](auto fast_tag, uint32_t it) {
+        constexpr bool F = decltype(fast_tag)::value;
         T m0, m1;
-        m.first(m0, m1, &u[0]);
+        m.first(m0, m1, UP(0));
         w[0] = m0; w[1] = m1;
 #pragma unroll
         for (int i = 1; i < H; ++i) {
-            m.fwd(m0, m1, &u[2 * i]);
+            m.fwd(m0, m1, UP(2 * i));
             w[2 * i] = m0; w[2 * i + 1] = m1;
         }
         T n0, n1;
         m.bwd_last(n0, n1, m0, m1);
         // arg-max fused into the backward sweep: descending with '>=' picks what dlib's ascending strict '>' picks
-        T max_df = (T)0, best_u = (T)0;
+        T max_df = (T)0, best_mm = (T)0;
         int best = 0, best_sign = 0;
 #pragma unroll
         for (int i = H - 1; i >= 0; --i) {
             if (i < H - 1) m.bwd(n0, n1, w[2 * i], w[2 * i + 1]);
+            T ui[2];
+            UP2(2 * i, ui);
 #pragma unroll
             for (int j = I - 1; j >= 0; --j) {
                 const int q = 2 * i + j;
-                const T uu = u[q];
+                const T uu = ui[j];
                 const T dd = m.df(j, n0, n1, uu, s_mm[q][lane]);
-                const T up = (uu <= m.lo[j]) ? (T)0 : dd;
-                const T dn = (uu >= m.hi[j]) ? (T)0 : -dd;
-                const T mag = tmax(up, dn);
-                const bool better = mag >= max_df && mag > (T)0;
-                max_df = tmax(max_df, mag);
-                best = better ? q : best;
-                best_sign = better ? sign_word(dd) : best_sign;
-                best_u = better ? uu : best_u;
+                if constexpr (F) {
+                    const T g_lo = ub::fma_(uu, huge, lo_h[j]), g_hi = ub::fma_(-huge, uu, hi_h[j]);
+                    const T mm = tmax(tmin(dd, g_lo), -g_hi);         // df where dlib counts it (mpc.h:298-299), else 0
+                    const bool better = tabs(mm) >= tabs(best_mm);   // (zeros may pass one another: all of them mean 'none')
+                    best_mm = better ? mm : best_mm;
+                    best = better ? q : best;
+                } else {
+                    const T up = (uu <= m.lo[j]) ? (T)0 : dd;
+                    const T dn = (uu >= m.hi[j]) ? (T)0 : -dd;
+                    const T mag = tmax(up, dn);
+                    const bool better = mag >= max_df && mag > (T)0;
+                    max_df = tmax(max_df, mag);
+                    best = better ? q : best;
+                    best_sign = better ? sign_word(dd) : best_sign;
+                }
             }
         }
-        if (!stopped && max_df < eps) stopped = true;           // mpc.h:310-311
-        if (!stopped) {
-            const T best_df = with_sign(max_df, best_sign);
-            const T rq = s_rqd[best][lane];
-            if (rq != (T)0) {                                   // mpc.h:322 (`continue` still counts)
-                // (bounds picked by select: a run-time index would put the model in scratch)
-                const bool second = I == 2 && (best & 1);
-                const T blo = second ? m.lo[I - 1] : m.lo[0], bhi = second ? m.hi[I - 1] : m.hi[0];
-                const T nu = tmax(tmin(ub::fma_(-rq, best_df, best_u), bhi), blo);   // mpc.h:325-326
+        if constexpr (F) max_df = tabs(best_mm);
+        stopped = stopped || max_df < eps;                      // mpc.h:310-311
+        const bool act = !stopped;
+        T best_df;
+        if constexpr (F) best_df = best_mm; else best_df = with_sign(max_df, best_sign);
+        const T best_u = s_u[best][lane];
+        const T rq = s_rqd[best][lane];
+        const bool upd = act && rq != (T)0;                     // mpc.h:322 (`continue` still counts)
+        // (bounds picked by select: a run-time index would put the model in scratch)
+        const bool second = I == 2 && (best & 1);
+        const T blo = second ? m.lo[I - 1] : m.lo[0], bhi = second ? m.hi[I - 1] : m.hi[0];
+        const T nu = tmax(tmin(ub::fma_(-rq, best_df, best_u), bhi), blo);   // mpc.h:325-326
+        if (upd) s_u[best][lane] = nu;
+        if constexpr (!XL) {
+            const int sel = upd ? best : -1;
 #pragma unroll
-                for (int q = 0; q < 2 * H; ++q)
-                    if ((q & 1) < I) u[q] = (q == best) ? nu : u[q];
-                vinit = (it + 1 == kn.smo_iters);               // mpc.h:330-334
-            }
-            ++iter;
+            for (int q = 0; q < 2 * H; ++q)
+                if ((q & 1) < I) u[q] = (q == sel) ? nu : u[q];
+        }
+        vinit = upd ? (it + 1 == kn.smo_iters) : vinit;         // mpc.h:330-334
+        iter += act ? 1u : 0u;
+    };
+    if (failing == 0ull) {
+#pragma unroll 1
+        for (uint32_t it = 0; it < cd_iters; ++it) {
+            if (__ballot(!stopped) == 0ull) break;
+            iteration(std::true_type{}, it);
+        }
+    } else {
+#pragma unroll 1
+        for (uint32_t it = 0; it < cd_iters; ++it) {
+            if (__ballot(!stopped) == 0ull) break;
+            iteration(std::false_type{}, it);
         }
     }
 
     T* rec = recs + (int64_t)k * RL;
 #pragma unroll
-    for (int q = 0; q < 2 * H; ++q) rec[q] = ((q & 1) < I) ? u[q] : (T)0;
+    for (int q = 0; q < 2 * H; ++q) rec[q] = ((q & 1) < I) ? U(q) : (T)0;
     rec[2 * H] = lambda;
     uint64_t meta = (uint64_t)iter;
     if (stopped) meta |= kMetaStopped;
@@ -153,7 +202,7 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void ubg_cd_kernel(Genera
     uint32_t f = 0;
     if (finished) {
 #pragma unroll
-        for (int j = 0; j < I; ++j) ((T*)g.u0)[(int64_t)j * g.ld + k] = u[j];
+        for (int j = 0; j < I; ++j) ((T*)g.u0)[(int64_t)j * g.ld + k] = U(j);
         if (g.iters) g.iters[k] = (int32_t)iter;
         if (nonfinite) f |= 0x1u;
         if (badmodel) f |= 0x4u;

@@ -87,8 +87,8 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
  *   AUTO : the fastest family that meets the 1e-6 parity target: WAVE below a measured crossover, from
  *          there up LANE_FMA where it exists (above) and LANE elsewhere.  On a 256-CU part the
  *          crossover lies between 21 504 and 32 768 instances (the largest batch the WAVE work queue takes)
- *          depending on horizon, dtype and form -- compact form, fp64: 32 768 at N = 4, 5, 30, 40, 28 672 at
- *          N = 10, 21 504 at N = 20; general form at N = 40: 19 456 -- and scales with the CU count.  A host
+ *          depending on horizon, dtype and form -- compact form, fp64: 28 672 at N = 4, 5, 26 624 at N = 10,
+ *          21 504 at N = 20, 32 768 at N = 30, 40; general form at N = 40: 19 456 -- and scales with the CU count.  A host
  *          that needs dlib's bits asks for LANE. */
 typedef enum tpc_mpc_algo {
     TPC_MPC_ALGO_AUTO = 0, TPC_MPC_ALGO_WAVE = 1, TPC_MPC_ALGO_LANE = 2, TPC_MPC_ALGO_LANE_FMA = 3

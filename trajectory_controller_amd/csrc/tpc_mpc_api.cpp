@@ -99,13 +99,16 @@ int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n, int d
         // compact form: the other side is LANE_FMA, twice as fast as LANE, so WAVE gives way earlier where the two
         // meet below the queue's limit (profiles/r03_crossover.txt, kernel times in ms at 16 384 / 24 576 / 32 768
         // instances, WAVE against LANE_FMA):
-        //   fp64  N=10: .36/.53  .49/.54  .63/.54     N=20: 2.8/3.6  4.1/3.6  5.3/3.7     N=4, 5, 30, 40: WAVE up to 32 768
-        //   fp32  N=4: .10/.14  .14/.15  .17/.15      N=5, 10: .13/.16 .19/.17, .46/.59 .66/.59      N=20, 30, 40: WAVE up to 32 768
+        //   fp64  N=4: .083/.128 .123/.134 .147/.140   N=5: .098/.149 .147/.156 .171/.164   N=10: .36/.52 .49/.53 .65/.53
+        //         N=20: 2.9/3.6 4.1/3.6 5.2/3.6        N=30, 40: WAVE up to 32 768
+        //   fp32  N=4: .10/.13 .136/.139 .175/.143     N=5: .13/.15 .19/.16 .24/.17         N=10: .46/.57 .67/.57 .88/.58
+        //         N=20, 30, 40: WAVE up to 32 768
         const bool d = dtype == TPC_MPC_F64;
         int64_t at = kWaveQueueMaxInstances + 1;
-        if (d && H == 10) at = 28672;
+        if (d && (H == 4 || H == 5)) at = 28672;
+        if (d && H == 10) at = 26624;
         if (d && H == 20) at = 21504;
-        if (!d && H == 4) at = 28672;
+        if (!d && H == 4) at = 24576;
         if (!d && (H == 5 || H == 10)) at = 21504;
         crossover = at * h->cu_count / 256 < at ? at * h->cu_count / 256 : at;
     }

@@ -361,22 +361,57 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
         if (g.iters) g.iters[k] = (int32_t)it;
     };
 
+    // The queue (longest first) is handed out in two parts.  The first kDeal percent is DEALT: wavefront w of W
+    // owns entries w, w + W, w + 2W, ... (every wavefront gets one instance of each block of W neighbours in the order,
+    // so the shares are even), knows its next 64 entries a pass ahead (one coalesced-in-time load per lane, issued with
+    // the previous pass's record loads) and needs no atomic: a refill pass is ONE memory round trip -- the records --
+    // instead of three dependent ones (ticket, queue entry, record: ~5.5 us of which the ticket atomic, at 17 M/s on one
+    // address, was the longest).  The rest -- the shortest instances -- goes through the ticket as before and evens out
+    // what the deal left uneven.
+    // Measured (PG kernel, 262 144 instances, fp64; dealt share 0 / 70 / 85 / 95 %): N = 4: 0.198 / 0.163 / 0.160 / 0.154 ms,
+    // N = 10: 0.910 / 0.915 / 0.901 / 0.888, N = 20: 5.34 / 5.41 / 5.40 / 5.52 -- at N = 20 a pass is dominated by the 42 scattered
+    // record loads and the set-up behind them, not by the round trips in front, and the deal's 0.6 % of extra wave
+    // iterations (shares are even by rank, not by iteration count) cost more than it saves: dealt up to N = 10 only.
+#ifdef TPC_UB_DEAL
+    constexpr int kDeal = TPC_UB_DEAL;
+#else
+    constexpr int kDeal = H <= 10 ? 95 : 0;
+#endif
+    const int wl = lane & (kWave - 1);
+    const uint32_t n_waves = gridDim.x * (uint32_t)P::occ;
+    const uint32_t wave_id = blockIdx.x * (uint32_t)P::occ + ((uint32_t)threadIdx.x >> 6);
+    const uint32_t per_wave = (uint32_t)((n_queue * kDeal / 100) / (int64_t)n_waves);   // dealt entries per wavefront
+    const uint32_t dyn_base = per_wave * n_waves;                                            // first entry of the ticket part
+    uint32_t dealt = 0;                                                                      // (wave-uniform)
+    uint32_t next_k = (uint32_t)wl < per_wave ? order[(int64_t)wl * n_waves + wave_id] : 0u;
+
 #pragma unroll 1
     while (true) {
         // ---- refill: see lane_pg_fused_kernel
         const unsigned long long want = __ballot(!have && !exhausted);
         if (want != 0ull && (__popcll(want) >= UbRefillBatch<H>::value || __ballot(have) == 0ull)) {
             ++refills;
-            const int wl = lane & (kWave - 1);
+            const uint32_t cnt = (uint32_t)__popcll(want);
+            const uint32_t rank = (uint32_t)__popcll(want & ((1ull << wl) - 1ull));
+            // the dealt part of the queue first (no atomic, its entries already here), then tickets
+            const uint32_t left = per_wave - dealt;
+            const uint32_t n_stat = cnt < left ? cnt : left, n_dyn = cnt - n_stat;      // (wave-uniform)
+            const uint32_t k_dealt = (uint32_t)__shfl((int)next_k, (int)rank);         // entry dealt + rank sits in lane `rank`
+            if (n_stat != 0u) {   // the entries of the next pass: this load travels with the record loads below
+                dealt += n_stat;
+                next_k = dealt + (uint32_t)wl < per_wave ? order[(int64_t)(dealt + (uint32_t)wl) * n_waves + wave_id] : 0u;
+            }
             uint32_t first_ticket = 0;
-            if (wl == __ffsll((long long)want) - 1) first_ticket = atomicAdd(ticket, (uint32_t)__popcll(want));
-            first_ticket = (uint32_t)__shfl((int)first_ticket, __ffsll((long long)want) - 1);
+            if (n_dyn != 0u) {
+                if (wl == __ffsll((long long)want) - 1) first_ticket = atomicAdd(ticket, n_dyn);
+                first_ticket = (uint32_t)__shfl((int)first_ticket, __ffsll((long long)want) - 1);
+            }
             if (!have && !exhausted) {
-                const uint32_t t = first_ticket + (uint32_t)__popcll(want & ((1ull << wl) - 1ull));
-                if ((int64_t)t >= n_queue) {
+                const uint32_t t = dyn_base + first_ticket + (rank - n_stat);          // (used by the lanes past the dealt ones)
+                if (rank >= n_stat && (int64_t)t >= n_queue) {
                     exhausted = true;
                 } else {
-                    k = (int64_t)order[t];
+                    k = rank < n_stat ? (int64_t)k_dealt : (int64_t)order[t];
                     const T* rec = recs + k * RL;
                     const T vk = ((const T*)g.v)[k], ty = ((const T*)g.dy)[k], tphi = ((const T*)g.dphi)[k];
 #pragma unroll

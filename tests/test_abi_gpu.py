@@ -275,6 +275,33 @@ def test_sharded_entry_through_rccl_world_of_one(torch_cuda, ragged):
     assert torch.equal(f, want[0]) and torch.equal(r, want[1])
 
 
+@pytest.mark.parametrize("ragged", [False, True])
+def test_general_sharded_entry(torch_cuda, oracle, ragged):
+    """tpc_mpc_solve_batch_general_sharded: a world of one without a communicator, then through a real one-rank RCCL
+    communicator (grouped in-place ncclAllGather per row of u0, or the per-owner ncclBroadcast form): the full batch,
+    bit-identical to the plain general solve and to the oracle (LANE family)."""
+    from trajectory_controller_amd import MpcSolver
+    from trajectory_controller_amd.synth import general_inputs
+    torch = torch_cuda
+    I, H, n = 2, 10, 2049
+    g = general_inputs(H, n, I=I, first=321)
+    names = ["A", "B", "C", "Q", "R", "lo", "hi", "x0", "targets"]
+    ou0, _, oit = oracle.solve_general(I, H, *[g[k] for k in names], nthreads=8)
+    dev = [torch.from_numpy(np.ascontiguousarray(g[k].reshape(n, -1).T)).cuda() for k in names]
+    with _solver(H, "lane") as s:
+        want = s.solve_batch_general(*dev, inputs=I)
+        u0 = s.solve_batch_general_sharded(*dev, inputs=I)
+        s.comm_test_mode(True, ragged)
+        s.comm_init(MpcSolver.comm_unique_id(), 0, 1)
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            u1, it = s.solve_batch_general_sharded(*dev, inputs=I, want_iters=True)
+        stream.synchronize()
+        assert s.last_flags == 0
+    assert torch.equal(u0, want) and torch.equal(u1, want)
+    assert bits_equal(want.cpu().numpy().T, ou0) and np.array_equal(it.cpu().numpy(), oit)
+
+
 _RANK_WORKER = r'''
 import os, sys
 sys.path.insert(0, {root!r})

@@ -34,7 +34,8 @@ EXPORTS = ("tpc_mpc_default_params", "tpc_mpc_create", "tpc_mpc_destroy", "tpc_m
            "tpc_mpc_build_info", "tpc_mpc_set_resident", "tpc_mpc_solve_batch_compact_mixed",
            "tpc_mpc_follow_batch_horizon", "tpc_mpc_comm_unique_id", "tpc_mpc_comm_init_rank",
            "tpc_mpc_comm_destroy", "tpc_mpc_group_begin", "tpc_mpc_group_end", "tpc_mpc_shard_range",
-           "tpc_mpc_solve_batch_compact_sharded", "tpc_mpc_comm_test_mode")
+           "tpc_mpc_solve_batch_compact_sharded", "tpc_mpc_comm_test_mode",
+           "tpc_mpc_solve_batch_general_sharded")
 
 
 class Params(C.Structure):
@@ -98,6 +99,7 @@ def load_library(path: str | None = None) -> C.CDLL:
                                                 vp, u32p, C.c_int, vp]
     lib.tpc_mpc_solve_batch_general.argtypes = [vp, C.POINTER(Params), C.POINTER(GeneralIO), u32p,
                                                 C.c_int, vp]
+    lib.tpc_mpc_solve_batch_general_sharded.argtypes = [vp, C.POINTER(Params), C.POINTER(GeneralIO), u32p, vp]
     lib.tpc_mpc_rollout.argtypes = [vp, C.POINTER(Params), C.POINTER(GeneralIO), C.c_int32, vp, vp, vp,
                                     vp, u32p, C.c_int, vp]
     lib.tpc_mpc_set_profiling.argtypes = [vp, C.c_int]

@@ -335,6 +335,36 @@ int context_new(int device, int cu_count, tpc_mpc_context** out) {
     return TPC_MPC_OK;
 }
 
+// The general form on DEVICE arrays, launches only (the sharded entry, tpc_mpc_comm.cpp, brackets it with the stream
+// order, the flag word and the exchange): io describes the block to solve.
+int general_launch(tpc_mpc_context* h, const tpc_mpc_params* p, const tpc_mpc_general_io* io, hipStream_t s) {
+    const int I = io->inputs, H = p->horizon;
+    const int64_t n = io->n;
+    const int algo = pick_algo(h, p->algo, I, H, n, p->dtype, fma_general_usable(H, io->controls_inout, io->v_inout), false);
+    if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel exists for the specialised horizons with inputs*horizon <= 64 only; use LANE or AUTO");
+    GeneralArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.n = n; a.ld = io->ld; a.shift_controls = 1;
+    a.A = io->A; a.B = io->B; a.C = io->C; a.Q = io->Q; a.R = io->R; a.lo = io->lower; a.hi = io->upper;
+    a.x0 = io->x0; a.targets = io->targets; a.controls = io->controls_inout; a.v = io->v_inout;
+    a.u0 = io->u0; a.iters = io->iters;
+    a.flags = h->ws_words + 1;
+    a.work_hint = take_hint(h, n);
+    Workspace ws;
+    int rc = prepare_workspace(h, algo, H, p->dtype, n, &ws);
+    if (rc) return rc;
+    hipError_t e = dispatch_general(algo, I, H, p->dtype, a, knobs_of(p), ws, s);
+    if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
+    return TPC_MPC_OK;
+}
+int check_general_device_io(tpc_mpc_context* h, const tpc_mpc_general_io* io) {
+    int rc = check_general_io(h, io, TPC_MPC_DEVICE);
+    if (rc) return rc;
+    if (io->n > 0 && (!io->A || !io->B || !io->C || !io->Q || !io->R || !io->lower || !io->upper || !io->x0 || !io->targets || !io->u0))
+        return fail(h, TPC_MPC_ERR_BAD_ARG, "null batch pointer");
+    return TPC_MPC_OK;
+}
+
 int compact_launch(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy,
                    const void* dphi, void* front, void* rear, int32_t* iters, hipStream_t s) {
     const int algo = pick_algo(h, p->algo, 2, p->horizon, n, p->dtype, fma_usable(p));

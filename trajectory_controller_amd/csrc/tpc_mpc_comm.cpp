@@ -262,4 +262,66 @@ int tpc_mpc_solve_batch_compact_sharded(tpc_mpc_handle h, const tpc_mpc_params* 
     });
 }
 
+int tpc_mpc_solve_batch_general_sharded(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mpc_general_io* io_all,
+                                        uint32_t* flags_out, void* stream) {
+    return guarded(h, [&]() -> int {
+        int rc = check_common(h, p);
+        if (rc) return rc;
+        rc = check_general_device_io(h, io_all);
+        if (rc) return rc;
+        const int64_t n_total = io_all->n, ld = io_all->ld;
+        if (n_total == 0) { if (flags_out) *flags_out = 0; return TPC_MPC_OK; }
+        const int rank = h->comm ? h->comm->rank : 0, world = h->comm ? h->comm->world : 1;
+        int64_t first = 0, count = 0;
+        shard_range(n_total, rank, world, &first, &count);
+        HIP_TRY(h, hipSetDevice(h->device));
+        hipStream_t s = (hipStream_t)stream;
+        const int64_t es = (int64_t)esize(p->dtype);
+        const int I = io_all->inputs;
+        StreamOrderScope order(h, s);
+        rc = order.begin();
+        if (rc) return rc;
+        HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
+        // this rank's block: columns [first, first + count) of the full-size arrays, solved in place
+        if (count > 0) {
+            tpc_mpc_general_io blk = *io_all;
+            auto at = [&](const void* base) -> const void* { return base ? (const char*)base + first * es : nullptr; };
+            blk.n = count;
+            blk.A = at(io_all->A); blk.B = at(io_all->B); blk.C = at(io_all->C); blk.Q = at(io_all->Q); blk.R = at(io_all->R);
+            blk.lower = at(io_all->lower); blk.upper = at(io_all->upper); blk.x0 = at(io_all->x0); blk.targets = at(io_all->targets);
+            blk.controls_inout = (void*)at(io_all->controls_inout); blk.v_inout = (void*)at(io_all->v_inout);
+            blk.u0 = (void*)at(io_all->u0);
+            blk.iters = io_all->iters ? io_all->iters + first : nullptr;
+            rc = general_launch(h, p, &blk, s);
+            if (rc) return rc;
+        }
+        if (world > 1 || h->comm) {
+            Rccl* r = rccl();
+            if (!r) return fail(h, TPC_MPC_ERR_COMM, "RCCL is not available in this process: %s", g_rccl.why);
+            const ncclDataType_t dt = p->dtype == TPC_MPC_F64 ? ncclFloat64 : ncclFloat32;
+            ncclComm_t c = h->comm->comm;
+            GroupScope group(r);
+            RCCL_TRY(h, r, group.begin());
+            // u0 is I rows of ld: each row's slots are exchanged in place like the compact form's two outputs
+            for (int j = 0; j < I; ++j) {
+                char* row = (char*)io_all->u0 + (int64_t)j * ld * es;
+                if (n_total % world == 0 && !h->comm_test_ragged) {
+                    RCCL_TRY(h, r, r->AllGather(row + first * es, row, (size_t)count, dt, c, s));
+                } else {
+                    for (int q = 0; q < world; ++q) {
+                        int64_t qf = 0, qc = 0;
+                        shard_range(n_total, q, world, &qf, &qc);
+                        if (qc == 0) continue;
+                        RCCL_TRY(h, r, r->Broadcast(row + qf * es, row + qf * es, (size_t)qc, dt, q, c, s));
+                    }
+                }
+            }
+            RCCL_TRY(h, r, group.end());
+        }
+        rc = order.end();
+        if (rc) return rc;
+        return finish_flags(h, flags_out, s);
+    });
+}
+
 }  // extern "C"

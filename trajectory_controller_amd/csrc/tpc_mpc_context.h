@@ -157,6 +157,8 @@ struct StreamOrderScope {
 };
 // n instances of the compact form, arrays in DEVICE memory, launches only (no flag reset, no
 // stream-order bookkeeping, no synchronisation): the core of every compact entry point.
+int general_launch(tpc_mpc_context* h, const tpc_mpc_params* p, const tpc_mpc_general_io* io, hipStream_t s);
+int check_general_device_io(tpc_mpc_context* h, const tpc_mpc_general_io* io);
 int compact_launch(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy,
                    const void* dphi, void* front, void* rear, int32_t* iters, hipStream_t s);
 // scratch of the LANE family for (H, dtype, n), without launching (grows the handle's workspace)

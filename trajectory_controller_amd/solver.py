@@ -271,6 +271,35 @@ class MpcSolver:
         self.last_flags = flags.value
         return (front, rear, iters) if want_iters else (front, rear)
 
+    def solve_batch_general_sharded(self, A, B, Cc, Q, R, lower, upper, x0, targets, inputs: Optional[int] = None,
+                                    want_iters: bool = False, **over):
+        """The general form sharded (tpc_mpc_solve_batch_general_sharded): FULL-size component-major CUDA tensors
+        [rows, n_total] on every rank (only this rank's block of columns has to be filled); solves that block in
+        place and all-gathers the rows of u0 over RCCL.  Returns the full u0[I, n_total] (and this rank's iters)."""
+        import torch
+        p = self._params(**over)
+        H = p.horizon
+        tdt = torch.float64 if p.dtype == capi.F64 else torch.float32
+        n = A.shape[-1]
+        I = inputs or R.shape[0]
+
+        def ptr(t, rows):
+            if not (t.is_cuda and t.dtype == tdt and t.is_contiguous() and tuple(t.shape) == (rows, n)):
+                raise ValueError(f"expected contiguous CUDA tensor [{rows},{n}] of the solver dtype")
+            return t.data_ptr()
+        u0 = torch.empty((I, n), dtype=tdt, device=A.device)
+        iters = torch.zeros(n, dtype=torch.int32, device=A.device) if want_iters else None
+        io = capi.GeneralIO(inputs=I, n=n, ld=n, A=ptr(A, 4), B=ptr(B, 2 * I), C=ptr(Cc, 2), Q=ptr(Q, 2),
+                            R=ptr(R, I), lower=ptr(lower, I), upper=ptr(upper, I), x0=ptr(x0, 2),
+                            targets=ptr(targets, 2 * H), controls_inout=None, v_inout=None, u0=u0.data_ptr(),
+                            iters=iters.data_ptr() if want_iters else None)
+        flags = C.c_uint32(0)
+        stream = torch.cuda.current_stream(A.device).cuda_stream
+        self._check(self._lib.tpc_mpc_solve_batch_general_sharded(self._h, C.byref(p), C.byref(io), C.byref(flags),
+                                                                  C.c_void_p(stream)))
+        self.last_flags = flags.value
+        return (u0, iters) if want_iters else u0
+
     def solve_batch_general(self, A, B, Cc, Q, R, lower, upper, x0, targets, controls=None,
                             v_state=None, inputs: Optional[int] = None, want_iters: bool = False,
                             **over):

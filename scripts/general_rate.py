@@ -17,4 +17,4 @@ with MpcSolver(horizon=H, algo=algo) as s:
     for _ in range(reps):
         u0, it = s.solve_batch_general(*dev, inputs=I, want_iters=True)
         k1, k2, _ = s.last_kernel_times()
-print(f"general I={I} H={H} n={n} {algo}: {k1 + k2:8.3f} ms  {n / (k1 + k2) / 1e3:8.3f} M solves/s  mean iters {float(it.double().mean()):.0f}")
+print(f"general I={I} H={H} n={n} {algo}: {k1 + k2:8.3f} ms (cd {k1:.3f} pg {k2:.3f})  {n / (k1 + k2) / 1e3:8.3f} M solves/s  mean iters {float(it.double().mean()):.0f}")

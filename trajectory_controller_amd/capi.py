@@ -84,6 +84,15 @@ def load_library(path: str | None = None) -> C.CDLL:
         raise FileNotFoundError(
             f"{path} not found: build the HIP library first "
             f"(python -c 'import __graft_entry__ as g; g.build()' or make -C trajectory_controller_amd/csrc)")
+    # One HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64 / libhsa-runtime64; libtpc_mpc.so names
+    # them by SONAME only, so it binds to whichever copy is already loaded.  Loaded FIRST it pulls in /opt/rocm's, torch
+    # then brings its own, and the second runtime to initialise finds no device ("no ROCm-capable device is detected";
+    # measured: scripts/probes/import_order.py).  A Python process that has torch gets torch's runtime loaded first here,
+    # whatever the import order of the caller; a process without torch (a C host) has only /opt/rocm's anyway.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     vp, i32p, u32p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
     lib.tpc_mpc_abi_version.restype = C.c_int

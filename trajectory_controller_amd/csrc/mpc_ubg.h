@@ -57,7 +57,11 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value > 2 ? 2 : CdOcc<T, H>::valu
 
     // u: a copy in LDS always (the winner is read and written there by index); in registers too, except where they are
     // short (fp64, N = 20: the passes read the LDS copy)
+#ifdef TPC_UBG_CD_XLDS
+    constexpr bool XL = TPC_UBG_CD_XLDS != 0;
+#else
     constexpr bool XL = sizeof(T) == 8 && H >= 20;
+#endif
     T u[XL ? 2 : 2 * H], w[2 * H];
     auto U = [&](int q) -> T { if constexpr (XL) return s_u[q][lane]; else return u[q]; };
     // the I controls of a step as the model's pointer argument

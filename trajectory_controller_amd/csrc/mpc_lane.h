@@ -174,45 +174,104 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args 
     uint32_t iter = 0;
     bool stopped = (Model::kScreen && nonfinite) || badmodel;   // see CompactModel::kScreen, GeneralModel::invalid
     bool vinit = false;
-#pragma unroll 1
-    for (uint32_t it = 0; it < cd_iters; ++it) {
-        if (__ballot(!stopped) == 0ull) break;
+    // Two builds of the arg-max scan (the arithmetic of the gradient and of the step is dlib's in both, so both are
+    // bit-exact; only how the SAME decisions are reached differs -- see ub_cd_kernel, mpc_ub.h):
+    //   exact   dlib's mask by compare and select (mpc.h:298-299), running maximum, its index, sign and u;
+    //   fast    where every lane of the wavefront passed the screen of the select-free stop test and starts inside
+    //           its box (a cold start; a caller's warm start may lie outside): the mask as arithmetic on the gaps
+    //           (u - lower) 2^600 and (upper - u) 2^600, which are 0 exactly on the bound and beyond every |df| off it,
+    //           and ONE signed value for the running arg-max; the winner's u by index from an LDS copy where it fits.
+    // (a third LDS array beside s_qd and s_mm must not cost residency: 4 * CdOcc wavefronts per CU share 160 KB.  With
+    // this family's two arrays it never fits -- fp64 N = 20: 3 x 20 KB x 4 -- so the winner's u is tracked by select;
+    // measured with the copy at N = 20: 1.0 ms against 0.68, half the SIMDs idle)
+    constexpr bool kMirror = 3 * (2 * H * kWave * (int)sizeof(T)) * 4 * CdOcc<T, H>::value <= 160 * 1024;
+    __shared__ T s_u[kMirror ? 2 * H : 1][kWave];
+    if constexpr (kMirror) {
+#pragma unroll
+        for (int q = 0; q < 2 * H; ++q) s_u[q][lane] = u[q];
+    }
+    constexpr T kHuge = (T)(sizeof(T) == 8 ? 0x1p600 : 0x1p100);
+    T huge = kHuge;
+    asm volatile("" : "+v"(huge));
+    T lo_h[I], hi_h[I];
+#pragma unroll
+    for (int j = 0; j < I; ++j) { lo_h[j] = -(m.lo(j) * huge); hi_h[j] = m.hi(j) * huge; }
+
+    auto iteration = [&](auto fast_tag, uint32_t it) {
+        constexpr bool F = decltype(fast_tag)::value;
         gradient<T, I, H>(m, u, [&](int q) { return s_mm[q][lane]; }, w);
         // arg-max |df| over free variables, scanning i then j, strict '>' (mpc.h:289-309)
-        T max_df = (T)0, best_u = (T)0;
+        T max_df = (T)0, best_u = (T)0, best_mm = (T)0;
         int best = 0, best_sign = 0;
 #pragma unroll
         for (int i = 0; i < H; ++i)
 #pragma unroll
             for (int j = 0; j < I; ++j) {
-                // select form of `if (!blocked && |df| > max_df)`: a variable at its lower bound may
-                // only contribute a negative df, one at its upper bound a positive one; the gated
-                // magnitude is |df| or 0, NaN stays NaN and loses every `>` like in dlib.  (As an
-                // `if` the compiler built a branch per variable: 1430 instructions per iteration.)
-                const T uu = u[2 * i + j], dd = w[2 * i + j];
-                const T up = (uu <= m.lo(j)) ? (T)0 : dd;
-                const T dn = (uu >= m.hi(j)) ? (T)0 : -dd;
-                const T mag = tmax(up, dn);
-                const bool better = mag > max_df;
-                max_df = tmax(max_df, mag);               // == better ? mag : max_df, NaN included
-                best = better ? 2 * i + j : best;
-                best_sign = better ? sign_word(dd) : best_sign;   // df[best] = +-max_df: only its sign is kept
-                best_u = better ? uu : best_u;
+                const int q = 2 * i + j;
+                const T uu = u[q], dd = w[q];
+                if constexpr (F) {
+                    const T g_lo = tfma(uu, huge, lo_h[j]), g_hi = tfma(-huge, uu, hi_h[j]);
+                    const T mm = tmax(tmin(dd, g_lo), -g_hi);           // df where dlib counts it, else 0
+                    const bool better = tabs(mm) > tabs(best_mm);
+                    best_mm = better ? mm : best_mm;
+                    best = better ? q : best;
+                    if constexpr (!kMirror) best_u = better ? uu : best_u;
+                } else {
+                    // select form of `if (!blocked && |df| > max_df)`: a variable at its lower bound may
+                    // only contribute a negative df, one at its upper bound a positive one; the gated
+                    // magnitude is |df| or 0, NaN stays NaN and loses every `>` like in dlib.  (As an
+                    // `if` the compiler built a branch per variable: 1430 instructions per iteration.)
+                    const T up = (uu <= m.lo(j)) ? (T)0 : dd;
+                    const T dn = (uu >= m.hi(j)) ? (T)0 : -dd;
+                    const T mag = tmax(up, dn);
+                    const bool better = mag > max_df;
+                    max_df = tmax(max_df, mag);               // == better ? mag : max_df, NaN included
+                    best = better ? q : best;
+                    best_sign = better ? sign_word(dd) : best_sign;   // df[best] = +-max_df: only its sign is kept
+                    best_u = better ? uu : best_u;
+                }
             }
-        if (!stopped && max_df < eps) stopped = true;           // mpc.h:310-311
-        if (!stopped) {
-            const T best_df = with_sign(max_df, best_sign);
-            const T qdv = s_qd[best][lane];
-            if (qdv != (T)0) {                                  // mpc.h:322 (`continue` still counts)
-                const int bj = best & 1;
-                T nu = -(best_df - qdv * best_u) / qdv;         // mpc.h:325
-                nu = put_in_range(m.lo(bj), m.hi(bj), nu);      // mpc.h:326
+        if constexpr (F) max_df = tabs(best_mm);
+        // (select form, no divergent block: a conditional update of the register array costs a copy of all of it)
+        stopped = stopped || max_df < eps;                      // mpc.h:310-311
+        const bool act = !stopped;
+        T best_df;
+        if constexpr (F) best_df = best_mm; else best_df = with_sign(max_df, best_sign);
+        if constexpr (F && kMirror) best_u = s_u[best][lane];
+        const T qdv = s_qd[best][lane];
+        const bool upd = act && qdv != (T)0;                    // mpc.h:322 (`continue` still counts)
+        // (bounds picked by select: a run-time index would put the model in scratch)
+        const bool second = I == 2 && (best & 1);
+        const T blo = second ? m.lo(I - 1) : m.lo(0), bhi = second ? m.hi(I - 1) : m.hi(0);
+        T nu = -(best_df - qdv * best_u) / (upd ? qdv : (T)1);  // mpc.h:325
+        nu = put_in_range(blo, bhi, nu);                        // mpc.h:326
+        if constexpr (kMirror) { if (upd) s_u[best][lane] = nu; }
+        const int sel = upd ? best : -1;
 #pragma unroll
-                for (int q = 0; q < 2 * H; ++q)
-                    if ((q & 1) < I) u[q] = (q == best) ? nu : u[q];
-                vinit = (it + 1 == kn.smo_iters);               // mpc.h:330-334
-            }
-            ++iter;
+        for (int q = 0; q < 2 * H; ++q)
+            if ((q & 1) < I) u[q] = (q == sel) ? nu : u[q];
+        vinit = upd ? (it + 1 == kn.smo_iters) : vinit;         // mpc.h:330-334
+        iter += act ? 1u : 0u;
+    };
+    bool fast_cd = false;
+    if constexpr (Model::kFastStop) {
+        bool inside = true;
+#pragma unroll
+        for (int q = 0; q < 2 * H; ++q)
+            if ((q & 1) < I) inside = inside && u[q] >= m.lo(q & 1) && u[q] <= m.hi(q & 1);
+        fast_cd = __ballot(!(m.fast_stop_ok(mm_max, eps, lambda, H) && inside)) == 0ull;
+    }
+    if (fast_cd) {
+#pragma unroll 1
+        for (uint32_t it = 0; it < cd_iters; ++it) {
+            if (__ballot(!stopped) == 0ull) break;
+            iteration(std::true_type{}, it);
+        }
+    } else {
+#pragma unroll 1
+        for (uint32_t it = 0; it < cd_iters; ++it) {
+            if (__ballot(!stopped) == 0ull) break;
+            iteration(std::false_type{}, it);
         }
     }
 

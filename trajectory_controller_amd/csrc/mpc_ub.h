@@ -45,8 +45,10 @@ template <typename T, bool EQB> TPC_DEV void ub_set_uniform(ub::Unit<T, EQB>& m,
 // the passes read x from LDS too and no register copy exists -- the 120-instruction select chain that wrote one
 // element of a register array, and ~240 AGPR moves per iteration, are gone.
 template <typename T, int H> struct UbCdPlan {
-    // x[2H][64] beside s_iqd[2H][64] within a workgroup's 64 KB of static LDS
-    static constexpr bool mirror = 2 * (2 * H * kWave * (int)sizeof(T)) <= 64 * 1024;
+    // x[2H][64] beside s_iqd[2H][64]: within a workgroup's 64 KB of static LDS, and without costing residency (the
+    // 4 x CdOcc wavefronts of a CU share 160 KB: fp64 N = 30 would keep two of four SIMDs idle)
+    static constexpr bool mirror = 2 * (2 * H * kWave * (int)sizeof(T)) <= 64 * 1024 &&
+                                   2 * (2 * H * kWave * (int)sizeof(T)) * 4 * CdOcc<T, H>::value <= 160 * 1024;
 #ifdef TPC_UB_CD_XLDS
     static constexpr bool x_in_lds = mirror && TPC_UB_CD_XLDS != 0;
 #else

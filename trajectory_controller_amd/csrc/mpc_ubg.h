@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value > 2 ? 2 : CdOcc<T, H>::valu
     constexpr int RL = LaneRec<T, H>::kLen;
     __shared__ T s_rqd[2 * H][kWave];
     __shared__ T s_mm[2 * H][kWave];
-    __shared__ T s_u[2 * H][kWave];
+    __shared__ T s_u[(3 * (2 * H * kWave * (int)sizeof(T)) * 4 * (CdOcc<T, H>::value > 2 ? 2 : CdOcc<T, H>::value) <= 160 * 1024) ? 2 * H : 1][kWave];
     const int lane = threadIdx.x;
     const int64_t k = (int64_t)blockIdx.x * kWave + lane;
     if (k >= g.n) return;
@@ -57,24 +57,29 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value > 2 ? 2 : CdOcc<T, H>::valu
 
     // u: a copy in LDS always (the winner is read and written there by index); in registers too, except where they are
     // short (fp64, N = 20: the passes read the LDS copy)
+    // A third LDS array must not cost residency (4 x waves-per-SIMD wavefronts of a CU share 160 KB): at fp64 N = 20 three
+    // arrays of 20 KB leave two wavefronts per CU -- half the SIMDs idle, 0.84 ms against 0.72 -- so there the copy is
+    // dropped and the winner's u is tracked by select, its update written by a select chain.
+    constexpr int kCdWaves = CdOcc<T, H>::value > 2 ? 2 : CdOcc<T, H>::value;
+    constexpr bool MIRROR = 3 * (2 * H * kWave * (int)sizeof(T)) * 4 * kCdWaves <= 160 * 1024;
 #ifdef TPC_UBG_CD_XLDS
-    constexpr bool XL = TPC_UBG_CD_XLDS != 0;
+    constexpr bool XL = MIRROR && TPC_UBG_CD_XLDS != 0;
 #else
-    constexpr bool XL = sizeof(T) == 8 && H >= 20;
+    constexpr bool XL = MIRROR && sizeof(T) == 8 && H >= 20;
 #endif
     T u[XL ? 2 : 2 * H], w[2 * H];
-    auto U = [&](int q) -> T { if constexpr (XL) return s_u[q][lane]; else return u[q]; };
+    auto U = [&](int q) -> T { if constexpr (XL) return s_u[XL ? q : 0][lane]; else return u[q]; };
     // the I controls of a step as the model's pointer argument
     T tmp_u[2] = {(T)0, (T)0};
     auto UP = [&](int q) -> const T* {
-        if constexpr (XL) { tmp_u[0] = s_u[q][lane]; if (I == 2) tmp_u[1] = s_u[q + 1][lane]; return tmp_u; }
+        if constexpr (XL) { tmp_u[0] = s_u[XL ? q : 0][lane]; if (I == 2) tmp_u[1] = s_u[XL ? q + 1 : 0][lane]; return tmp_u; }
         else return &u[q];
     };
     auto UP2 = [&](int q, T* out) { out[0] = U(q); out[1] = I == 2 ? U(q + 1) : (T)0; };
 #pragma unroll
     for (int q = 0; q < 2 * H; ++q) {
         if constexpr (!XL) u[q] = (T)0;
-        s_u[q][lane] = (T)0;
+        if constexpr (MIRROR) s_u[q][lane] = (T)0;
     }
     const T lambda = ubg::ctor_lambda_qdiag<T, I, H>(m, [&](int i, int j, T val) {
         s_rqd[2 * i + j][lane] = val != (T)0 ? (T)1 / val : (T)0;   // mpc.h:322: a zero Q_diag never updates
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value > 2 ? 2 : CdOcc<T, H>::valu
         T n0, n1;
         m.bwd_last(n0, n1, m0, m1);
         // arg-max fused into the backward sweep: descending with '>=' picks what dlib's ascending strict '>' picks
-        T max_df = (T)0, best_mm = (T)0;
+        T max_df = (T)0, best_mm = (T)0, best_u = (T)0;
         int best = 0, best_sign = 0;
 #pragma unroll
         for (int i = H - 1; i >= 0; --i) {
@@ -134,6 +139,7 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value > 2 ? 2 : CdOcc<T, H>::valu
                     const bool better = tabs(mm) >= tabs(best_mm);   // (zeros may pass one another: all of them mean 'none')
                     best_mm = better ? mm : best_mm;
                     best = better ? q : best;
+                    if constexpr (!MIRROR) best_u = better ? uu : best_u;
                 } else {
                     const T up = (uu <= m.lo[j]) ? (T)0 : dd;
                     const T dn = (uu >= m.hi[j]) ? (T)0 : -dd;
@@ -142,6 +148,7 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value > 2 ? 2 : CdOcc<T, H>::valu
                     max_df = tmax(max_df, mag);
                     best = better ? q : best;
                     best_sign = better ? sign_word(dd) : best_sign;
+                    if constexpr (!MIRROR) best_u = better ? uu : best_u;
                 }
             }
         }
@@ -150,14 +157,14 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value > 2 ? 2 : CdOcc<T, H>::valu
         const bool act = !stopped;
         T best_df;
         if constexpr (F) best_df = best_mm; else best_df = with_sign(max_df, best_sign);
-        const T best_u = s_u[best][lane];
+        if constexpr (MIRROR) best_u = s_u[MIRROR ? best : 0][lane];
         const T rq = s_rqd[best][lane];
         const bool upd = act && rq != (T)0;                     // mpc.h:322 (`continue` still counts)
         // (bounds picked by select: a run-time index would put the model in scratch)
         const bool second = I == 2 && (best & 1);
         const T blo = second ? m.lo[I - 1] : m.lo[0], bhi = second ? m.hi[I - 1] : m.hi[0];
         const T nu = tmax(tmin(ub::fma_(-rq, best_df, best_u), bhi), blo);   // mpc.h:325-326
-        if (upd) s_u[best][lane] = nu;
+        if constexpr (MIRROR) { if (upd) s_u[MIRROR ? best : 0][lane] = nu; }
         if constexpr (!XL) {
             const int sel = upd ? best : -1;
 #pragma unroll

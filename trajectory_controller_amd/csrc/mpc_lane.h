@@ -180,16 +180,9 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args 
     //   fast    where every lane of the wavefront passed the screen of the select-free stop test and starts inside
     //           its box (a cold start; a caller's warm start may lie outside): the mask as arithmetic on the gaps
     //           (u - lower) 2^600 and (upper - u) 2^600, which are 0 exactly on the bound and beyond every |df| off it,
-    //           and ONE signed value for the running arg-max; the winner's u by index from an LDS copy where it fits.
-    // (a third LDS array beside s_qd and s_mm must not cost residency: 4 * CdOcc wavefronts per CU share 160 KB.  With
-    // this family's two arrays it never fits -- fp64 N = 20: 3 x 20 KB x 4 -- so the winner's u is tracked by select;
-    // measured with the copy at N = 20: 1.0 ms against 0.68, half the SIMDs idle)
-    constexpr bool kMirror = 3 * (2 * H * kWave * (int)sizeof(T)) * 4 * CdOcc<T, H>::value <= 160 * 1024;
-    __shared__ T s_u[kMirror ? 2 * H : 1][kWave];
-    if constexpr (kMirror) {
-#pragma unroll
-        for (int q = 0; q < 2 * H; ++q) s_u[q][lane] = u[q];
-    }
+    //           and ONE signed value for the running arg-max.
+    // (the winner's u is tracked by select: an LDS copy of u read by index -- ub_cd_kernel's way -- would be a third
+    // array beside s_qd and s_mm and cost residency at every horizon: measured at N = 20, 1.0 ms against 0.68)
     constexpr T kHuge = (T)(sizeof(T) == 8 ? 0x1p600 : 0x1p100);
     T huge = kHuge;
     asm volatile("" : "+v"(huge));
@@ -215,7 +208,7 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args 
                     const bool better = tabs(mm) > tabs(best_mm);
                     best_mm = better ? mm : best_mm;
                     best = better ? q : best;
-                    if constexpr (!kMirror) best_u = better ? uu : best_u;
+                    best_u = better ? uu : best_u;
                 } else {
                     // select form of `if (!blocked && |df| > max_df)`: a variable at its lower bound may
                     // only contribute a negative df, one at its upper bound a positive one; the gated
@@ -237,7 +230,6 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args 
         const bool act = !stopped;
         T best_df;
         if constexpr (F) best_df = best_mm; else best_df = with_sign(max_df, best_sign);
-        if constexpr (F && kMirror) best_u = s_u[best][lane];
         const T qdv = s_qd[best][lane];
         const bool upd = act && qdv != (T)0;                    // mpc.h:322 (`continue` still counts)
         // (bounds picked by select: a run-time index would put the model in scratch)
@@ -245,7 +237,6 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args 
         const T blo = second ? m.lo(I - 1) : m.lo(0), bhi = second ? m.hi(I - 1) : m.hi(0);
         T nu = -(best_df - qdv * best_u) / (upd ? qdv : (T)1);  // mpc.h:325
         nu = put_in_range(blo, bhi, nu);                        // mpc.h:326
-        if constexpr (kMirror) { if (upd) s_u[best][lane] = nu; }
         const int sel = upd ? best : -1;
 #pragma unroll
         for (int q = 0; q < 2 * H; ++q)

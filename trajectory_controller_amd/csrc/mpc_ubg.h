@@ -55,30 +55,16 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value > 2 ? 2 : CdOcc<T, H>::valu
     const bool badmodel = m.invalid();
     const T* tg = (const T*)g.targets + k;
 
-    // u: a copy in LDS always (the winner is read and written there by index); in registers too, except where they are
-    // short (fp64, N = 20: the passes read the LDS copy)
+    // u in registers; where it costs no residency, a copy in LDS too (the winner is read and written there by index)
     // A third LDS array must not cost residency (4 x waves-per-SIMD wavefronts of a CU share 160 KB): at fp64 N = 20 three
     // arrays of 20 KB leave two wavefronts per CU -- half the SIMDs idle, 0.84 ms against 0.72 -- so there the copy is
     // dropped and the winner's u is tracked by select, its update written by a select chain.
     constexpr int kCdWaves = CdOcc<T, H>::value > 2 ? 2 : CdOcc<T, H>::value;
     constexpr bool MIRROR = 3 * (2 * H * kWave * (int)sizeof(T)) * 4 * kCdWaves <= 160 * 1024;
-#ifdef TPC_UBG_CD_XLDS
-    constexpr bool XL = MIRROR && TPC_UBG_CD_XLDS != 0;
-#else
-    constexpr bool XL = MIRROR && sizeof(T) == 8 && H >= 20;
-#endif
-    T u[XL ? 2 : 2 * H], w[2 * H];
-    auto U = [&](int q) -> T { if constexpr (XL) return s_u[XL ? q : 0][lane]; else return u[q]; };
-    // the I controls of a step as the model's pointer argument
-    T tmp_u[2] = {(T)0, (T)0};
-    auto UP = [&](int q) -> const T* {
-        if constexpr (XL) { tmp_u[0] = s_u[XL ? q : 0][lane]; if (I == 2) tmp_u[1] = s_u[XL ? q + 1 : 0][lane]; return tmp_u; }
-        else return &u[q];
-    };
-    auto UP2 = [&](int q, T* out) { out[0] = U(q); out[1] = I == 2 ? U(q + 1) : (T)0; };
+    T u[2 * H], w[2 * H];
 #pragma unroll
     for (int q = 0; q < 2 * H; ++q) {
-        if constexpr (!XL) u[q] = (T)0;
+        u[q] = (T)0;
         if constexpr (MIRROR) s_u[q][lane] = (T)0;
     }
     const T lambda = ubg::ctor_lambda_qdiag<T, I, H>(m, [&](int i, int j, T val) {
@@ -111,11 +97,11 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value > 2 ? 2 : CdOcc<T, H>::valu
     auto iteration = [&](auto fast_tag, uint32_t it) {
         constexpr bool F = decltype(fast_tag)::value;
         T m0, m1;
-        m.first(m0, m1, UP(0));
+        m.first(m0, m1, &u[0]);
         w[0] = m0; w[1] = m1;
 #pragma unroll
         for (int i = 1; i < H; ++i) {
-            m.fwd(m0, m1, UP(2 * i));
+            m.fwd(m0, m1, &u[2 * i]);
             w[2 * i] = m0; w[2 * i + 1] = m1;
         }
         T n0, n1;
@@ -126,8 +112,7 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value > 2 ? 2 : CdOcc<T, H>::valu
 #pragma unroll
         for (int i = H - 1; i >= 0; --i) {
             if (i < H - 1) m.bwd(n0, n1, w[2 * i], w[2 * i + 1]);
-            T ui[2];
-            UP2(2 * i, ui);
+            const T ui[2] = {u[2 * i], u[2 * i + 1]};
 #pragma unroll
             for (int j = I - 1; j >= 0; --j) {
                 const int q = 2 * i + j;
@@ -165,12 +150,10 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value > 2 ? 2 : CdOcc<T, H>::valu
         const T blo = second ? m.lo[I - 1] : m.lo[0], bhi = second ? m.hi[I - 1] : m.hi[0];
         const T nu = tmax(tmin(ub::fma_(-rq, best_df, best_u), bhi), blo);   // mpc.h:325-326
         if constexpr (MIRROR) { if (upd) s_u[MIRROR ? best : 0][lane] = nu; }
-        if constexpr (!XL) {
-            const int sel = upd ? best : -1;
+        const int sel = upd ? best : -1;
 #pragma unroll
-            for (int q = 0; q < 2 * H; ++q)
-                if ((q & 1) < I) u[q] = (q == sel) ? nu : u[q];
-        }
+        for (int q = 0; q < 2 * H; ++q)
+            if ((q & 1) < I) u[q] = (q == sel) ? nu : u[q];
         vinit = upd ? (it + 1 == kn.smo_iters) : vinit;         // mpc.h:330-334
         iter += act ? 1u : 0u;
     };
@@ -190,7 +173,7 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value > 2 ? 2 : CdOcc<T, H>::valu
 
     T* rec = recs + (int64_t)k * RL;
 #pragma unroll
-    for (int q = 0; q < 2 * H; ++q) rec[q] = ((q & 1) < I) ? U(q) : (T)0;
+    for (int q = 0; q < 2 * H; ++q) rec[q] = ((q & 1) < I) ? u[q] : (T)0;
     rec[2 * H] = lambda;
     uint64_t meta = (uint64_t)iter;
     if (stopped) meta |= kMetaStopped;
@@ -213,7 +196,7 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value > 2 ? 2 : CdOcc<T, H>::valu
     uint32_t f = 0;
     if (finished) {
 #pragma unroll
-        for (int j = 0; j < I; ++j) ((T*)g.u0)[(int64_t)j * g.ld + k] = U(j);
+        for (int j = 0; j < I; ++j) ((T*)g.u0)[(int64_t)j * g.ld + k] = u[j];
         if (g.iters) g.iters[k] = (int32_t)iter;
         if (nonfinite) f |= 0x1u;
         if (badmodel) f |= 0x4u;

@@ -353,3 +353,27 @@ def test_ubg_flags_phase_boundaries_and_state_requests(torch_cuda, model, oracle
         torch.cuda.synchronize()
         assert s.last_kernel_times()[2] == 2            # LANE
     assert bits_equal(u0.cpu().numpy().T, ou0) and np.array_equal(it.cpu().numpy(), oit)
+
+
+@pytest.mark.parametrize("I", [1, 2])
+def test_ubg_full_batch_vs_bit_exact_family(torch_cuda, I):
+    """The general form at the BASELINE batch size (262 144 x N = 20, fp64): LANE_FMA against the bit-exact LANE family
+    on every instance -- identical iteration counts, |du| <= 1e-9, bound-sitting controls bit for bit -- AUTO takes
+    this family, and a second run returns the same bits whatever lane solved what."""
+    from trajectory_controller_amd.synth import general_inputs
+    torch = torch_cuda
+    H, n = 20, 262144
+    g = general_inputs(H, n, I=I)
+    dev = [torch.from_numpy(_soa(g[k])).to("cuda:0") for k in GNAMES]
+    with _solver(H, "lane") as s:
+        lu0, lit = s.solve_batch_general(*dev, inputs=I, want_iters=True)
+    with _solver(H, "auto") as s:
+        s.set_profiling(True)
+        u0, it = s.solve_batch_general(*dev, inputs=I, want_iters=True)
+        assert s.last_kernel_times()[2] == LANE_FMA
+        u1, it1 = s.solve_batch_general(*dev, inputs=I, want_iters=True)
+    assert torch.equal(it, lit)
+    assert float((u0 - lu0).abs().max()) <= UB_ATOL
+    lo, hi = dev[5], dev[6]
+    assert torch.equal((lu0 == lo) | (lu0 == hi), (u0 == lo) | (u0 == hi))
+    assert torch.equal(u0, u1) and torch.equal(it, it1)

@@ -317,7 +317,8 @@ int tpc_mpc_solve_batch_compact_sharded(tpc_mpc_handle h, const tpc_mpc_params* 
                                         void* steering_rear_all, int32_t* iters_shard,
                                         uint32_t* flags_out, void* stream);
 
-/* The general form sharded the same way: io_all describes the FULL batch (n = n_total, ld >= n_total, DEVICE memory;
+/* No reference counterpart (the reference drives one dlib::mpc object on one device: src/trajectory_point_follower.cpp:366).
+ * The general form sharded the same way: io_all describes the FULL batch (n = n_total, ld >= n_total, DEVICE memory;
  * every rank passes the same shapes).  The rank solves columns [first, first + count) of those arrays in place -- only
  * that block of the inputs has to be filled on this rank -- and the I rows of u0 are exchanged in place as above, so on
  * return every GPU holds all of u0.  controls_inout / v_inout / iters, when given, are read and written for this

@@ -358,7 +358,7 @@ def main():
                     "serial_kernels_frac": tfl_serial / peak_tf,
                     "flops_per_solve": (46 * H - 16) * mean_iters},
         }
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:   # (the CPU baseline and the side legs below belong to the N = 1 line only)
             cb, ns, cf, cr = cpu_baseline(H, v, dy, dphi, a.cpu_seconds)
             gf, gr = front[:ns].cpu().numpy().astype(np.float64), rear[:ns].cpu().numpy().astype(np.float64)
             out["cpu_baseline"] = cb
@@ -425,7 +425,7 @@ def main():
                                 "ms_per_step": dp / a.steps * 1e3, "outputs_identical_to_serial": same,
                                 "alu_frac": alg_flops / (dp / a.steps) / 1e12 / peak_tf}
             s2.close()
-        if not a.no_fp32 and a.dtype == "f64":
+        if world == 1 and not a.no_fp32 and a.dtype == "f64":
             s32 = MpcSolver(horizon=H, device=local_rank, dtype="f32", algo=a.algo)
             s32.set_profiling(True)
             s32.reserve(n)

@@ -487,6 +487,31 @@ def test_solve_one_resident_vs_oracle(torch_cuda, oracle, H):
         assert abs(f - e2f[1]) <= 1e-9 and abs(r - e2r[1]) <= 1e-9
 
 
+@pytest.mark.parametrize("H", [4, 10, 20])
+def test_solve_one_kept_setup(torch_cuda, oracle, H):
+    """The resident wave keeps the model-only part of its set-up (Hessian row, Q_diag, lambda, 1/lambda, beta) while a
+    request repeats the previous one's v and parameters: runs of requests with the speed held and the targets moving,
+    then a changed speed, changed weights, changed bounds and a changed eps in between -- every answer against the
+    oracle for ITS parameters."""
+    rng = np.random.default_rng(77 + H)
+    with _solver(H, "auto") as s:
+        for block in range(6):
+            v = float(rng.uniform(0.3, 3.8))
+            kw = {}
+            if block == 2: kw = dict(weight_y=35.0, weight_steering_rear=4.0)
+            if block == 3: kw = dict(lower=(-0.2, -0.3), upper=(0.25, 0.3))
+            if block == 4: kw = dict(eps=1e-3)
+            okw = {}
+            if block == 2: okw = dict(weights=(35.0, 7.0, 0.0005, 4.0))
+            if block == 3: okw = dict(lo=(-0.2, -0.3), hi=(0.25, 0.3))
+            if block == 4: okw = dict(eps=1e-3)
+            for rep in range(6):
+                dy, dphi = float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.6, 0.6))
+                of, orr, _ = oracle.solve_compact(H, [v], [dy], [dphi], **okw)
+                f, r = s.solve_one(v, dy, dphi, **kw)
+                assert abs(f - of[0]) <= 1e-9 and abs(r - orr[0]) <= 1e-9, (H, block, rep)
+
+
 @pytest.mark.parametrize("where", ["device", "host"])
 def test_solve_one_request_lines_placement(torch_cuda, oracle, where):
     """The resident wave takes its requests from device memory the CPU writes through the BAR (where the

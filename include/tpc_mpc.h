@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TPC_MPC_ABI_VERSION 3
+#define TPC_MPC_ABI_VERSION 4
 
 typedef struct tpc_mpc_context* tpc_mpc_handle;
 
@@ -91,7 +91,7 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
  *          21 504 at N = 20, 32 768 at N = 30, 40; general form at N = 40: 19 456 -- and scales with the CU count.  A host
  *          that needs dlib's bits asks for LANE. */
 typedef enum tpc_mpc_algo {
-    TPC_MPC_ALGO_AUTO = 0, TPC_MPC_ALGO_WAVE = 1, TPC_MPC_ALGO_LANE = 2, TPC_MPC_ALGO_LANE_FMA = 3
+    TPC_MPC_ALGO_AUTO = 0, TPC_MPC_ALGO_WAVE = 1, TPC_MPC_ALGO_LANE = 2, TPC_MPC_ALGO_LANE_FMA = 3, TPC_MPC_ALGO_GROUP = 4
 } tpc_mpc_algo;
 
 /* Non-fatal per-call flags, OR-ed into *flags_out (may be NULL). */
@@ -164,6 +164,15 @@ const char* tpc_mpc_build_info(void);
  * so the call costs no kernel launch and no synchronisation call. */
 int tpc_mpc_solve_one(tpc_mpc_handle h, const tpc_mpc_params* p, double v, double delta_y,
                       double delta_phi, double* steering_front, double* steering_rear);
+
+/* What the last tpc_mpc_solve_one on this handle reported beside its two outputs: the non-fatal flags the
+ * batch entries return through flags_out (TPC_MPC_FLAG_NONFINITE: a NaN / Inf speed or target, the call returned
+ * dlib's untouched start point (0, 0); TPC_MPC_FLAG_MAX_ITER: the solve was cut off by max_iter) and the
+ * iteration count.  The reference's counterpart is the NaN check and log line behind the call
+ * (src/trajectory_point_follower.cpp:101-103); dlib itself reports nothing (mpc.h:298-311).  Either pointer
+ * may be NULL.  Costs nothing: the resident wavefront stores the word with its outputs.  TPC_MPC_ERR_BAD_ARG
+ * before the first solve_one. */
+int tpc_mpc_last_flags(tpc_mpc_handle h, uint32_t* flags, int32_t* iters);
 
 /* No reference counterpart.  tpc_mpc_solve_one keeps one wavefront resident on the GPU between
  * calls (fp64, the specialised horizons, algo AUTO or WAVE; other requests take an ordinary launch).
@@ -345,7 +354,7 @@ int tpc_mpc_reserve(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n, int me
  *   TPC_MPC_OPT_MAILBOX_HOST 1 = tpc_mpc_solve_one's request lines live in pinned host memory even where the
  *                            CPU could write device memory through the BAR (0, default: device memory where
  *                            hipDeviceAttributeIsLargeBar says so).  Restarts the resident wavefront. */
-typedef enum tpc_mpc_option { TPC_MPC_OPT_WAVE_GROUP = 1, TPC_MPC_OPT_MAILBOX_HOST = 2 } tpc_mpc_option;
+typedef enum tpc_mpc_option { TPC_MPC_OPT_WAVE_GROUP = 1, TPC_MPC_OPT_MAILBOX_HOST = 2, TPC_MPC_OPT_GROUP_LANES = 3, TPC_MPC_OPT_GROUP_WAVES = 4 } tpc_mpc_option;
 int tpc_mpc_set_option(tpc_mpc_handle h, int option, int64_t value);
 
 /* ---- measurement ------------------------------------------------------------------------------ */

@@ -176,7 +176,7 @@ def test_build_info_names_the_schedulers(torch_cuda):
     from trajectory_controller_amd import MpcSolver
     info = MpcSolver.build_info()
     print(info)
-    assert "abi 3" in info and all(f"h{h}[sched=default]" in info for h in (4, 5, 10, 20, 30, 40))
+    assert "abi 4" in info and all(f"h{h}[sched=default]" in info for h in (4, 5, 10, 20, 30, 40))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -510,6 +510,68 @@ def test_solve_one_kept_setup(torch_cuda, oracle, H):
                 of, orr, _ = oracle.solve_compact(H, [v], [dy], [dphi], **okw)
                 f, r = s.solve_one(v, dy, dphi, **kw)
                 assert abs(f - of[0]) <= 1e-9 and abs(r - orr[0]) <= 1e-9, (H, block, rep)
+
+
+def _solve_one_paths(s, capi, path):
+    """Put solver `s` on one of tpc_mpc_solve_one's three paths."""
+    if path == "launch":          # resident mode off: one WAVE launch per call
+        s.set_resident(0)
+    elif path == "resident_host":  # request lines in the pinned block instead of device memory behind the BAR
+        s.set_option(capi.OPT_MAILBOX_HOST, 1)
+
+
+@pytest.mark.parametrize("path", ["resident", "resident_host", "launch", "lane"])
+@pytest.mark.parametrize("H", [4, 20])
+def test_solve_one_edge_cases_and_flags(torch_cuda, oracle, H, path):
+    """Every row of the real-dlib edge fixture (NaN v / delta_y / delta_phi, zero target, saturating targets, v = 1e-3
+    and 50) through the call that replaces mpcControllerTobi, on each of its paths -- the resident wavefront (request
+    lines behind the BAR or in the pinned block), one WAVE launch per call, one LANE launch per call: dlib's outputs
+    (a NaN input returns the untouched start point, mpc.h:298-311), the non-fatal flags and the iteration count
+    through tpc_mpc_last_flags, and no call anywhere near the resident path's 2 s give-up."""
+    from trajectory_controller_amd import FLAG_MAX_ITER, FLAG_NONFINITE, capi
+    g = load_golden("compact_edge.npz")
+    _, _, oit = oracle.solve_compact(H, g["v"], g["dy"], g["dphi"])
+    algo = "lane" if path == "lane" else "auto"
+    with _solver(H, algo) as s:
+        _solve_one_paths(s, capi, path)
+        s.solve_one(1.0, 0.1, 0.05)   # (start-up of the resident wave is not what is timed below)
+        for rep in range(2):
+            for k in range(len(g["v"])):
+                t0 = time.perf_counter()
+                f, r = s.solve_one(g["v"][k], g["dy"][k], g["dphi"][k])
+                dt = time.perf_counter() - t0
+                flags, it = s.last_solve_one_flags()
+                ef, er = g[f"front_H{H}"][k], g[f"rear_H{H}"][k]
+                if path == "lane":
+                    assert bits_equal([f, r], [ef, er]), (k, f, r)
+                else:
+                    assert abs(f - ef) <= 1e-9 and abs(r - er) <= 1e-9, (k, f, r)
+                nan_in = bool(np.isnan(g["v"][k]) or np.isnan(g["dy"][k]) or np.isnan(g["dphi"][k]))
+                # (the v = 50 row ends on the iteration cap in dlib too: that is what the second flag says)
+                assert flags == (FLAG_NONFINITE if nan_in else (FLAG_MAX_ITER if oit[k] == 10000 else 0)), (k, flags)
+                assert it == oit[k], (k, it, oit[k])
+                if nan_in:
+                    assert f == 0 and r == 0 and it == 0
+                assert dt < 0.5, (k, dt)
+        # infinities are non-finite inputs too; a finite request right behind them is answered as usual
+        for v, dy, dphi in ((np.inf, 0.1, 0.1), (1.0, -np.inf, 0.1), (1.0, 0.1, np.inf), (-np.inf, np.nan, 0.0)):
+            f, r = s.solve_one(v, dy, dphi)
+            assert f == 0 and r == 0 and s.last_solve_one_flags() == (FLAG_NONFINITE, 0)
+        # a solve cut off by max_iter says so, and returns the iterate dlib returns
+        of, orr, oit2 = oracle.solve_compact(H, [2.0], [-0.2], [0.1], max_iter=30)
+        f, r = s.solve_one(2.0, -0.2, 0.1, max_iter=30)
+        assert s.last_solve_one_flags() == (FLAG_MAX_ITER, 30) and oit2[0] == 30
+        assert abs(f - of[0]) <= 1e-9 and abs(r - orr[0]) <= 1e-9
+        f, r = s.solve_one(1.0, 0.1, 0.05)
+        of, orr, oit3 = oracle.solve_compact(H, [1.0], [0.1], [0.05])
+        assert abs(f - of[0]) <= 1e-9 and abs(r - orr[0]) <= 1e-9 and s.last_solve_one_flags() == (0, int(oit3[0]))
+
+
+def test_last_flags_before_any_solve_one(torch_cuda):
+    from trajectory_controller_amd import TpcMpcError
+    with _solver(4, "auto") as s:
+        with pytest.raises(TpcMpcError):
+            s.last_solve_one_flags()
 
 
 @pytest.mark.parametrize("where", ["device", "host"])

@@ -27,7 +27,7 @@ def test_library_exports_whole_abi():
     out = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH], text=True)
     exported = set(re.findall(r" T (tpc_mpc_[a-z_0-9]+)", out))
     assert set(decl) <= exported
-    assert lib.tpc_mpc_abi_version() == capi.ABI_VERSION == 3
+    assert lib.tpc_mpc_abi_version() == capi.ABI_VERSION == 4
 
 
 def test_header_is_plain_c(tmp_path):

@@ -88,10 +88,11 @@ def test_ub_golden(torch_cuda, H):
     assert np.all(it[known] >= g["iters_lb"][known])
 
 
-@pytest.mark.parametrize("H,n", [(4, 4096), (10, 4096), (20, 3000), (30, 1000)])
+@pytest.mark.parametrize("H,n", [(4, 4096), (5, 4096), (10, 4096), (20, 3000), (30, 1000), (40, 700)])
 def test_ub_vs_oracle_iters(torch_cuda, oracle, H, n):
-    """Fresh seeded inputs against the pinned oracle: identical iteration counts, |du| <= 1e-9.
-    (H = 10, n = 4 096 is BASELINE config 2 at its exact size.)"""
+    """Fresh seeded inputs against the pinned oracle: identical iteration counts, |du| <= 1e-9, at every specialised
+    horizon.  (H = 10, n = 4 096 is BASELINE config 2 at its exact size; at H = 40 a tenth of the instances end on
+    the iteration cap, where the count is the cap on both sides and the outputs have not converged: still <= 1e-9.)"""
     from trajectory_controller_amd.synth import compact_inputs
     v, dy, dphi = compact_inputs(H, n)
     of, orr, oit = oracle.solve_compact(H, v, dy, dphi, nthreads=8)
@@ -285,7 +286,7 @@ def test_ubg_golden(torch_cuda, I, H):
     assert np.abs(u0 - g["u0"]).max() <= UB_ATOL
 
 
-@pytest.mark.parametrize("I,H,n", [(1, 4, 4096), (2, 10, 4096), (1, 20, 2000), (2, 20, 3000)])
+@pytest.mark.parametrize("I,H,n", [(1, 4, 4096), (2, 5, 4096), (1, 5, 2000), (2, 10, 4096), (1, 20, 2000), (2, 20, 3000)])
 def test_ubg_vs_oracle_iters(torch_cuda, oracle, I, H, n):
     """Fresh seeded inputs against the pinned oracle: identical iteration counts, |du| <= 1e-9, and a control dlib
     leaves on a bound is on it bit for bit."""

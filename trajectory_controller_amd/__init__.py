@@ -6,9 +6,9 @@ Only the hot path lives here: csrc/ holds the gfx950 HIP kernels and
 host/ is the C++ module shim that keeps the LMS surface.  Nothing in this package imports
 oracle/ -- that directory is the checker used by tests/ and bench.py only.
 """
-from .capi import (ALGO_AUTO, ALGO_LANE, ALGO_LANE_FMA, ALGO_WAVE, F32, F64, FLAG_BAD_MODEL, FLAG_MAX_ITER, FLAG_NONFINITE,
+from .capi import (ALGO_AUTO, ALGO_GROUP, ALGO_LANE, ALGO_LANE_FMA, ALGO_WAVE, F32, F64, FLAG_BAD_MODEL, FLAG_MAX_ITER, FLAG_NONFINITE,
                    TpcMpcError, default_params, load_library)
 from .solver import MpcSolver
 
 __all__ = ["MpcSolver", "TpcMpcError", "default_params", "load_library", "ALGO_AUTO", "ALGO_WAVE",
-           "ALGO_LANE", "ALGO_LANE_FMA", "F64", "F32", "FLAG_NONFINITE", "FLAG_MAX_ITER", "FLAG_BAD_MODEL"]
+           "ALGO_LANE", "ALGO_LANE_FMA", "ALGO_GROUP", "F64", "F32", "FLAG_NONFINITE", "FLAG_MAX_ITER", "FLAG_BAD_MODEL"]

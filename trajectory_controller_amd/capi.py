@@ -16,13 +16,13 @@ LIB_PATH = os.environ.get("TPC_MPC_LIB") or os.path.join(_HERE, "lib", "libtpc_m
 OK = 0
 F64, F32 = 0, 1
 HOST, DEVICE = 0, 1
-ALGO_AUTO, ALGO_WAVE, ALGO_LANE, ALGO_LANE_FMA = 0, 1, 2, 3
-OPT_WAVE_GROUP, OPT_MAILBOX_HOST = 1, 2
+ALGO_AUTO, ALGO_WAVE, ALGO_LANE, ALGO_LANE_FMA, ALGO_GROUP = 0, 1, 2, 3, 4
+OPT_WAVE_GROUP, OPT_MAILBOX_HOST, OPT_GROUP_LANES, OPT_GROUP_WAVES = 1, 2, 3, 4
 FLAG_NONFINITE, FLAG_MAX_ITER, FLAG_BAD_MODEL = 0x1, 0x2, 0x4
 
 STATUS_NAMES = {0: "OK", 1: "BAD_ARG", 2: "BAD_WEIGHTS", 3: "BAD_BOUNDS", 4: "BAD_HORIZON",
                 5: "BAD_EPS", 6: "NO_DEVICE", 7: "HIP", 8: "ALLOC", 9: "COMM"}
-ABI_VERSION = 3
+ABI_VERSION = 4
 COMM_ID_BYTES = 128
 
 # every symbol include/tpc_mpc.h declares
@@ -35,7 +35,7 @@ EXPORTS = ("tpc_mpc_default_params", "tpc_mpc_create", "tpc_mpc_destroy", "tpc_m
            "tpc_mpc_follow_batch_horizon", "tpc_mpc_comm_unique_id", "tpc_mpc_comm_init_rank",
            "tpc_mpc_comm_destroy", "tpc_mpc_group_begin", "tpc_mpc_group_end", "tpc_mpc_shard_range",
            "tpc_mpc_solve_batch_compact_sharded", "tpc_mpc_comm_test_mode",
-           "tpc_mpc_solve_batch_general_sharded")
+           "tpc_mpc_solve_batch_general_sharded", "tpc_mpc_last_flags")
 
 
 class Params(C.Structure):
@@ -104,6 +104,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.tpc_mpc_last_error.restype = C.c_char_p
     lib.tpc_mpc_solve_one.argtypes = [vp, C.POINTER(Params), C.c_double, C.c_double, C.c_double,
                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.tpc_mpc_last_flags.argtypes = [vp, u32p, i32p]
     lib.tpc_mpc_solve_batch_compact.argtypes = [vp, C.POINTER(Params), C.c_int64, vp, vp, vp, vp, vp,
                                                 vp, u32p, C.c_int, vp]
     lib.tpc_mpc_solve_batch_general.argtypes = [vp, C.POINTER(Params), C.POINTER(GeneralIO), u32p,

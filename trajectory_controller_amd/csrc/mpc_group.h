@@ -1,0 +1,297 @@
+// GROUP kernels: G lanes per MPC instance -- the family between "one wavefront per instance" (WAVE, mpc_wave.h)
+// and "one lane per instance" (LANE_FMA, mpc_ub.h), for batches too small to give every lane of the chip an
+// instance of its own and too large for a wavefront each.
+//
+// What is computed is the LANE_FMA family's projected-gradient phase (reference: accelerated projected gradient,
+// dlib_files/dlib/control/mpc.h:336-345, on the gradient of mpc.h:275-283, stop test mpc.h:289-311), in the
+// arithmetic of mpc_ub_model.h (unit-box coordinates, fused multiply-adds, the linear term folded into the backward
+// recurrence).  The coordinate-descent phase (mpc.h:319-335), the records it leaves, the longest-first queue and the
+// screen of the select-free stop test are LANE_FMA's own (ub_cd_kernel, mpc_sort.hip): this file adds one kernel,
+// group_pg_kernel, that consumes the same records.
+//
+// Layout.  The H horizon steps of an instance are cut into G chunks of L = H / G consecutive steps; lane p of a
+// group owns chunk p: its 2L controls x, dlib's momentum v, and the chunk's part of both recurrences, all in
+// registers.  A wavefront carries 64 / G instances.  Both recurrences of mpc.h:275-281 are affine in the state they
+// carry with a CONSTANT matrix (A = [1 a; 0 1], so A^k = [1 ka; 0 1]), hence each is computed as
+//     1. the chunk's recurrence from a zero start (L steps in registers, every lane at once),
+//     2. an exclusive scan over the G lanes of the chunk summaries -- a summary is the chunk's offset pair, and
+//        combining with the summary d lanes away is `z += z' + (d L a) y';  y += y'`: log2 G steps of two
+//        DPP-moved values and three fused multiply-adds, out-of-group lanes cancelled by 0 / 1 weights --
+//     3. the correction of the L local values by the incoming state (an arithmetic progression: one addition each).
+// Forward: (Z, Y) = predicted state error;  backward: (N0, N1) = the costate.  The stop test (the largest free
+// gradient component against eps) is a per-lane maximum and one OR over the group, the arg-max is not needed in this
+// phase.  30 VALU instructions per horizon step against LANE_FMA's 25, plus ~36 (G = 4) for the two scans: at N = 20
+// an iteration is ~200 instructions for 16 instances where WAVE spends ~90 on one or two and LANE_FMA 660 on 64 that
+// must all be there.
+//
+// Lanes of a group finish together (the verdict is the group's), and a group whose instance has finished takes the
+// next one from the longest-first queue exactly as a LANE_FMA lane does (one ticket atomic per refill pass).
+//
+// Results: the same decisions as dlib on quantities that differ from dlib's by rounding (a third association of the
+// same sums, beside WAVE's and LANE_FMA's): held to <= 1e-9 and to identical iteration counts against the oracle
+// and the real-dlib fixtures (tests/test_group_gpu.py).  Only the screened ("fast") stop test is built; a batch the
+// screen refuses runs LANE_FMA's exact build on the same records.
+#pragma once
+
+#include "mpc_ub.h"
+
+namespace tpc {
+
+// DPP moves inside a group of G lanes: the value of the lane `D` places below (Shr) or above (Shl).  Where that lane
+// lies outside the group the result is another lane's value or zero -- finite either way (only screened, finite
+// instances are ever loaded), and multiplied by a zero weight where it is used.
+template <int G, int D, bool UP> struct GroupDpp {
+    // quad_perm codes keep every read inside the quad; wider groups use row shifts with zero fill
+    static constexpr int ctrl =
+        G <= 4 ? (UP ? (D == 1 ? (G == 2 ? 0xF5 : 0xF9) : 0xEE)     // [1,1,3,3] / [1,2,3,3] / [2,3,2,3]
+                     : (D == 1 ? (G == 2 ? 0xA0 : 0x90) : 0x44))    // [0,0,2,2] / [0,0,1,2] / [0,1,0,1]
+               : (UP ? 0x100 + D : 0x110 + D);                      // row_shl:D / row_shr:D
+};
+template <int CTRL> TPC_DEV double group_mov(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL> TPC_DEV float group_mov(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+// OR over the lanes of a group, left in every lane (butterfly: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror)
+template <int G> TPC_DEV int group_or(int x) {
+    if constexpr (G > 1) x |= __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);
+    if constexpr (G > 2) x |= __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);
+    if constexpr (G > 4) x |= __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true);
+    if constexpr (G > 8) x |= __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, true);
+    return x;
+}
+
+#ifndef TPC_GROUP_OCC
+#define TPC_GROUP_OCC 0
+#endif
+template <typename T, int H, int G> struct GroupPlan {
+    static_assert(G == 2 || G == 4 || G == 8 || G == 16, "a group is 2, 4, 8 or 16 lanes of one DPP row");
+    static_assert(H % G == 0, "chunks of equal length");
+    static constexpr int L = H / G;            // horizon steps per lane
+    static constexpr int NG = kWave / G;       // instances per wavefront
+    // scan steps after the initial shift by one lane: the exclusive prefix of lane p spans up to G - 1 lanes, and each
+    // step doubles what a lane's partial result spans (1 after the shift)
+    static constexpr int steps = G == 2 ? 0 : (G == 4 ? 2 : (G == 8 ? 3 : 4));
+    // state of a lane: x, v, the local forward and backward passes: 8 L values (+ ~25 constants)
+    static constexpr int words = sizeof(T) == 8 ? 2 : 1;
+    static constexpr int est_regs = (8 * L + 28) * words + 24;
+    static constexpr int occ_default = est_regs <= 128 ? 4 : (est_regs <= 168 ? 3 : (est_regs <= 256 ? 2 : 1));
+    static constexpr int occ = TPC_GROUP_OCC > 0 ? TPC_GROUP_OCC : occ_default;   // wavefronts per SIMD the kernel is built for
+};
+#ifdef TPC_GROUP_REFILL_BATCH
+template <int G> struct GroupRefillBatch { static constexpr int value = TPC_GROUP_REFILL_BATCH; };
+#else
+// groups that wait for an instance before a refill pass is worth leaving the loop for
+template <int G> struct GroupRefillBatch { static constexpr int value = G >= 8 ? 1 : 2; };
+#endif
+
+template <typename T, int H, int G, bool EQB>
+__global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel(
+    CompactArgs g, Knobs kn, const T* __restrict__ recs, const uint32_t* __restrict__ order,
+    uint32_t* __restrict__ ticket, unsigned long long* __restrict__ stats, const uint32_t* __restrict__ queue_len) {
+    using P = GroupPlan<T, H, G>;
+    constexpr int L = P::L, RL = LaneRec<T, H>::kLen;
+    constexpr bool D64 = sizeof(T) == 8;
+    const int64_t n_queue = (int64_t)__builtin_nontemporal_load(queue_len);
+    // the screened stop test only: a batch the coordinate-descent kernel's screen refused is LANE_FMA's exact build's
+    if (__builtin_nontemporal_load(&stats[2]) != 0ull) return;
+
+    const int lane = threadIdx.x;
+    const int p = lane & (G - 1);                 // chunk of this lane
+    const int gbase = lane & ~(G - 1);            // first lane of its group
+    constexpr T gs = ub::GradScale<T>::g;
+    const T geps = gs * (T)kn.eps;
+    T huge = (T)0x1p100;                          // fp32: dlib's mask as arithmetic (ub_pg_kernel)
+    asm volatile("" : "+v"(huge));
+
+    ub::Unit<T, EQB> m;
+    ub_set_uniform(m, gs, g);
+    m.a = m.c = m.as1 = m.cs0 = m.cs1 = m.dlt = m.z0 = m.q1th = (T)0;
+    // 0 / 1 weights of the scan steps: lane p combines with the lane d below (forward) / above (backward) if that
+    // lane belongs to the group
+    constexpr int KS = P::steps, KA = KS > 0 ? KS : 1;
+    T wf[KA], wb[KA];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        wf[s] = p >= (1 << s) ? (T)1 : (T)0;
+        wb[s] = p + (1 << s) < G ? (T)1 : (T)0;
+    }
+    const T wf0 = p >= 1 ? (T)1 : (T)0, wb0 = p + 1 < G ? (T)1 : (T)0;   // the initial shift by one lane
+    // per instance: d L a times the weight, and the start of the local forward pass (the true start in chunk 0)
+    T cf[KA], cb[KA];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) cf[s] = cb[s] = (T)0;
+    T zst = (T)0, yst = (T)0;
+
+    T x[2 * L], v[2 * L];
+    T x0_prev[2] = {(T)0, (T)0};
+    T il[2] = {(T)0, (T)0}, beta = (T)0;
+    int64_t k = 0;
+    uint32_t iter = 0;
+    bool have = false, exhausted = false;        // (the same in every lane of a group)
+    uint32_t flags = 0;
+    uint32_t wave_iters = 0, refills = 0;
+#pragma unroll
+    for (int q = 0; q < 2 * L; ++q) { x[q] = (T)0; v[q] = (T)0; }
+
+    auto publish = [&](T a0, T a1, uint32_t it) {   // chunk 0 holds step 0
+        if (p == 0) {
+            ((T*)g.front)[k] = m.control(0, a0);
+            ((T*)g.rear)[k] = m.control(1, a1);
+            if (g.iters) g.iters[k] = (int32_t)it;
+        }
+    };
+
+#pragma unroll 1
+    while (true) {
+        // ---- refill: groups without an instance take the next entries of the longest-first queue
+        const unsigned long long want = __ballot(!have && !exhausted);
+        if (want != 0ull && (__popcll(want) >= GroupRefillBatch<G>::value * G || __ballot(have) == 0ull)) {
+            ++refills;
+            const uint32_t cnt = (uint32_t)__popcll(want) / G;
+            const uint32_t rank = (uint32_t)__popcll(want & ((1ull << gbase) - 1ull)) / G;
+            const int leader = __ffsll((long long)want) - 1;
+            uint32_t first_ticket = 0;
+            if (lane == leader) first_ticket = atomicAdd(ticket, cnt);
+            first_ticket = (uint32_t)__shfl((int)first_ticket, leader);
+            if (!have && !exhausted) {
+                const uint32_t t = first_ticket + rank;
+                if ((int64_t)t >= n_queue) {
+                    exhausted = true;
+                } else {
+                    k = (int64_t)order[t];
+                    const T* rec = recs + k * RL;
+                    const T vk = ((const T*)g.v)[k], ty = ((const T*)g.dy)[k], tphi = ((const T*)g.dphi)[k];
+#pragma unroll
+                    for (int q = 0; q < 2 * L; ++q) x[q] = rec[2 * L * p + q];
+                    const T lambda = rec[2 * H];
+                    const uint64_t meta = load_meta<T>(rec + 2 * H + 1);
+                    iter = (uint32_t)meta;
+                    const bool vinit = (meta & kMetaVInit) != 0;   // mpc.h:330-334, else a fresh v = 0
+#pragma unroll
+                    for (int q = 0; q < 2 * L; ++q) v[q] = vinit ? x[q] : m.xz(q & 1);
+                    m.set_instance((T)g.step, (T)g.wheelbase, vk, ty, tphi);
+                    T dummy_z, dummy_y;
+                    m.fwd_init(dummy_z, dummy_y);
+                    zst = p == 0 ? dummy_z : (T)0;
+                    yst = p == 0 ? dummy_y : (T)0;
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        const T dla = (T)((1 << s) * L) * m.a;
+                        cf[s] = wf[s] * dla;
+                        cb[s] = wb[s] * dla;
+                    }
+                    if ((meta & kMetaStopped) || iter >= kn.max_iter) {
+                        // (ub_cd_kernel publishes these itself and keeps them out of the queue; kept for a queue that holds one)
+                        if (!(meta & kMetaStopped)) flags |= 0x2u;
+                        if (meta & kMetaNonFinite) { flags |= 0x1u; if (p == 0) { ((T*)g.front)[k] = (T)0; ((T*)g.rear)[k] = (T)0; if (g.iters) g.iters[k] = (int32_t)iter; } }
+                        else publish(x[0], x[1], iter);
+                    } else {
+                        ub::pg_constants<T>(lambda, m.s0, m.s1, il[0], il[1], beta);   // mpc.h:342-343
+                        have = true;
+                    }
+                }
+            }
+        }
+        if (__ballot(have) == 0ull) {
+            if (__ballot(!exhausted) == 0ull) break;
+            continue;
+        }
+
+        bool stop = false, cap = false;
+#pragma unroll 1
+        do {
+            // ---- forward recurrence of the chunk from its local start (mpc.h:275-277)
+            T wz[L], wy[L];
+            T Z = zst, Y = yst;
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                m.fwd(Z, Y, x[2 * l], x[2 * l + 1]);
+                wz[l] = Z; wy[l] = Y;
+            }
+            // ---- exclusive scan of the chunk summaries over the group: (ez, ey) = state entering this chunk
+            //      minus what the local start already carried
+            T ez = wf0 * group_mov<GroupDpp<G, 1, false>::ctrl>(Z), ey = wf0 * group_mov<GroupDpp<G, 1, false>::ctrl>(Y);
+            static_for<KS>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                constexpr int ctrl = GroupDpp<G, (1 << s), false>::ctrl;
+                const T oz = group_mov<ctrl>(ez), oy = group_mov<ctrl>(ey);
+                ez = ub::fma_(cf[s], oy, ub::fma_(wf[s], oz, ez));
+                ey = ub::fma_(wf[s], oy, ey);
+            });
+            // ---- backward recurrence of the chunk on the corrected states, from a zero costate (mpc.h:278-281)
+            x0_prev[0] = x[0]; x0_prev[1] = x[1];
+            const T aey = m.a * ey;
+            const T e1c = ub::fma_(m.gq1, ey, -m.q1th);
+            T zc = ub::fma_((T)L, aey, ez);
+            T nl0[L], nl1[L];
+            T n0 = (T)0, n1 = (T)0;
+#pragma unroll
+            for (int l = L - 1; l >= 0; --l) {
+                const T zt = wz[l] + zc;
+                if (l > 0) zc = zc - aey;
+                const T e1 = ub::fma_(m.gq1, wy[l], e1c);
+                const T t1 = ub::fma_(m.a, n0, n1) + e1;
+                n0 = ub::fma_(m.gq0, zt, n0);
+                n1 = t1;
+                nl0[l] = n0; nl1[l] = n1;
+            }
+            // ---- exclusive suffix scan: (f0, f1) = costate at the first step of the next chunk
+            T f0 = wb0 * group_mov<GroupDpp<G, 1, true>::ctrl>(n0), f1 = wb0 * group_mov<GroupDpp<G, 1, true>::ctrl>(n1);
+            static_for<KS>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                constexpr int ctrl = GroupDpp<G, (1 << s), true>::ctrl;
+                const T o0 = group_mov<ctrl>(f0), o1 = group_mov<ctrl>(f1);
+                f1 = ub::fma_(cb[s], o0, ub::fma_(wb[s], o1, f1));
+                f0 = ub::fma_(wb[s], o0, f0);
+            });
+            // ---- gradient (mpc.h:283), stop test (mpc.h:289-311) and the speculative update (mpc.h:342-343)
+            const T af0 = m.a * f0;
+            T n1c = ub::fma_((T)L, af0, f1);
+            T acc0 = (T)0, acc1 = (T)0;
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const T N0 = nl0[l] + f0;
+                const T N1 = nl1[l] + n1c;
+                if (l + 1 < L) n1c = n1c - af0;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int q = 2 * l + j;
+                    const T xx = x[q];
+                    const T dd = j == 0 ? m.df0(N1, xx) : m.df1(N0, N1, xx);
+                    const T vn = m.template project<true>(ub::fma_(-il[j], dd, xx), j);          // mpc.h:342
+                    T& acc = j == 0 ? acc0 : acc1;
+                    if constexpr (D64) {
+                        acc = tmax(acc, tmin(tabs(dd), tabs(xx - vn)));
+                    } else {
+                        const T g_lo = m.gap_lo(j, xx, huge), g_hi = m.gap_hi(j, xx, huge);
+                        acc = tmax(acc, tabs((T)med3_neglo((float)dd, (float)g_hi, (float)g_lo)));
+                    }
+                    x[q] = m.template project<true>(ub::fma_(beta, vn - v[q], vn), j);           // mpc.h:343 (difference form)
+                    v[q] = vn;
+                }
+            }
+            const int go = group_or<G>(tmax(acc0, acc1) >= geps ? 1 : 0);
+            ++wave_iters;
+            stop = have && go == 0;                                                 // mpc.h:310-311
+            ++iter;
+            cap = have && !stop && iter >= kn.max_iter;                             // mpc.h:271
+            if (__ballot(stop || cap) != 0ull) {
+                if (stop) { publish(x0_prev[0], x0_prev[1], iter - 1); have = false; }
+                if (cap) { flags |= 0x2u; publish(x[0], x[1], iter); have = false; }
+                const unsigned long long waiting = __ballot(!have && !exhausted);
+                if (__popcll(waiting) >= GroupRefillBatch<G>::value * G || __ballot(have) == 0ull) break;
+            }
+        } while (true);
+    }
+    raise_flags(g.flags, flags);
+    if (stats && lane == 0) {
+        atomicAdd(&stats[0], (unsigned long long)wave_iters);
+        atomicAdd(&stats[1], (unsigned long long)refills);
+    }
+}
+
+}  // namespace tpc

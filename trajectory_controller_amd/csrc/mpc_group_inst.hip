@@ -1,0 +1,91 @@
+// One translation unit per horizon (compile with -DTPC_GROUP_H=<H>): instantiates the GROUP kernels (mpc_group.h:
+// G lanes per instance) for fp64 / fp32, compact model, at the group sizes that divide the horizon, and exports
+// their launcher.  The coordinate-descent phase, the queue order and the exact-stop-test fallback are the LANE_FMA
+// unit's of the same horizon (mpc_ub_inst.hip).
+#include <cstdint>
+
+#include "mpc_group.h"
+
+#ifndef TPC_GROUP_H
+#error "compile with -DTPC_GROUP_H=<horizon>"
+#endif
+
+namespace tpc {
+
+#define TPC_CAT2(a, b) a##b
+#define TPC_CAT(a, b) TPC_CAT2(a, b)
+hipError_t TPC_CAT(ub_phase1_h, TPC_GROUP_H)(int, int, const CompactArgs&, const Knobs&, const Workspace&, hipStream_t);
+hipError_t TPC_CAT(ub_exact_h, TPC_GROUP_H)(int, int, const CompactArgs&, const Knobs&, const Workspace&, hipStream_t);
+
+namespace {
+
+constexpr int kH = TPC_GROUP_H;
+
+// persistent-wavefront count: what the device holds of this kernel
+template <class Tag, class Kernel> inline int group_grid(Kernel kernel) {
+    constexpr int kMaxDev = 64;
+    static int cache[kMaxDev] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev >= 0 && dev < kMaxDev && cache[dev] > 0) return cache[dev];
+    int cus = 256, per_cu = 4;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWave, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (dev >= 0 && dev < kMaxDev) cache[dev] = cus * per_cu;
+    return cus * per_cu;
+}
+template <typename T, int G, bool EQB> struct Tag {};
+
+template <typename T, int G, bool EQB>
+hipError_t pg(const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s, int waves_per_simd) {
+    if constexpr (kH % G != 0) {
+        return hipErrorInvalidValue;
+    } else {
+        constexpr int NG = GroupPlan<T, kH, G>::NG;
+        const int64_t need = (a.n + NG - 1) / NG;
+        int cap = group_grid<Tag<T, G, EQB>>(group_pg_kernel<T, kH, G, EQB>);
+        // (a smaller persistent grid -- fewer wavefronts per SIMD, each faster -- when the caller asks for it)
+        if (waves_per_simd > 0) {
+            int cus = 256;
+            hipDeviceProp_t prop;
+            int dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+            const int lim = cus * 4 * waves_per_simd;
+            if (lim < cap) cap = lim;
+        }
+        hipLaunchKernelGGL((group_pg_kernel<T, kH, G, EQB>), dim3((unsigned)(need < cap ? need : cap)), dim3(kWave), 0, s, a, k,
+                           (const T*)ws.state, (const uint32_t*)ws.order, ws.ticket, ws.stats, order_queue_len(ws.sort_temp));
+        return hipGetLastError();
+    }
+}
+
+template <typename T, bool EQB>
+hipError_t pg_any(int G, const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s, int wps) {
+    switch (G) {
+        case 2: return pg<T, 2, EQB>(a, k, ws, s, wps);
+        case 4: return pg<T, 4, EQB>(a, k, ws, s, wps);
+        case 8: return pg<T, 8, EQB>(a, k, ws, s, wps);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+// G lanes per instance (2, 4 or 8, dividing the horizon).  `waves_per_simd` > 0 caps the persistent grid.
+hipError_t TPC_CAT(group_compact_h, TPC_GROUP_H)(int dtype, int equal_bounds, int G, int waves_per_simd, const CompactArgs& a,
+                                                  const Knobs& k, const Workspace& ws, hipStream_t s) {
+    if (a.n <= 0) return hipSuccess;
+    if (kH % G != 0 || (G != 2 && G != 4 && G != 8)) return hipErrorInvalidValue;
+    hipError_t e = TPC_CAT(ub_phase1_h, TPC_GROUP_H)(dtype, equal_bounds, a, k, ws, s);
+    if (e != hipSuccess) return e;
+    if (dtype == 0) e = equal_bounds ? pg_any<double, true>(G, a, k, ws, s, waves_per_simd) : pg_any<double, false>(G, a, k, ws, s, waves_per_simd);
+    else e = pg_any<float, true>(G, a, k, ws, s, waves_per_simd);
+    if (e != hipSuccess) return e;
+    // a batch the screen of the select-free stop test refused: LANE_FMA's exact build, on the same records
+    e = TPC_CAT(ub_exact_h, TPC_GROUP_H)(dtype, equal_bounds, a, k, ws, s);
+    if (ws.ev) (void)hipEventRecord(ws.ev[2], s);
+    return e;
+}
+
+}  // namespace tpc

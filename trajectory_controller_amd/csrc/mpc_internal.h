@@ -35,6 +35,7 @@ struct OneArgs {
     double step, wheelbase;
     double q[2], r[2], lo[2], hi[2];
     uint64_t* out;                         // front, rear (8-byte stores visible to the host)
+    uint64_t* info;                        // (TPC_MPC_FLAG_* << 32) | iteration count, stored like the outputs
     static constexpr int32_t* iters = nullptr;
     static constexpr uint32_t* flags = nullptr;
 };
@@ -66,6 +67,8 @@ struct Workspace {
     // (ev[0] .. ev[1] first kernel, ev[1] .. ev[2] second kernel); null when profiling is off
     hipEvent_t* ev;
     int wave_group = 0;   // TPC_MPC_OPT_WAVE_GROUP: 0 auto, 1 / 2 / 4 instances per wavefront
+    int group_lanes = 0;  // GROUP: lanes per instance (2 / 4 / 8) for this horizon
+    int group_waves = 0;  // GROUP: cap on the persistent grid in wavefronts per SIMD (0: none)
 };
 
 // WAVE work queue (mpc_wave.h): the dynamic part of the queue is dealt out through kQueueTickets counters on

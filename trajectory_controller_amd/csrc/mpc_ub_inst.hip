@@ -1,6 +1,7 @@
 // One translation unit per horizon (compile with -DTPC_UB_H=<H>): instantiates the LANE_FMA kernels
 // (mpc_ub.h) for fp64 / fp32, compact model, and exports their launcher.
 #include <cstdint>
+#include <type_traits>
 
 #include "mpc_ub.h"
 
@@ -34,9 +35,10 @@ inline int ub_grid(Kernel kernel, int block) {
 template <typename T, bool EQB> struct TagFast {};
 template <typename T, bool EQB> struct TagExact {};
 
+// coordinate descent + queue order: everything up to the projected-gradient launches (also the front half of the
+// GROUP family, mpc_group_inst.hip, which consumes the same records)
 template <typename T, bool EQB>
-hipError_t run(const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
-    if (a.n <= 0) return hipSuccess;
+hipError_t phase1(const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
     T* recs = (T*)ws.state;
     hipError_t e = hipMemsetAsync(ws.ticket, 0, sizeof(uint32_t), s);
     if (e == hipSuccess) e = hipMemsetAsync(ws.stats, 0, 3 * sizeof(unsigned long long), s);
@@ -51,17 +53,27 @@ hipError_t run(const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStr
     e = order_finish(ws.keys, ws.rank, ws.order, a.n, ws.sort_temp, s);
     if (e != hipSuccess) return e;
     if (ws.ev) (void)hipEventRecord(ws.ev[1], s);
+    return hipSuccess;
+}
+// one build of the projected-gradient kernel (it returns at once unless the coordinate-descent kernel's screen picked it)
+template <typename T, bool EQB, bool FAST>
+hipError_t pg_launch(const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
     constexpr int bt = kWave * UbPlan<T, kH>::occ;
     const int64_t need = (a.n + bt - 1) / bt;
-    const uint32_t* queue_len = order_queue_len(ws.sort_temp);
+    const int cap = ub_grid<std::conditional_t<FAST, TagFast<T, EQB>, TagExact<T, EQB>>>(ub_pg_kernel<T, kH, EQB, FAST>, bt);
+    hipLaunchKernelGGL((ub_pg_kernel<T, kH, EQB, FAST>), dim3((unsigned)(need < cap ? need : cap)), dim3(bt), 0, s, a, k,
+                       (const T*)ws.state, (const uint32_t*)ws.order, ws.ticket, ws.stats, order_queue_len(ws.sort_temp));
+    return hipGetLastError();
+}
+
+template <typename T, bool EQB>
+hipError_t run(const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
+    if (a.n <= 0) return hipSuccess;
+    hipError_t e = phase1<T, EQB>(a, k, ws, s);
+    if (e != hipSuccess) return e;
     // both builds go out; the one the coordinate-descent kernel's screen did not pick returns at once
-    const int fast_cap = ub_grid<TagFast<T, EQB>>(ub_pg_kernel<T, kH, EQB, true>, bt);
-    hipLaunchKernelGGL((ub_pg_kernel<T, kH, EQB, true>), dim3((unsigned)(need < fast_cap ? need : fast_cap)), dim3(bt), 0,
-                       s, a, k, (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats, queue_len);
-    const int grid_cap = ub_grid<TagExact<T, EQB>>(ub_pg_kernel<T, kH, EQB, false>, bt);
-    hipLaunchKernelGGL((ub_pg_kernel<T, kH, EQB, false>), dim3((unsigned)(need < grid_cap ? need : grid_cap)), dim3(bt), 0,
-                       s, a, k, (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats, queue_len);
-    e = hipGetLastError();
+    e = pg_launch<T, EQB, true>(a, k, ws, s);
+    if (e == hipSuccess) e = pg_launch<T, EQB, false>(a, k, ws, s);
     if (ws.ev) (void)hipEventRecord(ws.ev[2], s);
     return e;
 }
@@ -77,6 +89,19 @@ hipError_t TPC_CAT(ub_compact_h, TPC_UB_H)(int dtype, int equal_bounds, const Co
                                             const Workspace& ws, hipStream_t s) {
     if (dtype == 0) return equal_bounds ? run<double, true>(a, k, ws, s) : run<double, false>(a, k, ws, s);
     return run<float, true>(a, k, ws, s);   // fp32 keeps dlib's coordinates: no bound-dependent build (mpc_ub_model.h)
+}
+
+// The two halves the GROUP family borrows (mpc_group_inst.hip): the coordinate-descent kernel with the queue order,
+// and the exact-stop-test build of the projected-gradient kernel for a batch the screen refused.
+hipError_t TPC_CAT(ub_phase1_h, TPC_UB_H)(int dtype, int equal_bounds, const CompactArgs& a, const Knobs& k,
+                                           const Workspace& ws, hipStream_t s) {
+    if (dtype == 0) return equal_bounds ? phase1<double, true>(a, k, ws, s) : phase1<double, false>(a, k, ws, s);
+    return phase1<float, true>(a, k, ws, s);
+}
+hipError_t TPC_CAT(ub_exact_h, TPC_UB_H)(int dtype, int equal_bounds, const CompactArgs& a, const Knobs& k,
+                                          const Workspace& ws, hipStream_t s) {
+    if (dtype == 0) return equal_bounds ? pg_launch<double, true, false>(a, k, ws, s) : pg_launch<double, false, false>(a, k, ws, s);
+    return pg_launch<float, true, false>(a, k, ws, s);
 }
 
 }  // namespace tpc

@@ -260,6 +260,7 @@ template <typename T, int I, int H> struct WaveIO<T, I, H, CompactArgs> {
         }
         if (g.iters && reporter) g.iters[k] = (int32_t)it;
     }
+    static TPC_DEV void report(const CompactArgs&, uint32_t, uint32_t) {}
 };
 template <int I, int H> struct WaveIO<double, I, H, OneArgs> {
     static TPC_DEV double init_u(const OneArgs&, int64_t, int, int) { return 0.0; }
@@ -267,6 +268,12 @@ template <int I, int H> struct WaveIO<double, I, H, OneArgs> {
     static TPC_DEV void write(const OneArgs& g, int64_t, bool active, int qi, int qj, double u, double, uint32_t) {
         if (active && qi == 0)
             __hip_atomic_store(g.out + qj, (uint64_t)__double_as_longlong(u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // what the batch entries report through flags_out / iters, for the one instance of tpc_mpc_solve_one: the host
+    // waits for this word as it waits for the two outputs (tpc_mpc_one.hip), so the order of the three stores is free
+    static TPC_DEV void report(const OneArgs& g, uint32_t flags, uint32_t it) {
+        if ((threadIdx.x & 63) == 0)
+            __hip_atomic_store(g.info, ((uint64_t)flags << 32) | (uint64_t)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 };
 template <typename T, int I, int H> struct WaveIO<T, I, H, GeneralArgs> {
@@ -287,6 +294,7 @@ template <typename T, int I, int H> struct WaveIO<T, I, H, GeneralArgs> {
         }
         if (g.iters && reporter) g.iters[k] = (int32_t)it;
     }
+    static TPC_DEV void report(const GeneralArgs&, uint32_t, uint32_t) {}
 };
 
 // Row `slot` (= column, the Hessian is symmetric) of K'QK, i.e. of the Hessian Hd = K'QK + R WITHOUT its R
@@ -615,14 +623,13 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, Hook 
     if ((Model::kScreen && nonfinite) || badmodel) capped = false;
     else if (mask_ok) run(std::true_type{});
     else run(std::false_type{});
+    uint32_t f = 0;   // (all lanes alike)
+    if (nonfinite) f |= 0x1u;
+    if (badmodel) f |= 0x4u;
+    if (capped) f |= 0x2u;
+    WaveIO<T, I, H, Args>::report(g, f, iter);
     WaveIO<T, I, H, Args>::write(g, k, active, qi, qj, u, v, iter);
-    if (g.flags) {   // (all lanes alike)
-        uint32_t f = 0;
-        if (nonfinite) f |= 0x1u;
-        if (badmodel) f |= 0x4u;
-        if (capped) f |= 0x2u;
-        raise_flags(g.flags, f);
-    }
+    if (g.flags) raise_flags(g.flags, f);
 }
 
 // ---- two instances per wavefront ----------------------------------------------------------------------------
@@ -1225,15 +1232,14 @@ TPC_DEV void wave2_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s
     if ((Model::kScreen && nonfinite) || badmodel) capped = false;
     else if (mask_ok) run(std::true_type{});
     else run(std::false_type{});
+    uint32_t f = 0;
+    if (nonfinite) f |= 0x1u;
+    if (badmodel) f |= 0x4u;
+    if (capped) f |= 0x2u;
+    WaveIO<T, I, H, Args>::report(g, f, iter);
 #pragma unroll
     for (int e = 0; e < 2; ++e) WaveIO<T, I, H, Args>::write(g, k, active, qi, e, u[e], v[e], iter);
-    if (g.flags) {
-        uint32_t f = 0;
-        if (nonfinite) f |= 0x1u;
-        if (badmodel) f |= 0x4u;
-        if (capped) f |= 0x2u;
-        raise_flags(g.flags, f);
-    }
+    if (g.flags) raise_flags(g.flags, f);
 }
 
 // one instance by the calling wavefront, whichever layout its size needs

@@ -25,6 +25,10 @@ TPC_DECL_H(4) TPC_DECL_H(5) TPC_DECL_H(10) TPC_DECL_H(20) TPC_DECL_H(30) TPC_DEC
 #define TPC_DECL_H(h) hipError_t ub_general_h##h(int, int, const GeneralArgs&, const Knobs&, const Workspace&, hipStream_t);
 TPC_DECL_H(4) TPC_DECL_H(5) TPC_DECL_H(10) TPC_DECL_H(20)
 #undef TPC_DECL_H
+// GROUP: G lanes per instance (mpc_group_inst.hip), compact form, the horizons a power of two divides into chunks
+#define TPC_DECL_H(h) hipError_t group_compact_h##h(int, int, int, int, const CompactArgs&, const Knobs&, const Workspace&, hipStream_t);
+TPC_DECL_H(10) TPC_DECL_H(20) TPC_DECL_H(30) TPC_DECL_H(40)
+#undef TPC_DECL_H
 
 thread_local char g_create_error[kTpcErrLen] = "";
 }  // namespace tpc
@@ -58,6 +62,15 @@ const int32_t* take_hint(tpc_mpc_context* h, int64_t n) {
     return p;
 }
 
+// Lanes per instance of the GROUP family for horizon H: what TPC_MPC_OPT_GROUP_LANES pins if it divides H, else the
+// measured best; 0 where the family has no kernel (N = 4, 5 and the non-specialised horizons).
+int group_lanes(const tpc_mpc_context* h, int H) {
+    if (H != 10 && H != 20 && H != 30 && H != 40) return 0;
+    const int want = h->opt_group_lanes;
+    if ((want == 2 || want == 4 || want == 8) && H % want == 0) return want;
+    return H == 40 ? 8 : (H == 20 ? 4 : 2);
+}
+
 // LANE needs enough instances to give every SIMD a full wavefront; below that WAVE's
 // one-wavefront-per-instance launch finishes sooner.  Measured crossovers on MI355X
 // (scripts/crossover.py, fp64, compact form, round 2 kernels; the chip has 65 536 LANE slots):
@@ -75,6 +88,8 @@ int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n, int d
     if (algo == TPC_MPC_ALGO_WAVE) return wave_ok ? algo : -1;
     if (algo == TPC_MPC_ALGO_LANE) return algo;
     if (algo == TPC_MPC_ALGO_LANE_FMA) return lane;
+    // GROUP is LANE_FMA's arithmetic with G lanes per instance: the same requests, the horizons a group divides
+    if (algo == TPC_MPC_ALGO_GROUP) return (fma_ok && compact && group_lanes(h, H) > 0) ? algo : lane;
     const int64_t lanes = (int64_t)h->cu_count * 4 * kWave;
     // (N = 40 with two inputs: the two-variables-per-lane WAVE kernel against a LANE pass that lasts as long
     // as its slowest instance, 50 ms whatever the batch: 42.0 against 50.0 ms at 16 384, 62.4 against 49.9 at 24 576)
@@ -148,10 +163,18 @@ template <class Launch> hipError_t generic_launch(const Workspace& ws, hipStream
 hipError_t dispatch_compact(int algo, int H, int dtype, const CompactArgs& a, const Knobs& k,
                             const Workspace& ws, hipStream_t s) {
     if (algo == kAlgoGeneric) return generic_launch(ws, s, [&] { return generic_compact(dtype, H, a, k, ws.state, s); });
-    if (algo == TPC_MPC_ALGO_LANE_FMA) {
+    if (algo == TPC_MPC_ALGO_LANE_FMA || algo == TPC_MPC_ALGO_GROUP) {
         // (compared in the arithmetic type: the kernels see the bounds rounded to it)
         const bool eqb = dtype == TPC_MPC_F64 ? (a.lo[0] == a.lo[1] && a.hi[0] == a.hi[1])
                                               : ((float)a.lo[0] == (float)a.lo[1] && (float)a.hi[0] == (float)a.hi[1]);
+        if (algo == TPC_MPC_ALGO_GROUP) {
+            switch (H) {
+#define X(h) case h: return group_compact_h##h(dtype, eqb ? 1 : 0, ws.group_lanes, ws.group_waves, a, k, ws, s);
+                X(10) X(20) X(30) X(40)
+#undef X
+            }
+            return hipErrorInvalidValue;
+        }
         switch (H) {
 #define X(h) case h: return ub_compact_h##h(dtype, eqb ? 1 : 0, a, k, ws, s);
             X(4) X(5) X(10) X(20) X(30) X(40)
@@ -194,6 +217,8 @@ int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n,
     ws->capacity_bytes = 0;
     ws->ev = h->profiling ? h->ev : nullptr;
     ws->wave_group = h->opt_wave_group;
+    ws->group_lanes = group_lanes(h, H);
+    ws->group_waves = h->opt_group_waves;
     h->ev_valid = h->profiling;
     h->last_algo = algo;
     ws->keys = ws->rank = ws->order = nullptr;
@@ -214,7 +239,7 @@ int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n,
         ws->ticket = (uint32_t*)((char*)h->ws_state + pad256(n * 4));
         ws->capacity_bytes = h->ws_bytes;
     }
-    if (algo == TPC_MPC_ALGO_LANE || algo == TPC_MPC_ALGO_LANE_FMA) {
+    if (algo == TPC_MPC_ALGO_LANE || algo == TPC_MPC_ALGO_LANE_FMA || algo == TPC_MPC_ALGO_GROUP) {
         // records | keys | rank | order | counting-sort bins
         const int64_t rec_b = pad256(lane_rec_len(H, dtype) * (int64_t)esize(dtype) * n);
         const int64_t col_b = pad256(n * 4);
@@ -260,7 +285,7 @@ int check_common(tpc_mpc_context* h, const tpc_mpc_params* p) {
     if (!horizon_ok(p->horizon))
         return fail(h, TPC_MPC_ERR_BAD_HORIZON, "horizon %d outside 1 .. %d", p->horizon, kMaxHorizon);
     if (p->dtype != TPC_MPC_F64 && p->dtype != TPC_MPC_F32) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad dtype");
-    if (p->algo < TPC_MPC_ALGO_AUTO || p->algo > TPC_MPC_ALGO_LANE_FMA) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad algo");
+    if (p->algo < TPC_MPC_ALGO_AUTO || p->algo > TPC_MPC_ALGO_GROUP) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad algo");
     if (!(p->eps > 0)) return fail(h, TPC_MPC_ERR_BAD_EPS, "eps must be > 0 (mpc.h:202)");
     if (p->max_iter > 0x7fffffffull || p->smo_iters > 0x7fffffffull)
         return fail(h, TPC_MPC_ERR_BAD_ARG, "max_iter / smo_iters must fit in 31 bits");
@@ -541,6 +566,16 @@ int tpc_mpc_solve_one(tpc_mpc_handle h, const tpc_mpc_params* p, double v, doubl
         if (rc) return rc;
         // (no HIP call on the resident path: the parts of one_shot_solve that launch or wait select the device themselves)
         return one_shot_solve(h, p, v, delta_y, delta_phi, steering_front, steering_rear);
+    });
+}
+
+int tpc_mpc_last_flags(tpc_mpc_handle h, uint32_t* flags, int32_t* iters) {
+    return guarded(h, [&]() -> int {
+        if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+        if (!h->one_valid) return fail(h, TPC_MPC_ERR_BAD_ARG, "no tpc_mpc_solve_one on this handle yet");
+        if (flags) *flags = h->one_flags;
+        if (iters) *iters = h->one_iters;
+        return TPC_MPC_OK;
     });
 }
 
@@ -937,6 +972,15 @@ int tpc_mpc_set_option(tpc_mpc_handle h, int option, int64_t value) {
                 if (value != 0 && value != 1 && value != 2 && value != 4)
                     return fail(h, TPC_MPC_ERR_BAD_ARG, "TPC_MPC_OPT_WAVE_GROUP takes 0, 1, 2 or 4");
                 h->opt_wave_group = (int)value;
+                return TPC_MPC_OK;
+            case TPC_MPC_OPT_GROUP_LANES:
+                if (value != 0 && value != 2 && value != 4 && value != 8)
+                    return fail(h, TPC_MPC_ERR_BAD_ARG, "TPC_MPC_OPT_GROUP_LANES takes 0, 2, 4 or 8");
+                h->opt_group_lanes = (int)value;
+                return TPC_MPC_OK;
+            case TPC_MPC_OPT_GROUP_WAVES:
+                if (value < 0 || value > 8) return fail(h, TPC_MPC_ERR_BAD_ARG, "TPC_MPC_OPT_GROUP_WAVES takes 0 .. 8");
+                h->opt_group_waves = (int)value;
                 return TPC_MPC_OK;
             case TPC_MPC_OPT_MAILBOX_HOST:
                 HIP_TRY(h, hipSetDevice(h->device));

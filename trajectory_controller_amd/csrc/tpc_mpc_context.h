@@ -51,8 +51,12 @@ struct tpc_mpc_context {
     int64_t hint_n = 0;
     void* hint_own = nullptr;
     int64_t hint_own_bytes = 0;
-    // internal single solves have no flags output: they skip the flag word's memset and atomicOr
+    // internal solves without a flags output skip the flag word's atomicOr
     bool collect_flags = true;
+    // what the last tpc_mpc_solve_one reported (tpc_mpc_last_flags)
+    uint32_t one_flags = 0;
+    int32_t one_iters = 0;
+    bool one_valid = false;
     // optional kernel timing (tpc_mpc_set_profiling)
     bool profiling = false;
     bool ev_valid = false;
@@ -77,6 +81,8 @@ struct tpc_mpc_context {
     // tpc_mpc_set_option
     int opt_wave_group = 0;          // 0 auto, 1 / 2 / 4 instances per wavefront (fp64 WAVE)
     bool opt_mailbox_host = false;   // solve_one's request lines in pinned host memory
+    int opt_group_lanes = 0;         // GROUP: 0 auto, 2 / 4 / 8 lanes per instance
+    int opt_group_waves = 0;         // GROUP: 0 = what the device holds, else wavefronts per SIMD of the persistent grid
 };
 
 namespace tpc {

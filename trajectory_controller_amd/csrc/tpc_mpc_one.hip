@@ -44,14 +44,15 @@ namespace {
 // line 0 (host -> device): words 0..6 payload, word 7 seq
 // line 1 (host -> device): words 8..14 payload, word 15 seq
 // line 2 (host -> device): words 16..22 payload, word 23 seq
-// line 3 (device -> host): word 24 front, word 25 rear, word 26 alive
+// line 3 (device -> host): word 24 front, word 25 rear, word 26 alive, word 27 info = (TPC_MPC_FLAG_* << 32) | iterations
 enum : int {
     kW_HorizonQuit = 0,   // low 32 bits horizon, high 32 bits quit flag
     kW_Iters = 1,         // low 32 bits max_iter, high 32 bits smo_iters
     kW_Eps = 2, kW_Step = 3, kW_Wheelbase = 4, kW_Q0 = 5, kW_Q1 = 6, kW_Seq0 = 7,
     kW_R0 = 8, kW_R1 = 9, kW_Lo0 = 10, kW_Lo1 = 11, kW_Hi0 = 12, kW_Hi1 = 13, kW_V = 14, kW_Seq1 = 15,
     kW_Dy = 16, kW_Dphi = 17, kW_Seq2 = 23,
-    kW_Front = 24, kW_Rear = 25, kW_Alive = 26,
+    kW_Front = 24, kW_Rear = 25, kW_Alive = 26, kW_Info = 27,
+    kW_Timing = 28,       // 28..30: the -DTPC_ONE_TIMING diagnostic build's counters
     kReqWords = 24,
 };
 constexpr uint64_t kSentinel = 0x7ff8dead5eedc0deull;   // a NaN payload no solve produces
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(64) void one_shot_kernel(const uint64_t* req, uint6
             g.step = real(kW_Step); g.wheelbase = real(kW_Wheelbase);
             g.q[0] = real(kW_Q0); g.q[1] = real(kW_Q1); g.r[0] = real(kW_R0); g.r[1] = real(kW_R1);
             g.lo[0] = real(kW_Lo0); g.lo[1] = real(kW_Lo1); g.hi[0] = real(kW_Hi0); g.hi[1] = real(kW_Hi1);
-            g.out = mail + kW_Front;   // two 8-byte stores, each atomic for the host: they are the completion signal
+            g.out = mail + kW_Front;   // two 8-byte stores, each atomic for the host: with the info word they are the completion signal
+            g.info = mail + kW_Info;
             Knobs kn;
             kn.eps = real(kW_Eps);
             const uint64_t its = field(kW_Iters);
@@ -136,13 +138,14 @@ __global__ __launch_bounds__(64) void one_shot_kernel(const uint64_t* req, uint6
 #ifdef TPC_ONE_TIMING
             const uint64_t t_done = clock64();
             if (lane == 0) {
-                sys_store(mail + 27, sys_load(mail + 27) + (t_loops - t_seen));
-                sys_store(mail + 28, sys_load(mail + 28) + (t_done - t_loops));
-                sys_store(mail + 29, sys_load(mail + 29) + 1);
+                sys_store(mail + kW_Timing, sys_load(mail + kW_Timing) + (t_loops - t_seen));
+                sys_store(mail + kW_Timing + 1, sys_load(mail + kW_Timing + 1) + (t_done - t_loops));
+                sys_store(mail + kW_Timing + 2, sys_load(mail + kW_Timing + 2) + 1);
             }
 #endif
         } else if (lane < 2) {
             sys_store(mail + kW_Front + lane, 0x7ff8000000000badull);   // the host never asks this
+            if (lane == 0) sys_store(mail + kW_Info, 0ull);
         }
         idle_since = wall_clock64();
         polls = 0;
@@ -236,13 +239,19 @@ int launch_path(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double dy
     // (a stream of its own: the resident wave occupies the other one for as long as it lives)
     OneShot* o = h->one;
     if (!o->launch_stream) HIP_TRY(h, hipStreamCreateWithFlags(&o->launch_stream, hipStreamNonBlocking));
+    // the iteration count lands in the pinned block like the outputs; the flag word of the handle is copied
+    // there behind the kernels (words 40, 41 of the block: bytes 64.. of this path's half)
+    volatile uint32_t* extra = (volatile uint32_t*)(hp + 64);
+    const uint32_t sentinel_flags = 0xffffffffu;
+    extra[0] = 0; extra[2] = sentinel_flags;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
     StreamOrderScope order(h, o->launch_stream);
-        int rc = order.begin();
+    int rc = order.begin();
     if (rc) return rc;
-    h->collect_flags = false;
-    rc = compact_launch(h, &q, 1, dp, dp + es, dp + 2 * es, dp + 3 * es, dp + 4 * es, nullptr, o->launch_stream);
-    h->collect_flags = true;
+    HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), o->launch_stream));
+    rc = compact_launch(h, &q, 1, dp, dp + es, dp + 2 * es, dp + 3 * es, dp + 4 * es, (int32_t*)(dp + 64), o->launch_stream);
     if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync((void*)(hp + 72), h->ws_words + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, o->launch_stream));
     rc = order.end();
     if (rc) return rc;
     bool done = false;
@@ -255,9 +264,13 @@ int launch_path(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double dy
             const volatile uint32_t* o = (const volatile uint32_t*)(hp + 3 * es);
             done = o[0] != sentinel32 && o[1] != sentinel32;
         }
+        done = done && extra[2] != sentinel_flags;
         if (!done && (it & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
     }
     if (!done) HIP_TRY(h, hipStreamSynchronize(o->launch_stream));
+    h->one_flags = extra[2];
+    h->one_iters = (int32_t)extra[0];
+    h->one_valid = true;
     if (q.dtype == TPC_MPC_F64) { *front = ((double*)hp)[3]; *rear = ((double*)hp)[4]; }
     else { *front = ((float*)hp)[3]; *rear = ((float*)hp)[4]; }
     return TPC_MPC_OK;
@@ -271,8 +284,8 @@ void one_shot_destroy(tpc_mpc_context* h) {
 #ifdef TPC_ONE_TIMING
     {
         volatile uint64_t* m = mailbox(h);
-        if (m[29]) fprintf(stderr, "[one timing] %llu solves: request seen -> loops %.0f clocks, loops -> result stored %.0f clocks\n",
-                           (unsigned long long)m[29], (double)m[27] / m[29], (double)m[28] / m[29]);
+        if (m[kW_Timing + 2]) fprintf(stderr, "[one timing] %llu solves: request seen -> loops %.0f clocks, loops -> result stored %.0f clocks\n",
+                           (unsigned long long)m[kW_Timing + 2], (double)m[kW_Timing] / m[kW_Timing + 2], (double)m[kW_Timing + 1] / m[kW_Timing + 2]);
     }
 #endif
     if (o->stream) {
@@ -344,7 +357,7 @@ int one_shot_solve(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double
     volatile uint64_t* rq = request_lines(h);   // write-only for the host when it is device memory (reads over the BAR are slow)
     auto put = [&](int w, double x) { uint64_t b; std::memcpy(&b, &x, 8); rq[w] = b; };
     const uint64_t prev = o->seq, seq = ++o->seq;
-    m[kW_Front] = kSentinel; m[kW_Rear] = kSentinel;
+    m[kW_Front] = kSentinel; m[kW_Rear] = kSentinel; m[kW_Info] = kSentinel;
     rq[kW_HorizonQuit] = (uint64_t)(uint32_t)p->horizon;
     rq[kW_Iters] = (uint64_t)(uint32_t)p->max_iter | ((uint64_t)(uint32_t)p->smo_iters << 32);
     put(kW_Eps, p->eps); put(kW_Step, p->step_size); put(kW_Wheelbase, p->wheelbase);
@@ -363,12 +376,13 @@ int one_shot_solve(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double
     }
     const auto t0 = std::chrono::steady_clock::now();
     int restarts = 0;
+    auto answered = [&]() { return m[kW_Front] != kSentinel && m[kW_Rear] != kSentinel && m[kW_Info] != kSentinel; };
     for (uint32_t it = 1;; ++it) {
-        if (m[kW_Front] != kSentinel && m[kW_Rear] != kSentinel) break;
+        if (answered()) break;
         if ((it & 1023u) != 0) continue;
         if (!m[kW_Alive]) {
             // the wave left (idle timeout) just as the request was posted: start another one for it
-            if (m[kW_Front] != kSentinel && m[kW_Rear] != kSentinel) break;
+            if (answered()) break;
             if (++restarts > 3) { o->disabled = true; return launch_path(h, p, v, dy, dphi, front, rear); }
             int rc = start_kernel(h, o, p->horizon, prev);
             if (rc) return rc;
@@ -381,13 +395,17 @@ int one_shot_solve(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double
             o->disabled = true;
             int rc = stop_kernel(h, o);
             if (rc) return rc;
-            if (m[kW_Front] != kSentinel && m[kW_Rear] != kSentinel) break;   // it did answer in the end
+            if (answered()) break;   // it did answer in the end
             return launch_path(h, p, v, dy, dphi, front, rear);
         }
     }
     uint64_t fb = m[kW_Front], rb = m[kW_Rear];
     std::memcpy(front, &fb, 8);
     std::memcpy(rear, &rb, 8);
+    const uint64_t info = m[kW_Info];
+    h->one_flags = (uint32_t)(info >> 32);
+    h->one_iters = (int32_t)(uint32_t)info;
+    h->one_valid = true;
     return TPC_MPC_OK;
 }
 

@@ -171,6 +171,19 @@ void TrajectoryPointController::mpcControllerTobi(double v, double delta_y, doub
     if (rc != TPC_MPC_OK) {
         logger.error("trajectory_point_controller") << "tpc_mpc_solve_one: " << tpc_mpc_last_error(solver_);
         *steering_front = *steering_rear = std::nan("");   // surfaces through the NaN check in cycle()
+        return;
+    }
+    // dlib reports nothing; the reference only logs NaN outputs behind the call (:101-103).  A NaN / Inf input
+    // comes back as the start point (0, 0) -- which that check cannot see -- and a solve cut off by
+    // mpcMaxIterations as its last iterate: both are logged here, neither is fatal.
+    uint32_t flags = 0;
+    int32_t iters = 0;
+    if (tpc_mpc_last_flags(solver_, &flags, &iters) == TPC_MPC_OK && flags != 0) {
+        if (flags & TPC_MPC_FLAG_NONFINITE)
+            logger.warn("mpcControllerTobi") << "non-finite input (v " << v << ", delta_y " << delta_y << ", delta_phi "
+                                             << delta_phi << "): steering left at the start point";
+        if (flags & TPC_MPC_FLAG_MAX_ITER)
+            logger.warn("mpcControllerTobi") << "stopped by mpcMaxIterations after " << iters << " iterations";
     }
 }
 

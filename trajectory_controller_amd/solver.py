@@ -36,7 +36,7 @@ class MpcSolver:
         self.device = int(device)
         self.dtype = {"f64": capi.F64, "f32": capi.F32}[dtype]
         self.algo = {"auto": capi.ALGO_AUTO, "wave": capi.ALGO_WAVE, "lane": capi.ALGO_LANE,
-                     "lane_fma": capi.ALGO_LANE_FMA}[algo]
+                     "lane_fma": capi.ALGO_LANE_FMA, "group": capi.ALGO_GROUP}[algo]
         self.params = capi.default_params(horizon, self.dtype, self.algo, **params)
         self.last_flags = 0
         self.rank, self.world = 0, 1     # a handle without a communicator is a world of one
@@ -104,6 +104,14 @@ class MpcSolver:
         return f.value, r.value
 
     solve_one = mpc_controller_tobi
+
+    def last_solve_one_flags(self):
+        """(flags, iterations) of the last solve_one (tpc_mpc_last_flags): capi.FLAG_NONFINITE when the speed
+        or the target was NaN / Inf (the call returned dlib's untouched start point), capi.FLAG_MAX_ITER when
+        max_iter cut the solve off."""
+        f, it = C.c_uint32(), C.c_int32()
+        self._check(self._lib.tpc_mpc_last_flags(self._h, C.byref(f), C.byref(it)))
+        return f.value, it.value
 
     def set_option(self, option: int, value: int):
         """tpc_mpc_set_option: capi.OPT_WAVE_GROUP (0 auto, 1, 2, 4), capi.OPT_MAILBOX_HOST (0 / 1)."""

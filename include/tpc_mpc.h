@@ -354,7 +354,7 @@ int tpc_mpc_reserve(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n, int me
  *   TPC_MPC_OPT_MAILBOX_HOST 1 = tpc_mpc_solve_one's request lines live in pinned host memory even where the
  *                            CPU could write device memory through the BAR (0, default: device memory where
  *                            hipDeviceAttributeIsLargeBar says so).  Restarts the resident wavefront. */
-typedef enum tpc_mpc_option { TPC_MPC_OPT_WAVE_GROUP = 1, TPC_MPC_OPT_MAILBOX_HOST = 2, TPC_MPC_OPT_GROUP_LANES = 3, TPC_MPC_OPT_GROUP_WAVES = 4 } tpc_mpc_option;
+typedef enum tpc_mpc_option { TPC_MPC_OPT_WAVE_GROUP = 1, TPC_MPC_OPT_MAILBOX_HOST = 2, TPC_MPC_OPT_GROUP_LANES = 3 } tpc_mpc_option;
 int tpc_mpc_set_option(tpc_mpc_handle h, int option, int64_t value);
 
 /* ---- measurement ------------------------------------------------------------------------------ */

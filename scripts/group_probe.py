@@ -10,7 +10,7 @@ args = sys.argv[1:]
 dtype = args.pop(0) if args and args[0] in ("f64", "f32") else "f64"
 H = int(args[0]); Gs = [int(x) for x in args[1].split(",")]; ns = [int(x) for x in args[2].split(",")]
 check = len(args) > 3 and args[3] == "check"
-waves = [int(x) for x in args[4].split(",")] if len(args) > 4 else [0]
+waves = [0]
 tdt = torch.float64 if dtype == "f64" else torch.float32
 for n in ns:
     v, dy, dphi = compact_inputs(H, n)
@@ -26,7 +26,6 @@ for n in ns:
         with MpcSolver(horizon=H, algo=algo, dtype=dtype) as s:
             if G:
                 s.set_option(capi.OPT_GROUP_LANES, G)
-                s.set_option(capi.OPT_GROUP_WAVES, W)
             s.set_profiling(True)
             best = (1e9, 0, 0)
             for _ in range(3):

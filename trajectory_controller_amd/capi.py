@@ -17,7 +17,7 @@ OK = 0
 F64, F32 = 0, 1
 HOST, DEVICE = 0, 1
 ALGO_AUTO, ALGO_WAVE, ALGO_LANE, ALGO_LANE_FMA, ALGO_GROUP = 0, 1, 2, 3, 4
-OPT_WAVE_GROUP, OPT_MAILBOX_HOST, OPT_GROUP_LANES, OPT_GROUP_WAVES = 1, 2, 3, 4
+OPT_WAVE_GROUP, OPT_MAILBOX_HOST, OPT_GROUP_LANES = 1, 2, 3
 FLAG_NONFINITE, FLAG_MAX_ITER, FLAG_BAD_MODEL = 0x1, 0x2, 0x4
 
 STATUS_NAMES = {0: "OK", 1: "BAD_ARG", 2: "BAD_WEIGHTS", 3: "BAD_BOUNDS", 4: "BAD_HORIZON",

@@ -18,6 +18,8 @@
 //        combining with the summary d lanes away is `z += z' + (d L a) y';  y += y'`: log2 G steps of two
 //        DPP-moved values and three fused multiply-adds, out-of-group lanes cancelled by 0 / 1 weights --
 //     3. the correction of the L local values by the incoming state (an arithmetic progression: one addition each).
+// Where G does not divide H the chunks are L = ceil(H / G) steps and the last ones are padded with dummy steps that
+// cost nothing in the objective and never move (GroupPlan).
 // Forward: (Z, Y) = predicted state error;  backward: (N0, N1) = the costate.  The stop test (the largest free
 // gradient component against eps) is a per-lane maximum and one OR over the group, the arg-max is not needed in this
 // phase.  30 VALU instructions per horizon step against LANE_FMA's 25, plus ~36 (G = 4) for the two scans: at N = 20
@@ -64,22 +66,29 @@ template <int G> TPC_DEV int group_or(int x) {
     return x;
 }
 
+// ballot of a predicate as the compare that produced it leaves it (the int-typed __ballot re-materialises it)
+TPC_DEV unsigned long long ballot_b(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+
 #ifndef TPC_GROUP_OCC
 #define TPC_GROUP_OCC 0
 #endif
 template <typename T, int H, int G> struct GroupPlan {
     static_assert(G == 2 || G == 4 || G == 8 || G == 16, "a group is 2, 4, 8 or 16 lanes of one DPP row");
-    static_assert(H % G == 0, "chunks of equal length");
-    static constexpr int L = H / G;            // horizon steps per lane
+    static constexpr int L = (H + G - 1) / G;  // horizon steps per lane
+    // Where G does not divide H the last chunks are padded with DUMMY steps (global index >= H): their controls rest at
+    // u = 0, their stage cost is zero (nothing enters the backward recurrence) and their gradient is multiplied by zero
+    // (no step, no say in the stop test).  What a dummy step does to the forward state is seen by no real step.
+    static constexpr int pad = G * L - H;
+    static constexpr int dl0 = pad >= L ? 0 : L - pad;   // local steps dl0 .. L-1 are dummy in some lane
     static constexpr int NG = kWave / G;       // instances per wavefront
     // scan steps after the initial shift by one lane: the exclusive prefix of lane p spans up to G - 1 lanes, and each
     // step doubles what a lane's partial result spans (1 after the shift)
     static constexpr int steps = G == 2 ? 0 : (G == 4 ? 2 : (G == 8 ? 3 : 4));
-    // state of a lane: x, v, the local forward and backward passes: 8 L values (+ ~25 constants)
-    static constexpr int words = sizeof(T) == 8 ? 2 : 1;
-    static constexpr int est_regs = (8 * L + 28) * words + 24;
-    static constexpr int occ_default = est_regs <= 128 ? 4 : (est_regs <= 168 ? 3 : (est_regs <= 256 ? 2 : 1));
-    static constexpr int occ = TPC_GROUP_OCC > 0 ? TPC_GROUP_OCC : occ_default;   // wavefronts per SIMD the kernel is built for
+    // ONE wavefront per SIMD, like LANE_FMA: the family's place is the batch that cannot fill the chip's lanes, where
+    // what counts is how fast a lone wavefront iterates -- measured (N = 20, G = 4, 16 384 / 32 768 / 65 536 instances,
+    // persistent grids of one / two / three wavefronts per SIMD): 1.65 / 1.73 / 2.42 ms against 1.64 / 1.82 / 2.50 and
+    // 1.63 / 1.87 / 2.87 -- so the kernel is built with the whole register file and no scratch
+    static constexpr int occ = TPC_GROUP_OCC > 0 ? TPC_GROUP_OCC : 1;
 };
 #ifdef TPC_GROUP_REFILL_BATCH
 template <int G> struct GroupRefillBatch { static constexpr int value = TPC_GROUP_REFILL_BATCH; };
@@ -120,11 +129,21 @@ __global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel
         wb[s] = p + (1 << s) < G ? (T)1 : (T)0;
     }
     const T wf0 = p >= 1 ? (T)1 : (T)0, wb0 = p + 1 < G ? (T)1 : (T)0;   // the initial shift by one lane
+    // 1 for a real step, 0 for a dummy one (local steps DL0 .. L-1 only; the others are real in every lane), and the
+    // stage weights of those steps
+    constexpr int DL0 = P::dl0, ND = L - DL0 > 0 ? L - DL0 : 1;
+    T live[ND], gq0d[ND], gq1d[ND];
+#pragma unroll
+    for (int l = DL0; l < L; ++l) {
+        live[l - DL0] = p * L + l < H ? (T)1 : (T)0;
+        gq0d[l - DL0] = m.gq0 * live[l - DL0];
+        gq1d[l - DL0] = m.gq1 * live[l - DL0];
+    }
     // per instance: d L a times the weight, and the start of the local forward pass (the true start in chunk 0)
     T cf[KA], cb[KA];
 #pragma unroll
     for (int s = 0; s < KS; ++s) cf[s] = cb[s] = (T)0;
-    T zst = (T)0, yst = (T)0;
+    T zst = (T)0, yst = (T)0, la = (T)0;
 
     T x[2 * L], v[2 * L];
     T x0_prev[2] = {(T)0, (T)0};
@@ -148,8 +167,8 @@ __global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel
 #pragma unroll 1
     while (true) {
         // ---- refill: groups without an instance take the next entries of the longest-first queue
-        const unsigned long long want = __ballot(!have && !exhausted);
-        if (want != 0ull && (__popcll(want) >= GroupRefillBatch<G>::value * G || __ballot(have) == 0ull)) {
+        const unsigned long long want = ballot_b(!have && !exhausted);
+        if (want != 0ull && (__popcll(want) >= GroupRefillBatch<G>::value * G || ballot_b(have) == 0ull)) {
             ++refills;
             const uint32_t cnt = (uint32_t)__popcll(want) / G;
             const uint32_t rank = (uint32_t)__popcll(want & ((1ull << gbase) - 1ull)) / G;
@@ -166,7 +185,10 @@ __global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel
                     const T* rec = recs + k * RL;
                     const T vk = ((const T*)g.v)[k], ty = ((const T*)g.dy)[k], tphi = ((const T*)g.dphi)[k];
 #pragma unroll
-                    for (int q = 0; q < 2 * L; ++q) x[q] = rec[2 * L * p + q];
+                    for (int q = 0; q < 2 * L; ++q) {
+                        if (q / 2 < DL0) x[q] = rec[2 * L * p + q];
+                        else x[q] = p * L + q / 2 < H ? rec[2 * L * p + q] : m.xz(q & 1);
+                    }
                     const T lambda = rec[2 * H];
                     const uint64_t meta = load_meta<T>(rec + 2 * H + 1);
                     iter = (uint32_t)meta;
@@ -178,11 +200,17 @@ __global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel
                     m.fwd_init(dummy_z, dummy_y);
                     zst = p == 0 ? dummy_z : (T)0;
                     yst = p == 0 ? dummy_y : (T)0;
+                    la = (T)L * m.a;
+                    if constexpr (G == 4) {   // (the shortcut scan: one chunk of L steps sits behind the moved pair)
+                        cf[0] = wf[1] * la;
+                        cb[0] = wb[1] * la;
+                    } else {
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) {
-                        const T dla = (T)((1 << s) * L) * m.a;
-                        cf[s] = wf[s] * dla;
-                        cb[s] = wb[s] * dla;
+                        for (int s = 0; s < KS; ++s) {
+                            const T dla = (T)((1 << s) * L) * m.a;
+                            cf[s] = wf[s] * dla;
+                            cb[s] = wb[s] * dla;
+                        }
                     }
                     if ((meta & kMetaStopped) || iter >= kn.max_iter) {
                         // (ub_cd_kernel publishes these itself and keeps them out of the queue; kept for a queue that holds one)
@@ -196,8 +224,8 @@ __global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel
                 }
             }
         }
-        if (__ballot(have) == 0ull) {
-            if (__ballot(!exhausted) == 0ull) break;
+        if (ballot_b(have) == 0ull) {
+            if (ballot_b(!exhausted) == 0ull) break;
             continue;
         }
 
@@ -215,13 +243,22 @@ __global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel
             // ---- exclusive scan of the chunk summaries over the group: (ez, ey) = state entering this chunk
             //      minus what the local start already carried
             T ez = wf0 * group_mov<GroupDpp<G, 1, false>::ctrl>(Z), ey = wf0 * group_mov<GroupDpp<G, 1, false>::ctrl>(Y);
-            static_for<KS>([&](auto sc) {
-                constexpr int s = decltype(sc)::value;
-                constexpr int ctrl = GroupDpp<G, (1 << s), false>::ctrl;
-                const T oz = group_mov<ctrl>(ez), oy = group_mov<ctrl>(ey);
-                ez = ub::fma_(cf[s], oy, ub::fma_(wf[s], oz, ez));
-                ey = ub::fma_(wf[s], oy, ey);
-            });
+            if constexpr (G == 4) {
+                // four lanes: the pair (lane below, this lane) combined once, moved two lanes up and put in front of the
+                // single lane below -- one move fewer than shifting first and doubling twice
+                const T iz = ub::fma_(la, ey, ez + Z), iy = ey + Y;
+                const T oz = group_mov<GroupDpp<G, 2, false>::ctrl>(iz), oy = group_mov<GroupDpp<G, 2, false>::ctrl>(iy);
+                ez = ub::fma_(cf[0], oy, ub::fma_(wf[1], oz, ez));
+                ey = ub::fma_(wf[1], oy, ey);
+            } else {
+                static_for<KS>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    constexpr int ctrl = GroupDpp<G, (1 << s), false>::ctrl;
+                    const T oz = group_mov<ctrl>(ez), oy = group_mov<ctrl>(ey);
+                    ez = ub::fma_(cf[s], oy, ub::fma_(wf[s], oz, ez));
+                    ey = ub::fma_(wf[s], oy, ey);
+                });
+            }
             // ---- backward recurrence of the chunk on the corrected states, from a zero costate (mpc.h:278-281)
             x0_prev[0] = x[0]; x0_prev[1] = x[1];
             const T aey = m.a * ey;
@@ -233,35 +270,45 @@ __global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel
             for (int l = L - 1; l >= 0; --l) {
                 const T zt = wz[l] + zc;
                 if (l > 0) zc = zc - aey;
-                const T e1 = ub::fma_(m.gq1, wy[l], e1c);
+                T e1;
+                if (l >= DL0) e1 = ub::fma_(gq1d[l - DL0], wy[l], e1c * live[l - DL0]); else e1 = ub::fma_(m.gq1, wy[l], e1c);
                 const T t1 = ub::fma_(m.a, n0, n1) + e1;
-                n0 = ub::fma_(m.gq0, zt, n0);
+                if (l >= DL0) n0 = ub::fma_(gq0d[l - DL0], zt, n0); else n0 = ub::fma_(m.gq0, zt, n0);
                 n1 = t1;
                 nl0[l] = n0; nl1[l] = n1;
             }
             // ---- exclusive suffix scan: (f0, f1) = costate at the first step of the next chunk
             T f0 = wb0 * group_mov<GroupDpp<G, 1, true>::ctrl>(n0), f1 = wb0 * group_mov<GroupDpp<G, 1, true>::ctrl>(n1);
-            static_for<KS>([&](auto sc) {
-                constexpr int s = decltype(sc)::value;
-                constexpr int ctrl = GroupDpp<G, (1 << s), true>::ctrl;
-                const T o0 = group_mov<ctrl>(f0), o1 = group_mov<ctrl>(f1);
-                f1 = ub::fma_(cb[s], o0, ub::fma_(wb[s], o1, f1));
-                f0 = ub::fma_(wb[s], o0, f0);
-            });
+            if constexpr (G == 4) {
+                const T i1 = ub::fma_(la, f0, f1 + n1), i0 = f0 + n0;
+                const T o0 = group_mov<GroupDpp<G, 2, true>::ctrl>(i0), o1 = group_mov<GroupDpp<G, 2, true>::ctrl>(i1);
+                f1 = ub::fma_(cb[0], o0, ub::fma_(wb[1], o1, f1));
+                f0 = ub::fma_(wb[1], o0, f0);
+            } else {
+                static_for<KS>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    constexpr int ctrl = GroupDpp<G, (1 << s), true>::ctrl;
+                    const T o0 = group_mov<ctrl>(f0), o1 = group_mov<ctrl>(f1);
+                    f1 = ub::fma_(cb[s], o0, ub::fma_(wb[s], o1, f1));
+                    f0 = ub::fma_(wb[s], o0, f0);
+                });
+            }
             // ---- gradient (mpc.h:283), stop test (mpc.h:289-311) and the speculative update (mpc.h:342-343)
+            //      (the costate's first component enters df through a N0 only: a f0 joins the constant term)
             const T af0 = m.a * f0;
+            const T grl1f = af0 + m.grl1;
             T n1c = ub::fma_((T)L, af0, f1);
             T acc0 = (T)0, acc1 = (T)0;
 #pragma unroll
             for (int l = 0; l < L; ++l) {
-                const T N0 = nl0[l] + f0;
                 const T N1 = nl1[l] + n1c;
                 if (l + 1 < L) n1c = n1c - af0;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int q = 2 * l + j;
                     const T xx = x[q];
-                    const T dd = j == 0 ? m.df0(N1, xx) : m.df1(N0, N1, xx);
+                    T dd = j == 0 ? m.df0(N1, xx) : ub::fma_(m.a, nl0[l], ub::fma_(-m.c, N1, ub::fma_(m.grs1, xx, grl1f)));
+                    if (l >= DL0) dd = dd * live[l - DL0];
                     const T vn = m.template project<true>(ub::fma_(-il[j], dd, xx), j);          // mpc.h:342
                     T& acc = j == 0 ? acc0 : acc1;
                     if constexpr (D64) {
@@ -276,14 +323,15 @@ __global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel
             }
             const int go = group_or<G>(tmax(acc0, acc1) >= geps ? 1 : 0);
             ++wave_iters;
-            stop = have && go == 0;                                                 // mpc.h:310-311
             ++iter;
-            cap = have && !stop && iter >= kn.max_iter;                             // mpc.h:271
-            if (__ballot(stop || cap) != 0ull) {
+            const bool ends = go == 0 || iter >= kn.max_iter;                       // mpc.h:310-311, :271
+            if (ballot_b(have && ends) != 0ull) {
+                stop = have && go == 0;
+                cap = have && !stop && iter >= kn.max_iter;
                 if (stop) { publish(x0_prev[0], x0_prev[1], iter - 1); have = false; }
                 if (cap) { flags |= 0x2u; publish(x[0], x[1], iter); have = false; }
-                const unsigned long long waiting = __ballot(!have && !exhausted);
-                if (__popcll(waiting) >= GroupRefillBatch<G>::value * G || __ballot(have) == 0ull) break;
+                const unsigned long long waiting = ballot_b(!have && !exhausted);
+                if (__popcll(waiting) >= GroupRefillBatch<G>::value * G || ballot_b(have) == 0ull) break;
             }
         } while (true);
     }

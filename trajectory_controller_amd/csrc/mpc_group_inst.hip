@@ -21,39 +21,35 @@ namespace {
 
 constexpr int kH = TPC_GROUP_H;
 
-// persistent-wavefront count: what the device holds of this kernel
-template <class Tag, class Kernel> inline int group_grid(Kernel kernel) {
+// compute units of the current device (cached: the query costs tens of microseconds)
+inline int device_cus() {
     constexpr int kMaxDev = 64;
     static int cache[kMaxDev] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (dev >= 0 && dev < kMaxDev && cache[dev] > 0) return cache[dev];
-    int cus = 256, per_cu = 4;
+    int cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWave, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (dev >= 0 && dev < kMaxDev) cache[dev] = cus * per_cu;
-    return cus * per_cu;
+    if (dev >= 0 && dev < kMaxDev) cache[dev] = cus;
+    return cus;
 }
 template <typename T, int G, bool EQB> struct Tag {};
 
+// group sizes built per horizon (measured useful: chunks of 3 .. 10 steps)
+constexpr bool group_built(int H, int G) {
+    return H == 10 ? (G == 2 || G == 4) : (H == 20 || H == 30) ? (G == 2 || G == 4 || G == 8) : (H == 40 && (G == 4 || G == 8));
+}
+
 template <typename T, int G, bool EQB>
-hipError_t pg(const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s, int waves_per_simd) {
-    if constexpr (kH % G != 0) {
+hipError_t pg(const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
+    if constexpr (!group_built(kH, G)) {
         return hipErrorInvalidValue;
     } else {
         constexpr int NG = GroupPlan<T, kH, G>::NG;
         const int64_t need = (a.n + NG - 1) / NG;
-        int cap = group_grid<Tag<T, G, EQB>>(group_pg_kernel<T, kH, G, EQB>);
-        // (a smaller persistent grid -- fewer wavefronts per SIMD, each faster -- when the caller asks for it)
-        if (waves_per_simd > 0) {
-            int cus = 256;
-            hipDeviceProp_t prop;
-            int dev = 0;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-            const int lim = cus * 4 * waves_per_simd;
-            if (lim < cap) cap = lim;
-        }
+        // persistent grid: one wavefront per SIMD (the kernel is built for that, GroupPlan::occ)
+        const int cap = device_cus() * 4 * GroupPlan<T, kH, G>::occ;
         hipLaunchKernelGGL((group_pg_kernel<T, kH, G, EQB>), dim3((unsigned)(need < cap ? need : cap)), dim3(kWave), 0, s, a, k,
                            (const T*)ws.state, (const uint32_t*)ws.order, ws.ticket, ws.stats, order_queue_len(ws.sort_temp));
         return hipGetLastError();
@@ -61,26 +57,26 @@ hipError_t pg(const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStre
 }
 
 template <typename T, bool EQB>
-hipError_t pg_any(int G, const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s, int wps) {
+hipError_t pg_any(int G, const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
     switch (G) {
-        case 2: return pg<T, 2, EQB>(a, k, ws, s, wps);
-        case 4: return pg<T, 4, EQB>(a, k, ws, s, wps);
-        case 8: return pg<T, 8, EQB>(a, k, ws, s, wps);
+        case 2: return pg<T, 2, EQB>(a, k, ws, s);
+        case 4: return pg<T, 4, EQB>(a, k, ws, s);
+        case 8: return pg<T, 8, EQB>(a, k, ws, s);
     }
     return hipErrorInvalidValue;
 }
 
 }  // namespace
 
-// G lanes per instance (2, 4 or 8, dividing the horizon).  `waves_per_simd` > 0 caps the persistent grid.
-hipError_t TPC_CAT(group_compact_h, TPC_GROUP_H)(int dtype, int equal_bounds, int G, int waves_per_simd, const CompactArgs& a,
+// G lanes per instance (2, 4 or 8: group_built).
+hipError_t TPC_CAT(group_compact_h, TPC_GROUP_H)(int dtype, int equal_bounds, int G, const CompactArgs& a,
                                                   const Knobs& k, const Workspace& ws, hipStream_t s) {
     if (a.n <= 0) return hipSuccess;
-    if (kH % G != 0 || (G != 2 && G != 4 && G != 8)) return hipErrorInvalidValue;
+    if (!group_built(kH, G)) return hipErrorInvalidValue;
     hipError_t e = TPC_CAT(ub_phase1_h, TPC_GROUP_H)(dtype, equal_bounds, a, k, ws, s);
     if (e != hipSuccess) return e;
-    if (dtype == 0) e = equal_bounds ? pg_any<double, true>(G, a, k, ws, s, waves_per_simd) : pg_any<double, false>(G, a, k, ws, s, waves_per_simd);
-    else e = pg_any<float, true>(G, a, k, ws, s, waves_per_simd);
+    if (dtype == 0) e = equal_bounds ? pg_any<double, true>(G, a, k, ws, s) : pg_any<double, false>(G, a, k, ws, s);
+    else e = pg_any<float, true>(G, a, k, ws, s);
     if (e != hipSuccess) return e;
     // a batch the screen of the select-free stop test refused: LANE_FMA's exact build, on the same records
     e = TPC_CAT(ub_exact_h, TPC_GROUP_H)(dtype, equal_bounds, a, k, ws, s);

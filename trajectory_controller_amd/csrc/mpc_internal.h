@@ -68,7 +68,6 @@ struct Workspace {
     hipEvent_t* ev;
     int wave_group = 0;   // TPC_MPC_OPT_WAVE_GROUP: 0 auto, 1 / 2 / 4 instances per wavefront
     int group_lanes = 0;  // GROUP: lanes per instance (2 / 4 / 8) for this horizon
-    int group_waves = 0;  // GROUP: cap on the persistent grid in wavefronts per SIMD (0: none)
 };
 
 // WAVE work queue (mpc_wave.h): the dynamic part of the queue is dealt out through kQueueTickets counters on

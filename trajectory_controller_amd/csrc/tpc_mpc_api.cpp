@@ -4,6 +4,7 @@
 // solves over RCCL: tpc_mpc_comm.cpp; the resident single-solve kernel: tpc_mpc_one.hip.)
 #include "tpc_mpc_context.h"
 #include "tpc_mpc_experimental.h"
+#include "auto_table.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -26,7 +27,7 @@ TPC_DECL_H(4) TPC_DECL_H(5) TPC_DECL_H(10) TPC_DECL_H(20) TPC_DECL_H(30) TPC_DEC
 TPC_DECL_H(4) TPC_DECL_H(5) TPC_DECL_H(10) TPC_DECL_H(20)
 #undef TPC_DECL_H
 // GROUP: G lanes per instance (mpc_group_inst.hip), compact form, the horizons a power of two divides into chunks
-#define TPC_DECL_H(h) hipError_t group_compact_h##h(int, int, int, int, const CompactArgs&, const Knobs&, const Workspace&, hipStream_t);
+#define TPC_DECL_H(h) hipError_t group_compact_h##h(int, int, int, const CompactArgs&, const Knobs&, const Workspace&, hipStream_t);
 TPC_DECL_H(10) TPC_DECL_H(20) TPC_DECL_H(30) TPC_DECL_H(40)
 #undef TPC_DECL_H
 
@@ -64,11 +65,22 @@ const int32_t* take_hint(tpc_mpc_context* h, int64_t n) {
 
 // Lanes per instance of the GROUP family for horizon H: what TPC_MPC_OPT_GROUP_LANES pins if it divides H, else the
 // measured best; 0 where the family has no kernel (N = 4, 5 and the non-specialised horizons).
-int group_lanes(const tpc_mpc_context* h, int H) {
+int group_lanes(const tpc_mpc_context* h, int H, int dtype = 0, int64_t n = 0) {
     if (H != 10 && H != 20 && H != 30 && H != 40) return 0;
+    // (what mpc_group_inst.hip builds: chunks of 3 .. 10 steps, padded where G does not divide H)
+    auto built = [&](int G) { return H == 10 ? (G == 2 || G == 4) : H == 40 ? (G == 4 || G == 8) : (G == 2 || G == 4 || G == 8); };
     const int want = h->opt_group_lanes;
-    if ((want == 2 || want == 4 || want == 8) && H % want == 0) return want;
-    return H == 40 ? 8 : (H == 20 ? 4 : 2);
+    if (want > 0 && built(want)) return want;
+    // the measured best for this batch size (auto_table.h); where a row names a size that is not built, the next one down
+    for (const AutoRow& r : kAutoTable) {
+        if (r.dtype != dtype || r.horizon != H || n <= 0) continue;
+        auto scaled = [&](int64_t at) { return at * h->cu_count / 256 < at ? at * h->cu_count / 256 : at; };
+        int g = n < scaled(r.group8_below) ? 8 : (n < scaled(r.group4_below) ? 4 : 2);
+        while (g > 2 && !built(g)) g /= 2;
+        if (!built(g)) g = 4;
+        return g;
+    }
+    return H == 40 ? 8 : (H == 10 ? 2 : 4);
 }
 
 // LANE needs enough instances to give every SIMD a full wavefront; below that WAVE's
@@ -111,21 +123,22 @@ int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n, int d
     int64_t crossover = I * H > kWave ? two_per_lane_cross
                         : ((H >= 20 || paired) ? queue_cross : lanes * 7 / 16);
     if (fma_ok && compact) {
-        // compact form: the other side is LANE_FMA, twice as fast as LANE, so WAVE gives way earlier where the two
-        // meet below the queue's limit (profiles/r03_crossover.txt, kernel times in ms at 16 384 / 24 576 / 32 768
-        // instances, WAVE against LANE_FMA):
-        //   fp64  N=4: .083/.128 .123/.134 .147/.140   N=5: .098/.149 .147/.156 .171/.164   N=10: .36/.52 .49/.53 .65/.53
-        //         N=20: 2.9/3.6 4.1/3.6 5.2/3.6        N=30, 40: WAVE up to 32 768
-        //   fp32  N=4: .10/.13 .136/.139 .175/.143     N=5: .13/.15 .19/.16 .24/.17         N=10: .46/.57 .67/.57 .88/.58
-        //         N=20, 30, 40: WAVE up to 32 768
+        // compact form: WAVE, then GROUP with fewer and fewer lanes per instance, then LANE_FMA, at crossovers measured
+        // per dtype and horizon (auto_table.h, generated by scripts/measure_crossover.py; profiles/r04_crossover.txt).
+        // N = 4 and 5 have no GROUP kernels (profiles/r03_crossover.txt: WAVE up to 28 672 in fp64, 24 576 / 21 504 in fp32).
         const bool d = dtype == TPC_MPC_F64;
+        auto scaled = [&](int64_t at) { return at * h->cu_count / 256 < at ? at * h->cu_count / 256 : at; };
+        for (const AutoRow& r : kAutoTable) {
+            if (r.dtype != dtype || r.horizon != H) continue;
+            if (n < scaled(r.wave_below) && n <= kWaveQueueMaxInstances) return TPC_MPC_ALGO_WAVE;
+            if (n < scaled(r.group2_below)) return TPC_MPC_ALGO_GROUP;
+            return lane;
+        }
         int64_t at = kWaveQueueMaxInstances + 1;
         if (d && (H == 4 || H == 5)) at = 28672;
-        if (d && H == 10) at = 26624;
-        if (d && H == 20) at = 21504;
         if (!d && H == 4) at = 24576;
-        if (!d && (H == 5 || H == 10)) at = 21504;
-        crossover = at * h->cu_count / 256 < at ? at * h->cu_count / 256 : at;
+        if (!d && H == 5) at = 21504;
+        crossover = scaled(at);
     }
     return (n >= crossover || !wave_ok) ? lane : TPC_MPC_ALGO_WAVE;
 }
@@ -169,7 +182,7 @@ hipError_t dispatch_compact(int algo, int H, int dtype, const CompactArgs& a, co
                                               : ((float)a.lo[0] == (float)a.lo[1] && (float)a.hi[0] == (float)a.hi[1]);
         if (algo == TPC_MPC_ALGO_GROUP) {
             switch (H) {
-#define X(h) case h: return group_compact_h##h(dtype, eqb ? 1 : 0, ws.group_lanes, ws.group_waves, a, k, ws, s);
+#define X(h) case h: return group_compact_h##h(dtype, eqb ? 1 : 0, ws.group_lanes, a, k, ws, s);
                 X(10) X(20) X(30) X(40)
 #undef X
             }
@@ -217,8 +230,7 @@ int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n,
     ws->capacity_bytes = 0;
     ws->ev = h->profiling ? h->ev : nullptr;
     ws->wave_group = h->opt_wave_group;
-    ws->group_lanes = group_lanes(h, H);
-    ws->group_waves = h->opt_group_waves;
+    ws->group_lanes = group_lanes(h, H, dtype, n);
     h->ev_valid = h->profiling;
     h->last_algo = algo;
     ws->keys = ws->rank = ws->order = nullptr;
@@ -977,10 +989,6 @@ int tpc_mpc_set_option(tpc_mpc_handle h, int option, int64_t value) {
                 if (value != 0 && value != 2 && value != 4 && value != 8)
                     return fail(h, TPC_MPC_ERR_BAD_ARG, "TPC_MPC_OPT_GROUP_LANES takes 0, 2, 4 or 8");
                 h->opt_group_lanes = (int)value;
-                return TPC_MPC_OK;
-            case TPC_MPC_OPT_GROUP_WAVES:
-                if (value < 0 || value > 8) return fail(h, TPC_MPC_ERR_BAD_ARG, "TPC_MPC_OPT_GROUP_WAVES takes 0 .. 8");
-                h->opt_group_waves = (int)value;
                 return TPC_MPC_OK;
             case TPC_MPC_OPT_MAILBOX_HOST:
                 HIP_TRY(h, hipSetDevice(h->device));

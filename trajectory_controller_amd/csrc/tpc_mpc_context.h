@@ -82,7 +82,6 @@ struct tpc_mpc_context {
     int opt_wave_group = 0;          // 0 auto, 1 / 2 / 4 instances per wavefront (fp64 WAVE)
     bool opt_mailbox_host = false;   // solve_one's request lines in pinned host memory
     int opt_group_lanes = 0;         // GROUP: 0 auto, 2 / 4 / 8 lanes per instance
-    int opt_group_waves = 0;         // GROUP: 0 = what the device holds, else wavefronts per SIMD of the persistent grid
 };
 
 namespace tpc {

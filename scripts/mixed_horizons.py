@@ -10,7 +10,7 @@ parts = [compact_inputs(H, per) for H in Hs]
 v, dy, dphi = (np.concatenate([p[c] for p in parts]) for c in range(3))
 hz = np.repeat(np.array(Hs), per)
 perm = np.random.default_rng(3).permutation(len(hz))
-for dtype in ("f64", "f32"):
+for dtype in (sys.argv[1:] or ["f64", "f32"]):
     tdt = torch.float64 if dtype == "f64" else torch.float32
     tv, ty, tp = (torch.from_numpy(a[perm]).to("cuda", dtype=tdt) for a in (v, dy, dphi))
     with MpcSolver(horizon=20, dtype=dtype) as s:

@@ -567,6 +567,23 @@ def test_solve_one_edge_cases_and_flags(torch_cuda, oracle, H, path):
         assert abs(f - of[0]) <= 1e-9 and abs(r - orr[0]) <= 1e-9 and s.last_solve_one_flags() == (0, int(oit3[0]))
 
 
+def test_resident_off_survives_a_mailbox_restart(torch_cuda):
+    """tpc_mpc_set_resident(0) -- every solve_one an ordinary launch -- must still hold after
+    tpc_mpc_set_option(TPC_MPC_OPT_MAILBOX_HOST), which tears the single-solve state down and sets it up again.
+    Observable through the profiling events: only the launch path records kernel times."""
+    from trajectory_controller_amd import TpcMpcError, capi
+    with _solver(4, "auto") as s:
+        s.set_profiling(True)
+        s.solve_one(1.0, 0.1, 0.05)                  # resident: no launch, no kernel times
+        with pytest.raises(TpcMpcError):
+            s.last_kernel_times()
+        s.set_resident(0)
+        s.set_option(capi.OPT_MAILBOX_HOST, 1)
+        f, r = s.solve_one(1.0, 0.1, 0.05)
+        assert s.last_kernel_times()[2] == capi.ALGO_WAVE
+        assert abs(f - 0.28258865451261717) <= 1e-12 and abs(r - 0.059891817493776013) <= 1e-12
+
+
 def test_last_flags_before_any_solve_one(torch_cuda):
     from trajectory_controller_amd import TpcMpcError
     with _solver(4, "auto") as s:

@@ -49,7 +49,8 @@ hipError_t pg(const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStre
         constexpr int NG = GroupPlan<T, kH, G>::NG;
         const int64_t need = (a.n + NG - 1) / NG;
         // persistent grid: one wavefront per SIMD (the kernel is built for that, GroupPlan::occ)
-        const int cap = device_cus() * 4 * GroupPlan<T, kH, G>::occ;
+        int cap = device_cus() * 4 * GroupPlan<T, kH, G>::occ;
+        if (ws.max_waves > 0 && ws.max_waves < cap) cap = ws.max_waves;   // (experiments: tpc_mpc_x_set_group_share)
         hipLaunchKernelGGL((group_pg_kernel<T, kH, G, EQB>), dim3((unsigned)(need < cap ? need : cap)), dim3(kWave), 0, s, a, k,
                            (const T*)ws.state, (const uint32_t*)ws.order, ws.ticket, ws.stats, order_queue_len(ws.sort_temp));
         return hipGetLastError();

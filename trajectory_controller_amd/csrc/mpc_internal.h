@@ -68,6 +68,7 @@ struct Workspace {
     hipEvent_t* ev;
     int wave_group = 0;   // TPC_MPC_OPT_WAVE_GROUP: 0 auto, 1 / 2 / 4 instances per wavefront
     int group_lanes = 0;  // GROUP: lanes per instance (2 / 4 / 8) for this horizon
+    int max_waves = 0;    // GROUP: size of the persistent grid (0: one wavefront per SIMD of the device)
 };
 
 // WAVE work queue (mpc_wave.h): the dynamic part of the queue is dealt out through kQueueTickets counters on
@@ -79,6 +80,7 @@ constexpr int64_t kQueueTicketBytes = (int64_t)kQueueTickets * kQueueTicketStrid
 constexpr int64_t kWaveQueueMaxInstances = 32768;   // what one wave_order_kernel workgroup sorts (mpc_wave.h)
 
 // mpc_generic.hip: the any-horizon fallback (run-time H, per-instance arrays in a global workspace)
+constexpr int kAlgoMixed = 101;     // last_algo after a mixed-horizon batch whose bins ran on child handles
 constexpr int kAlgoGeneric = 100;   // internal kernel-family code next to TPC_MPC_ALGO_WAVE / _LANE / _LANE_FMA
 constexpr int kMaxHorizon = 64;
 int64_t generic_scratch_bytes(int H, int dtype, int64_t n);

@@ -231,6 +231,7 @@ int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n,
     ws->ev = h->profiling ? h->ev : nullptr;
     ws->wave_group = h->opt_wave_group;
     ws->group_lanes = group_lanes(h, H, dtype, n);
+    ws->max_waves = h->max_waves;
     h->ev_valid = h->profiling;
     h->last_algo = algo;
     ws->keys = ws->rank = ws->order = nullptr;
@@ -290,6 +291,12 @@ int check_general_io(tpc_mpc_context* h, const tpc_mpc_general_io* io, int mem) 
 }  // namespace
 
 namespace tpc {
+
+// A bin of a mixed-horizon batch that the GROUP family takes (tpc_mpc_mixed.hip runs those side by side, each on its
+// share of the SIMDs): AUTO or GROUP asked for, bounds the unit box can take, a horizon with group kernels.
+bool group_applicable(const tpc_mpc_context* h, const tpc_mpc_params* p, int H) {
+    return (p->algo == TPC_MPC_ALGO_AUTO || p->algo == TPC_MPC_ALGO_GROUP) && fma_usable(p) && group_lanes(h, H) > 0;
+}
 
 int check_common(tpc_mpc_context* h, const tpc_mpc_params* p) {
     if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
@@ -976,6 +983,16 @@ int tpc_mpc_x_set_work_hint(tpc_mpc_handle h, const int32_t* hint, int64_t n, in
     });
 }
 
+int tpc_mpc_x_set_group_share(tpc_mpc_handle h, int waves, int cu_count) {
+    return guarded(h, [&]() -> int {
+        if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+        if (waves < 0 || cu_count < 0) return fail(h, TPC_MPC_ERR_BAD_ARG, "need waves >= 0, cu_count >= 0");
+        h->max_waves = waves;
+        if (cu_count > 0) h->cu_count = cu_count;
+        return TPC_MPC_OK;
+    });
+}
+
 int tpc_mpc_set_option(tpc_mpc_handle h, int option, int64_t value) {
     return guarded(h, [&]() -> int {
         if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
@@ -1015,7 +1032,9 @@ int tpc_mpc_set_profiling(tpc_mpc_handle h, int enable) {
 int tpc_mpc_last_kernel_times(tpc_mpc_handle h, double* first_ms, double* second_ms, int* algo) {
     return guarded(h, [&]() -> int {
         if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
-        if (!h->ev_valid) return fail(h, TPC_MPC_ERR_BAD_ARG, "no profiled solve on this handle yet");
+        if (!h->ev_valid)
+            return fail(h, TPC_MPC_ERR_BAD_ARG, h->last_algo == kAlgoMixed ? "the last solve was a mixed-horizon batch: its bins ran on child handles"
+                                                                            : "no profiled solve on this handle yet");
         HIP_TRY(h, hipEventSynchronize(h->ev[2]));
         float a = 0, b = 0;
         HIP_TRY(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
@@ -1030,6 +1049,8 @@ int tpc_mpc_last_kernel_times(tpc_mpc_handle h, double* first_ms, double* second
 int tpc_mpc_last_lane_stats(tpc_mpc_handle h, uint64_t* wave_iterations, uint64_t* refill_blocks) {
     return guarded(h, [&]() -> int {
         if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+        if (h->last_algo == kAlgoMixed)
+            return fail(h, TPC_MPC_ERR_BAD_ARG, "the last solve was a mixed-horizon batch: its bins ran on child handles");
         HIP_TRY(h, hipSetDevice(h->device));
         unsigned long long st[2] = {0, 0};
         // waits for the handle's last solve only (its stream-order event), not for the whole device

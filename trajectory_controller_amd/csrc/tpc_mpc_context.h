@@ -81,7 +81,9 @@ struct tpc_mpc_context {
     // tpc_mpc_set_option
     int opt_wave_group = 0;          // 0 auto, 1 / 2 / 4 instances per wavefront (fp64 WAVE)
     bool opt_mailbox_host = false;   // solve_one's request lines in pinned host memory
+    int64_t one_idle_us = 20000;     // tpc_mpc_set_resident: idle timeout of the resident wavefront; <= 0 = resident mode off
     int opt_group_lanes = 0;         // GROUP: 0 auto, 2 / 4 / 8 lanes per instance
+    int max_waves = 0;               // persistent-grid limit of this handle's GROUP solves (child handles of a mixed batch: their share of the chip)
 };
 
 namespace tpc {
@@ -166,6 +168,7 @@ int general_launch(tpc_mpc_context* h, const tpc_mpc_params* p, const tpc_mpc_ge
 int check_general_device_io(tpc_mpc_context* h, const tpc_mpc_general_io* io);
 int compact_launch(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy,
                    const void* dphi, void* front, void* rear, int32_t* iters, hipStream_t s);
+bool group_applicable(const tpc_mpc_context* h, const tpc_mpc_params* p, int H);
 // scratch of the LANE family for (H, dtype, n), without launching (grows the handle's workspace)
 int reserve_lane_workspace(tpc_mpc_context* h, int H, int dtype, int64_t n);
 

@@ -19,6 +19,11 @@ extern "C" {
  * cycle old, inputs moved by 0.5 % of their range, buy nothing -- which is why this is not in the public header. */
 int tpc_mpc_x_set_work_hint(tpc_mpc_handle h, const int32_t* hint, int64_t n, int mem);
 
+/* The share of the chip a handle's GROUP solves take: `waves` persistent wavefronts (0 = one per SIMD, the default) and
+ * the CU count AUTO's crossover table is scaled to (0 = the device's).  What tpc_mpc_solve_batch_compact_mixed sets on
+ * the child handles of its bins; exported to measure one bin on a share by itself (scripts/group_share.py). */
+int tpc_mpc_x_set_group_share(tpc_mpc_handle h, int waves, int cu_count);
+
 #ifdef __cplusplus
 }
 #endif

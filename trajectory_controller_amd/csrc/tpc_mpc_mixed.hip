@@ -135,39 +135,98 @@ int run_mixed(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const int3
     // slowest instance on a fraction of the SIMDs (N = 40: 29 ms on a quarter of them at 16 384 instances): they
     // run CONCURRENTLY, each on a child handle (scratch, ticket and flag word of its own) and a stream of its own,
     // forked from the caller's stream here and joined back into it below; longest horizon first.
+    // The bins are independent batches.  How they share the chip:
+    //   * under AUTO (or GROUP) the bins of N = 10, 20, 30, 40 are GROUP's: persistent grids of one wavefront per SIMD
+    //     whose time is the time of their slowest instance at a LONE wavefront's pace.  Such bins must not overlap: a
+    //     second wavefront on a SIMD fills every gap the first one's dependent instructions leave and delays each of its
+    //     instructions by about two cycles, and one delayed wavefront delays the kernel (at N = 40 every wavefront holds
+    //     a 10 000-iteration instance).  Measured on config 5 (4 x 16 384 instances): all bins at once 9.3-9.6 ms -- the
+    //     N = 40 bin 7.7 ms instead of the 4.8 it takes alone, whatever s_setprio says; the bins on disjoint SHARES of
+    //     the wavefront slots (898 / 110 / 16, a quarter of a CU's LDS claimed per wavefront so that no CU takes five):
+    //     8.5-8.8 ms, because the hardware still stacks wavefronts of different kernels on one SIMD of a CU while
+    //     another idles (the same 898 wavefronts alone: 4.6 ms).  So they run ONE AFTER ANOTHER on the caller's stream,
+    //     each with the whole chip, shortest horizon first;
+    //   * otherwise (a family demanded explicitly) the bins run concurrently on child handles, as LANE passes over bins
+    //     smaller than the chip want (each lasts as long as its slowest instance on a fraction of the SIMDs).
     int live = 0;
-    for (int i = 0; i < bins.nb; ++i) live += hc[i] ? 1 : 0;
-    if (!h->fork_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
-    HIP_TRY(h, hipEventRecord(h->fork_ev, s));
-    for (int i = bins.nb - 1; i >= 0; --i) {
+    bool any_group = false;
+    for (int i = 0; i < bins.nb; ++i) {
         if (!hc[i]) continue;
-        tpc_mpc_params q = *p;
-        q.horizon = bins.horizon[i];
-        const int64_t o = ho[i];
-        if (live == 1) {   // nothing to overlap with: the handle itself, on the caller's stream
-            int rc = compact_launch(h, &q, hc[i], gv + o, gdy + o, gdphi + o, gfront + o, grear + o,
-                                    d_iters ? giters + o : nullptr, s);
+        ++live;
+        any_group = any_group || group_applicable(h, p, bins.horizon[i]);
+    }
+    if (!h->fork_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+    if (any_group || live == 1) {
+        for (int i = 0; i < bins.nb; ++i) {   // ascending horizon
+            if (!hc[i]) continue;
+            tpc_mpc_params q = *p;
+            q.horizon = bins.horizon[i];
+            const int64_t o = ho[i];
+            int rc = compact_launch(h, &q, hc[i], gv + o, gdy + o, gdphi + o, gfront + o, grear + o, d_iters ? giters + o : nullptr, s);
             if (rc) return rc;
-            continue;
         }
-        if (!h->kids[i]) {
-            int rc = context_new(h->device, h->cu_count, &h->kids[i]);
-            if (rc) return fail(h, rc, "mixed batch: child handle: %s", g_create_error);
-            HIP_TRY(h, hipStreamCreateWithFlags(&h->kid_stream[i], hipStreamNonBlocking));
-            HIP_TRY(h, hipEventCreateWithFlags(&h->kid_done[i], hipEventDisableTiming));
+        if (live > 1) {   // several solves went through this handle: its kernel times / lane statistics describe the last bin only
+            h->ev_valid = false;
+            h->last_algo = kAlgoMixed;
         }
-        tpc_mpc_context* kid = h->kids[i];
-        kid->opt_wave_group = h->opt_wave_group;
-        hipStream_t ks = h->kid_stream[i];
-        HIP_TRY(h, hipStreamWaitEvent(ks, h->fork_ev, 0));
-        HIP_TRY(h, hipMemsetAsync(kid->ws_words + 1, 0, sizeof(uint32_t), ks));
-        int rc = compact_launch(kid, &q, hc[i], gv + o, gdy + o, gdphi + o, gfront + o, grear + o,
-                                d_iters ? giters + o : nullptr, ks);
-        if (rc) return fail(h, rc, "mixed batch, horizon %d: %s", q.horizon, kid->err);
-        hipLaunchKernelGGL(mixed_or_flags_kernel, dim3(1), dim3(1), 0, ks, h->ws_words + 1, (const uint32_t*)(kid->ws_words + 1));
-        HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipEventRecord(h->kid_done[i], ks));
-        HIP_TRY(h, hipStreamWaitEvent(s, h->kid_done[i], 0));
+    } else {
+        h->ev_valid = false;   // the solves run on child handles
+        h->last_algo = kAlgoMixed;
+        HIP_TRY(h, hipEventRecord(h->fork_ev, s));
+        // Whatever goes wrong below, the caller's stream must wait for every child stream that already got work, or the
+        // next call's gather (or a growing scratch buffer) could overtake a child still running on the old contents.
+        bool forked[kBinsMax] = {false};
+        auto join = [&]() {
+            for (int i = 0; i < bins.nb; ++i)
+                if (forked[i] && hipEventRecord(h->kid_done[i], h->kid_stream[i]) == hipSuccess)
+                    (void)hipStreamWaitEvent(s, h->kid_done[i], 0);
+        };
+        for (int i = bins.nb - 1; i >= 0; --i) {   // longest horizon first
+            if (!hc[i]) continue;
+            tpc_mpc_params q = *p;
+            q.horizon = bins.horizon[i];
+            const int64_t o = ho[i];
+            if (!h->kids[i]) {   // published only when complete: handle, stream and event
+                tpc_mpc_context* kid = nullptr;
+                hipStream_t ks = nullptr;
+                hipEvent_t ke = nullptr;
+                int rc = context_new(h->device, h->cu_count, &kid);
+                if (rc) { join(); return fail(h, rc, "mixed batch: child handle: %s", g_create_error); }
+                hipError_t e = hipStreamCreateWithFlags(&ks, hipStreamNonBlocking);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&ke, hipEventDisableTiming);
+                if (e != hipSuccess) {
+                    if (ks) (void)hipStreamDestroy(ks);
+                    (void)tpc_mpc_destroy(kid);
+                    join();
+                    return hip_fail(h, e, "mixed batch: child stream / event");
+                }
+                h->kids[i] = kid; h->kid_stream[i] = ks; h->kid_done[i] = ke;
+            }
+            tpc_mpc_context* kid = h->kids[i];
+            kid->opt_wave_group = h->opt_wave_group;
+            kid->opt_group_lanes = h->opt_group_lanes;
+            hipStream_t ks = h->kid_stream[i];
+            hipError_t e = hipStreamWaitEvent(ks, h->fork_ev, 0);
+            if (e != hipSuccess) { join(); return hip_fail(h, e, "mixed batch: fork"); }
+            forked[i] = true;
+            e = hipMemsetAsync(kid->ws_words + 1, 0, sizeof(uint32_t), ks);
+            if (e != hipSuccess) { join(); return hip_fail(h, e, "mixed batch: flag word"); }
+            int rc = compact_launch(kid, &q, hc[i], gv + o, gdy + o, gdphi + o, gfront + o, grear + o,
+                                    d_iters ? giters + o : nullptr, ks);
+            if (rc) { join(); return fail(h, rc, "mixed batch, horizon %d: %s", q.horizon, kid->err); }
+            hipLaunchKernelGGL(mixed_or_flags_kernel, dim3(1), dim3(1), 0, ks, h->ws_words + 1, (const uint32_t*)(kid->ws_words + 1));
+            e = hipGetLastError();
+            if (e != hipSuccess) { join(); return hip_fail(h, e, "mixed batch: flags"); }
+        }
+        {   // join: the caller's stream continues behind every child
+            hipError_t e = hipSuccess;
+            for (int i = 0; i < bins.nb && e == hipSuccess; ++i) {
+                if (!forked[i]) continue;
+                e = hipEventRecord(h->kid_done[i], h->kid_stream[i]);
+                if (e == hipSuccess) e = hipStreamWaitEvent(s, h->kid_done[i], 0);
+            }
+            if (e != hipSuccess) { join(); return hip_fail(h, e, "mixed batch: join"); }
+        }
     }
     hipLaunchKernelGGL((mixed_scatter_kernel<T>), dim3(grid), dim3(256), 0, s, n, (const uint32_t*)perm, (const T*)gfront,
                        (const T*)grear, (const int32_t*)giters, d_front, d_rear, d_iters);

@@ -324,6 +324,7 @@ int one_shot_configure(tpc_mpc_context* h, int64_t idle_us) {
         }
     }
     OneShot* o = h->one;
+    h->one_idle_us = idle_us;   // kept on the handle: a mailbox restart (TPC_MPC_OPT_MAILBOX_HOST) must not forget it
     if (idle_us <= 0) {   // resident mode off: stop a running wave, keep the launch path
         int rc = stop_kernel(h, o);
         if (rc) return rc;
@@ -337,7 +338,7 @@ int one_shot_configure(tpc_mpc_context* h, int64_t idle_us) {
 
 int one_shot_solve(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double dy, double dphi, double* front, double* rear) {
     if (!h->one) {
-        int rc = one_shot_configure(h, 20000);
+        int rc = one_shot_configure(h, h->one_idle_us);   // (what tpc_mpc_set_resident last asked for; 20 ms by default)
         if (rc) return rc;
     }
     OneShot* o = h->one;

@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=262144, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=20)
-    ap.add_argument("--algo", default="auto", choices=["auto", "lane", "lane_fma", "wave"])
+    ap.add_argument("--algo", default="auto", choices=["auto", "lane", "lane_fma", "wave", "group"])
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
@@ -75,6 +75,10 @@ def parse():
     ap.add_argument("--no-config2", action="store_true", help="skip the BASELINE config 2 leg (4 096 x N=10, WAVE)")
     ap.add_argument("--no-bit-exact", action="store_true", help="skip the bit-exact LANE family leg")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE config 5 leg (65 536 mixed horizons)")
+    ap.add_argument("--no-mid", action="store_true", help="skip the mid-size batch leg (16 384 x N=20 through AUTO)")
+    ap.add_argument("--allow-fallback-gather", action="store_true",
+                    help="N > 1 only: let the run continue with a torch.distributed gather when the library's RCCL path "
+                         "cannot be set up (the line then carries \"gather\": \"fallback\"); by default such a run exits non-zero")
     return ap.parse_args()
 
 
@@ -222,6 +226,15 @@ def main():
         if int(ok.item()) == 0 and gather_path.startswith("library"):
             gather_path = "torch.distributed all_gather (another rank's library RCCL path failed)"
     use_lib_gather = gather_path.startswith("library")
+    # what produced the gathered outputs, as ONE top-level word: a scaling line made without the library's own
+    # RCCL exchange must not look like a library number
+    gather_word = "none" if world == 1 else ("library" if use_lib_gather else "fallback")
+    if gather_word == "fallback" and not a.allow_fallback_gather:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        raise SystemExit(f"[bench] rank {rank}: the library's RCCL gather is unavailable ({gather_path}); "
+                         f"refusing to time a torch.distributed gather (pass --allow-fallback-gather to do so)")
 
     def step(k):
         i = k % slots
@@ -301,18 +314,20 @@ def main():
         torch.cuda.synchronize()
         mean_iters = float(iters_t.double().mean().item())
         lane_stats = None
-        if algo_ran in (2, 3):
+        if algo_ran in (2, 3, 4):
             wi, rb = solver.last_lane_stats()
             pg_iters = float((iters_t.double() - 50.0).clamp(min=0).sum().item())
-            lane_stats = {"wave_iterations": wi, "refill_blocks": rb,
-                          "lane_utilisation": pg_iters / (64.0 * wi) if wi else None}
+            lane_stats = {"wave_iterations": wi, "refill_blocks": rb}
+            if algo_ran != 4:   # (a GROUP wavefront carries 64 / G instances: the figure has no such meaning there)
+                lane_stats["lane_utilisation"] = pg_iters / (64.0 * wi) if wi else None
         esz = 8 if a.dtype == "f64" else 4
         total = world * n * a.steps
         value = total / elapsed
         # dominant kernel = the longer of the two launches of a step
         dom_ms = max(k1, k2)
         dom_name = {1: "wave_kernel", 2: "lane_pg_fused_kernel" if k2 >= k1 else "lane_cd_kernel",
-                    3: "ub_pg_kernel" if k2 >= k1 else "ub_cd_kernel"}[algo_ran]
+                    3: "ub_pg_kernel" if k2 >= k1 else "ub_cd_kernel",
+                    4: "group_pg_kernel" if k2 >= k1 else "ub_cd_kernel"}[algo_ran]
         alg_bytes = 5 * esz * n                       # 3 in + 2 out scalars per solve
         # the PG kernel also reads what the CD kernel left per instance (not algorithmic traffic)
         hbm_gbs = alg_bytes / (dom_ms * 1e-3) / 1e9
@@ -340,10 +355,10 @@ def main():
             "metric": "MPC QP solves/sec (horizon N=20, 2 inputs) at 1/2/4/8 MI355X; max|du| vs dlib",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic", "gather": gather_word,
             "config": {"workload": f"batch {n} trajectories per GPU, N={H}, 2 inputs, compact "
                                    f"(mpcControllerTobi) form, cold start, eps 0.01, max_iter 10000",
-                       "global_batch": world * n, "horizon": H, "algo": {1: "wave", 2: "lane", 3: "lane_fma"}[algo_ran],
+                       "global_batch": world * n, "horizon": H, "algo": {1: "wave", 2: "lane", 3: "lane_fma", 4: "group"}[algo_ran],
                        "parallelism": f"batch-sharded x{world}", "batches_in_flight": slots,
                        "gather": gather_path, "gather_verified": gather_ok},
             "build": MpcSolver.build_info(),
@@ -444,7 +459,7 @@ def main():
             err = torch.maximum((f32.double() - front).abs(), (r32.double() - rear).abs())
             out["fp32"] = {"value": n * a.steps / d32, "unit": "solves/s (1 GPU)",
                            "ms_per_step": d32 / a.steps * 1e3,
-                           "algo": {1: "wave", 2: "lane", 3: "lane_fma"}.get(c_algo, str(c_algo)),
+                           "algo": {1: "wave", 2: "lane", 3: "lane_fma", 4: "group"}.get(c_algo, str(c_algo)),
                            "kernel_ms": {"first": c1, "second": c2},
                            "mean_iterations": float(it32.double().mean().item()),
                            "within": {str(t): float((err <= t).double().mean().item())
@@ -466,18 +481,47 @@ def main():
                 d2 = time.perf_counter() - t1
             out["config2"] = {"workload": "batch 4096, N=10, fp64, WAVE family", "value": 4096 * 50 / d2,
                               "unit": "solves/s", "ms_per_step": d2 / 50 * 1e3}
+        if world == 1 and not a.no_mid and a.dtype == "f64" and n == 262144 and H == 20:
+            # A mid-size batch beside the headline: 16 384 instances of the same workload through AUTO -- too many for a
+            # wavefront each, too few to fill the chip one lane each: the GROUP family's place (G lanes per instance)
+            cm = [torch.from_numpy(x).to(dev) for x in compact_inputs(20, 16384)]
+            with MpcSolver(horizon=20, device=local_rank, dtype="f64", algo="auto") as sg:
+                sg.set_profiling(True)
+                for _ in range(3):
+                    sg.solve_batch_compact(*cm, want_flags=False)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    sg.solve_batch_compact(*cm, want_flags=False)
+                torch.cuda.synchronize()
+                dm = time.perf_counter() - t1
+                m1, m2, m_algo = sg.last_kernel_times()
+                _, _, mit = sg.solve_batch_compact(*cm, want_iters=True)
+                torch.cuda.synchronize()
+            mflops = (46 * 20 - 16) * float(mit.double().sum().item())
+            out["mid_batch"] = {"workload": "batch 16384, N=20, fp64, AUTO", "algo": {1: "wave", 2: "lane", 3: "lane_fma", 4: "group"}.get(m_algo, str(m_algo)),
+                                "value": 16384 * 20 / dm, "unit": "solves/s", "ms_per_step": dm / 20 * 1e3,
+                                "kernel_ms": {"first": m1, "second": m2},
+                                "alu_frac": mflops / (dm / 20) / 1e12 / FP64_VECTOR_PEAK_TF}
         if world == 1 and not a.no_config5 and a.dtype == "f64" and n == 262144 and H == 20:
             # BASELINE config 5 beside the headline: 65 536 instances split evenly over N in {5, 10, 20, 40}, interleaved,
-            # ONE tpc_mpc_solve_batch_compact_mixed call per step (binned on the device, the bins run concurrently)
+            # ONE tpc_mpc_solve_batch_compact_mixed call per step (binned on the device; under AUTO the bins run one after
+            # another, each with the whole chip: tpc_mpc_mixed.hip)
             Hs, per = (5, 10, 20, 40), 16384
             parts = [compact_inputs(Hh, per) for Hh in Hs]
             mv, my, mp = (np.concatenate([pp[c] for pp in parts]) for c in range(3))
             hz = np.repeat(np.array(Hs, dtype=np.int32), per)
             perm = np.random.default_rng(3).permutation(len(hz))
-            c5 = {"workload": "batch 65536 mixed over N in {5,10,20,40}, one call", "unit": "ms per batch"}
-            for dt_name, dt_t in (("f64", torch.float64), ("f32", torch.float32)):
+            c5 = {"workload": "batch 65536 mixed over N in {5,10,20,40}, one call", "unit": "ms per batch",
+                  "note": "f64: AUTO as shipped -- the ~10 % of the N=40 instances that end on the 10 000-iteration cap are "
+                          "solved once more bit-exactly (one LANE pass: 10 000 iterations at one lane's pace); "
+                          "f64_fast_capped: TPC_MPC_PARAM_FAST_CAPPED, the tolerance families' answer kept (<= 1.5e-12 from "
+                          "dlib on this workload)"}
+            from trajectory_controller_amd import capi
+            for dt_name, dt_t, opt in (("f64", torch.float64, 0), ("f64_fast_capped", torch.float64, capi.PARAM_FAST_CAPPED),
+                                       ("f32", torch.float32, 0)):
                 xv, xy, xp = (torch.from_numpy(z[perm]).to(dev, dtype=dt_t) for z in (mv, my, mp))
-                with MpcSolver(horizon=20, device=local_rank, dtype=dt_name) as sm:
+                with MpcSolver(horizon=20, device=local_rank, dtype=dt_name[:3], options=opt) as sm:
                     sm.solve_batch_compact_mixed(hz[perm], xv, xy, xp)
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
@@ -486,6 +530,7 @@ def main():
                     torch.cuda.synchronize()
                     c5[dt_name] = (time.perf_counter() - t1) / 5 * 1e3
             c5["solves_per_s_f64"] = len(hz) / (c5["f64"] * 1e-3)
+            c5["solves_per_s_f64_fast_capped"] = len(hz) / (c5["f64_fast_capped"] * 1e-3)
             out["config5"] = c5
         print(json.dumps(out), flush=True)
     for sv in solvers:

@@ -109,6 +109,10 @@ typedef enum tpc_mpc_algo {
                                         the reference build); here the instance is not solved and
                                         returns its start point at iteration 0                    */
 
+/* tpc_mpc_params.options */
+#define TPC_MPC_PARAM_FAST_CAPPED 0x1  /* AUTO only: keep the tolerance family's answer for instances that end on
+                                          max_iter instead of solving them once more bit-exactly (see AUTO above) */
+
 /* Solver knobs.  Defaults (tpc_mpc_default_params) are dlib's and the reference module's:
  *   eps 0.01 (mpc.h:104), max_iter 10000 (mpc.h:103), smo_iters 50 (mpc.h:319),
  *   step_size 0.1 (src/trajectory_point_follower.cpp:96), wheelbase 0.21
@@ -118,7 +122,7 @@ typedef struct tpc_mpc_params {
     int32_t horizon;          /* H: MPC_HORIZON, include/trajectory_point_follower.h:48          */
     int32_t dtype;            /* tpc_mpc_dtype of the batch arrays and of the arithmetic          */
     int32_t algo;             /* tpc_mpc_algo                                                     */
-    int32_t reserved;
+    int32_t options;          /* TPC_MPC_PARAM_* bits, 0 by default                                */
     double eps;               /* dlib::mpc::set_epsilon        (mpc.h:197-208)                    */
     uint64_t max_iter;        /* dlib::mpc::set_max_iterations (mpc.h:190-195)                    */
     uint64_t smo_iters;       /* mpc.h:319                                                        */

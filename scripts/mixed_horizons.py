@@ -10,13 +10,16 @@ parts = [compact_inputs(H, per) for H in Hs]
 v, dy, dphi = (np.concatenate([p[c] for p in parts]) for c in range(3))
 hz = np.repeat(np.array(Hs), per)
 perm = np.random.default_rng(3).permutation(len(hz))
-for dtype in (sys.argv[1:] or ["f64", "f32"]):
+from trajectory_controller_amd import capi
+for dtype in (sys.argv[1:] or ["f64", "f64fast", "f32"]):
+    fast = dtype.endswith("fast")   # TPC_MPC_PARAM_FAST_CAPPED: capped instances keep the tolerance family's answer
+    label, dtype = dtype, dtype[:3]
     tdt = torch.float64 if dtype == "f64" else torch.float32
     tv, ty, tp = (torch.from_numpy(a[perm]).to("cuda", dtype=tdt) for a in (v, dy, dphi))
-    with MpcSolver(horizon=20, dtype=dtype) as s:
+    with MpcSolver(horizon=20, dtype=dtype, options=capi.PARAM_FAST_CAPPED if fast else 0) as s:
         s.solve_batch_compact_mixed(hz[perm], tv, ty, tp)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(3):
             s.solve_batch_compact_mixed(hz[perm], tv, ty, tp)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
-    print(f"{dtype}: {dt*1e3:.1f} ms per mixed batch of {len(hz)}  -> {len(hz)/dt/1e6:.2f} M solves/s")
+    print(f"{label}: {dt*1e3:.1f} ms per mixed batch of {len(hz)}  -> {len(hz)/dt/1e6:.2f} M solves/s")

@@ -1,0 +1,134 @@
+"""`-m gpu` tests of AUTO's parity guarantee for instances that end on the iteration cap (include/tpc_mpc.h, AUTO).
+
+An instance that runs into max_iter has not converged; over thousands of iterations of an ill-conditioned problem
+the tolerance families' rounding differences grow (profiles/r03_fuzz_lane_fma.txt: 2.3e-5 at N = 40 under adversarial
+parameters, profiles/r04_fuzz_capped.txt: 7e-8 on the set used below).  Under AUTO such instances are solved once more
+in dlib's own operation order (lane_cd_kernel, RESOLVE), so what the call returns for them is dlib's BITS whichever
+family solved the batch -- WAVE, GROUP or LANE_FMA, compact or general form, batch or solve_one -- and every instance
+is within the 1e-6 target.  TPC_MPC_PARAM_FAST_CAPPED keeps the tolerance family's answer.
+"""
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+WAVE, LANE, LANE_FMA, GROUP = 1, 2, 3, 4
+# the worst set of profiles/r04_fuzz_capped.txt: N = 40, 544 of 750 instances on the cap
+HOSTILE = dict(weight_y=17.66698177195007, weight_phi=72.39497127615921, weight_steering_front=0.00021630579900267817,
+               weight_steering_rear=0.045780005743250786, lower=(-0.40132006097329725, -0.13466087933638904),
+               upper=(0.13466087933638904, 0.40132006097329725), step_size=0.22085310545663503,
+               wheelbase=0.12366626463869, eps=0.004058013395383058, max_iter=10000, smo_iters=7)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch
+
+
+def _oracle_kw(kw):
+    return dict(weights=(kw["weight_y"], kw["weight_phi"], kw["weight_steering_front"], kw["weight_steering_rear"]),
+                T=kw["step_size"], l=kw["wheelbase"], lo=kw["lower"], hi=kw["upper"], eps=kw["eps"],
+                max_iter=kw["max_iter"], smo_iters=kw["smo_iters"])
+
+
+def _solve(torch, H, v, dy, dphi, algo="auto", expect=None, **kw):
+    from trajectory_controller_amd import MpcSolver
+    tv, ty, tp = (torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0") for a in (v, dy, dphi))
+    with MpcSolver(horizon=H, device=0, algo=algo, **kw) as s:
+        s.set_profiling(True)
+        f, r, it = s.solve_batch_compact(tv, ty, tp, want_iters=True)
+        torch.cuda.synchronize()
+        if expect is not None:
+            assert s.last_kernel_times()[2] == expect
+        flags = s.last_flags
+    return f.cpu().numpy(), r.cpu().numpy(), it.cpu().numpy(), flags
+
+
+def test_hostile_set_capped_instances_come_back_with_dlibs_bits(torch_cuda, oracle):
+    from trajectory_controller_amd import FLAG_MAX_ITER, capi
+    from trajectory_controller_amd.synth import compact_inputs
+    H, n = 40, 750
+    v, dy, dphi = compact_inputs(H, n, first=834746896)
+    of, orr, oit = oracle.solve_compact(H, v, dy, dphi, nthreads=8, **_oracle_kw(HOSTILE))
+    capped = oit == HOSTILE["max_iter"]
+    assert capped.sum() > 400
+    den = np.maximum(np.maximum(np.abs(of), np.abs(orr)), 0.13)
+    f, r, it, flags = _solve(torch_cuda, H, v, dy, dphi, expect=WAVE, **HOSTILE)
+    assert flags & FLAG_MAX_ITER and np.array_equal(it, oit)
+    assert bits_equal(f[capped], of[capped]) and bits_equal(r[capped], orr[capped])
+    assert (np.maximum(np.abs(f - of), np.abs(r - orr)) / den).max() <= 1e-6
+    # switched off: the tolerance family's own answer (close, but not dlib's bits on the capped instances)
+    f2, r2, it2, _ = _solve(torch_cuda, H, v, dy, dphi, expect=WAVE, options=capi.PARAM_FAST_CAPPED, **HOSTILE)
+    assert np.array_equal(it2, oit)
+    assert not (bits_equal(f2[capped], of[capped]) and bits_equal(r2[capped], orr[capped]))
+    assert np.array_equal(f2[~capped], f[~capped]) and np.array_equal(r2[~capped], r[~capped])
+    # an explicitly demanded tolerance family is taken at its word
+    f3, r3, _, _ = _solve(torch_cuda, H, v, dy, dphi, algo="wave", **HOSTILE)
+    assert np.array_equal(f3, f2) and np.array_equal(r3, r2)
+
+
+@pytest.mark.parametrize("H,n,cap,family", [(40, 8192, 10000, GROUP), (20, 16384, 1500, GROUP), (10, 100000, 300, LANE_FMA),
+                                            (20, 3000, 1000, WAVE), (5, 40000, 60, LANE_FMA), (30, 1024, 3000, WAVE)])
+def test_capped_instances_are_bit_exact_in_every_family(torch_cuda, oracle, H, n, cap, family):
+    """BASELINE inputs with a cap low enough that a good part of the batch runs into it, at batch sizes that send AUTO
+    to each of its tolerance families: the capped instances equal the oracle bit for bit, the rest is within 1e-9,
+    iteration counts are the oracle's everywhere."""
+    from trajectory_controller_amd import FLAG_MAX_ITER
+    from trajectory_controller_amd.synth import compact_inputs
+    v, dy, dphi = compact_inputs(H, n, first=123457)
+    of, orr, oit = oracle.solve_compact(H, v, dy, dphi, max_iter=cap, nthreads=8)
+    capped = oit == cap
+    assert 0 < capped.sum() < n
+    f, r, it, flags = _solve(torch_cuda, H, v, dy, dphi, expect=family, max_iter=cap)
+    assert flags & FLAG_MAX_ITER and np.array_equal(it, oit)
+    assert bits_equal(f[capped], of[capped]) and bits_equal(r[capped], orr[capped])
+    assert max(np.abs(f - of).max(), np.abs(r - orr).max()) <= 1e-9
+
+
+def test_no_capped_instance_no_change(torch_cuda, oracle):
+    """The usual case: nothing ends on the cap, the re-solve kernel leaves at once and the call returns what the
+    tolerance family computed."""
+    from trajectory_controller_amd import capi
+    from trajectory_controller_amd.synth import compact_inputs
+    H, n = 20, 16384
+    v, dy, dphi = compact_inputs(H, n)
+    f, r, it, flags = _solve(torch_cuda, H, v, dy, dphi, expect=GROUP)
+    f2, r2, it2, _ = _solve(torch_cuda, H, v, dy, dphi, expect=GROUP, options=capi.PARAM_FAST_CAPPED)
+    assert flags == 0 and np.array_equal(f, f2) and np.array_equal(r, r2) and np.array_equal(it, it2)
+
+
+@pytest.mark.parametrize("I", [1, 2])
+def test_general_form_capped_instances(torch_cuda, oracle, I):
+    """The general form (per-instance model, per-step targets, cold start) through AUTO: WAVE at this size."""
+    import torch
+    from trajectory_controller_amd import MpcSolver
+    from trajectory_controller_amd.synth import general_inputs
+    H, n, cap = 20, 2000, 400
+    names = ["A", "B", "C", "Q", "R", "lo", "hi", "x0", "targets"]
+    g = general_inputs(H, n, I=I, first=4711)
+    ou0, _, oit = oracle.solve_general(I, H, *[g[k] for k in names], max_iter=cap, nthreads=8)
+    capped = oit == cap
+    assert 0 < capped.sum() < n
+    dev = [torch.from_numpy(np.ascontiguousarray(g[k].reshape(n, -1).T)).to("cuda:0") for k in names]
+    with MpcSolver(horizon=H, device=0, max_iter=cap) as s:
+        u0, it = s.solve_batch_general(*dev, inputs=I, want_iters=True)
+        torch.cuda.synchronize()
+    u0, it = u0.cpu().numpy().T, it.cpu().numpy()
+    assert np.array_equal(it, oit)
+    assert bits_equal(u0[capped], ou0[capped]) and np.abs(u0 - ou0).max() <= 1e-9
+
+
+def test_solve_one_capped(torch_cuda, oracle):
+    """The call that replaces mpcControllerTobi: a solve the resident wavefront leaves on the cap is solved once more
+    bit-exactly (one LANE launch), the flag stays raised."""
+    from trajectory_controller_amd import FLAG_MAX_ITER, MpcSolver
+    of, orr, oit = oracle.solve_compact(20, [2.0, 50.0], [-0.2, 0.3], [0.1, 0.2], max_iter=200)
+    with MpcSolver(horizon=20, device=0, max_iter=200) as s:
+        for k in range(2):
+            f, r = s.solve_one([2.0, 50.0][k], [-0.2, 0.3][k], [0.1, 0.2][k])
+            assert s.last_solve_one_flags() == (FLAG_MAX_ITER, 200) and oit[k] == 200
+            assert bits_equal([f, r], [of[k], orr[k]])

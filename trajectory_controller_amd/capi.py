@@ -19,6 +19,7 @@ HOST, DEVICE = 0, 1
 ALGO_AUTO, ALGO_WAVE, ALGO_LANE, ALGO_LANE_FMA, ALGO_GROUP = 0, 1, 2, 3, 4
 OPT_WAVE_GROUP, OPT_MAILBOX_HOST, OPT_GROUP_LANES = 1, 2, 3
 FLAG_NONFINITE, FLAG_MAX_ITER, FLAG_BAD_MODEL = 0x1, 0x2, 0x4
+PARAM_FAST_CAPPED = 0x1   # tpc_mpc_params.options
 
 STATUS_NAMES = {0: "OK", 1: "BAD_ARG", 2: "BAD_WEIGHTS", 3: "BAD_BOUNDS", 4: "BAD_HORIZON",
                 5: "BAD_EPS", 6: "NO_DEVICE", 7: "HIP", 8: "ALLOC", 9: "COMM"}
@@ -41,7 +42,7 @@ EXPORTS = ("tpc_mpc_default_params", "tpc_mpc_create", "tpc_mpc_destroy", "tpc_m
 class Params(C.Structure):
     """struct tpc_mpc_params"""
     _fields_ = [("horizon", C.c_int32), ("dtype", C.c_int32), ("algo", C.c_int32),
-                ("reserved", C.c_int32), ("eps", C.c_double), ("max_iter", C.c_uint64),
+                ("options", C.c_int32), ("eps", C.c_double), ("max_iter", C.c_uint64),
                 ("smo_iters", C.c_uint64), ("step_size", C.c_double), ("wheelbase", C.c_double),
                 ("weight_y", C.c_double), ("weight_phi", C.c_double),
                 ("weight_steering_front", C.c_double), ("weight_steering_rear", C.c_double),

@@ -183,19 +183,18 @@ __global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel
                 } else {
                     k = (int64_t)order[t];
                     const T* rec = recs + k * RL;
-                    const T vk = ((const T*)g.v)[k], ty = ((const T*)g.dy)[k], tphi = ((const T*)g.dphi)[k];
+                    const T* ex = rec + LaneRec<T, H>::kExtra;   // (left by ub_cd_kernel: step constants, a, c, target)
 #pragma unroll
                     for (int q = 0; q < 2 * L; ++q) {
                         if (q / 2 < DL0) x[q] = rec[2 * L * p + q];
                         else x[q] = p * L + q / 2 < H ? rec[2 * L * p + q] : m.xz(q & 1);
                     }
-                    const T lambda = rec[2 * H];
                     const uint64_t meta = load_meta<T>(rec + 2 * H + 1);
                     iter = (uint32_t)meta;
                     const bool vinit = (meta & kMetaVInit) != 0;   // mpc.h:330-334, else a fresh v = 0
 #pragma unroll
                     for (int q = 0; q < 2 * L; ++q) v[q] = vinit ? x[q] : m.xz(q & 1);
-                    m.set_instance((T)g.step, (T)g.wheelbase, vk, ty, tphi);
+                    m.set_instance_ac(ex[3], ex[4], ex[5], ex[6]);
                     T dummy_z, dummy_y;
                     m.fwd_init(dummy_z, dummy_y);
                     zst = p == 0 ? dummy_z : (T)0;
@@ -218,7 +217,7 @@ __global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel
                         if (meta & kMetaNonFinite) { flags |= 0x1u; if (p == 0) { ((T*)g.front)[k] = (T)0; ((T*)g.rear)[k] = (T)0; if (g.iters) g.iters[k] = (int32_t)iter; } }
                         else publish(x[0], x[1], iter);
                     } else {
-                        ub::pg_constants<T>(lambda, m.s0, m.s1, il[0], il[1], beta);   // mpc.h:342-343
+                        il[0] = ex[0]; il[1] = ex[1]; beta = ex[2];                    // mpc.h:342-343 (ub::pg_constants)
                         have = true;
                     }
                 }

@@ -30,7 +30,8 @@
 namespace tpc {
 
 // Per-instance record handed from the CD phase to the PG phase:
-//   rec[0 .. 2H-1] controls (indexed 2*i + j), rec[2H] lambda, rec[2H+1] meta (bit pattern)
+//   rec[0 .. 2H-1] controls (indexed 2*i + j), rec[2H] lambda, rec[2H+1] meta (bit pattern), then kExtras values the
+//   LANE_FMA / GROUP kernels leave for their refill passes (mpc_ub.h: step constants, model scalars, target)
 // meta: low 32 bits iteration count; bit 32 = stopped (eps reached); bit 33 = v := u was executed
 // at the last CD iteration (mpc.h:330-334); bit 34 = non-finite inputs; bit 35 = invalid model.
 constexpr uint64_t kMetaStopped = 1ull << 32;
@@ -41,7 +42,9 @@ constexpr uint64_t kMetaBadModel = 1ull << 35;   // violates dlib's requires cla
 template <typename T, int H> struct LaneRec {
     // record length in T elements, padded to an even count of 8-byte words
     static constexpr int kMetaT = sizeof(T) == 8 ? 1 : 2;         // meta needs 64 bits
-    static constexpr int kLen = ((2 * H + 1 + kMetaT) + 1) / 2 * 2;
+    static constexpr int kExtra = 2 * H + 1 + kMetaT;              // first extra value
+    static constexpr int kExtras = 7;
+    static constexpr int kLen = ((2 * H + 1 + kMetaT + kExtras) + 1) / 2 * 2;
 };
 
 template <typename T> TPC_DEV void store_meta(T* rec, uint64_t meta);
@@ -134,19 +137,33 @@ template <typename T, int H> struct CdOcc {
     static constexpr int value = H * (int)sizeof(T) <= 40 ? 4 : (H * (int)sizeof(T) <= 80 ? 2 : 1);
 };
 
-template <typename T, int I, int H, class Model, class Args>
-__global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args g, Knobs kn, T* __restrict__ recs,
+//
+// RESOLVE = true is the same kernel carried through to the end of the solve -- the projected-gradient phase of
+// lane_pg_kernel behind the coordinate-descent phase, one lane per instance, no queue -- for the instances of a batch
+// that a tolerance family (WAVE, LANE_FMA, GROUP) left on the iteration cap: `select[k] == max_iter` picks them,
+// `gate` (the batch's flag word) says whether there is any.  Those instances have not converged, and over
+// thousands of iterations of an ill-conditioned problem the tolerance families' rounding differences grow
+// (2.3e-5 seen under adversarial parameters, profiles/r03_fuzz_lane_fma.txt): AUTO re-solves them here, in dlib's
+// own operation order, and publishes dlib's bits (tpc_mpc_api.cpp, resolve_capped).  They all run the same
+// max_iter iterations, so there is nothing for a refill queue to balance.
+template <typename T, int I, int H, class Model, class Args, bool RESOLVE = false>
+__global__ __launch_bounds__(64, (RESOLVE ? 1 : CdOcc<T, H>::value)) void lane_cd_kernel(Args g, Knobs kn, T* __restrict__ recs,
                                                          uint32_t* __restrict__ keys,
                                                          uint32_t* __restrict__ key_rank,
                                                          uint32_t* __restrict__ key_hist,
                                                          unsigned long long* __restrict__ stats,
-                                                         int publish_finished) {
+                                                         int publish_finished, const int32_t* __restrict__ select = nullptr,
+                                                         const uint32_t* __restrict__ gate = nullptr) {
     constexpr int RL = LaneRec<T, H>::kLen;
     __shared__ T s_qd[2 * H][kWave];   // Q_diag[i](j) of lane l at s_qd[2*i + j][l]
     __shared__ T s_mm[2 * H][kWave];   // MM[i](j)
     const int lane = threadIdx.x;
     const int64_t k = (int64_t)blockIdx.x * kWave + lane;
     if (k >= g.n) return;   // no barriers below: a partial last wave just runs with fewer lanes
+    if constexpr (RESOLVE) {
+        if ((__builtin_nontemporal_load(gate) & 0x2u) == 0u) return;      // nothing ended on the cap: the usual case
+        if (select[k] != (int32_t)kn.max_iter) return;
+    }
 
     Model m;
     m.load(g, k);
@@ -166,7 +183,7 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args 
     // fused PG kernel (stats[2], read by both builds at launch; see lane_pg_fused_kernel)
     // (one atomic per wavefront at most: when the failing condition is batch-wide -- bounds that do
     // not straddle zero, a huge eps -- every lane fails, and n atomics on one word would serialise)
-    if constexpr (Model::kFastStop) {
+    if constexpr (Model::kFastStop && !RESOLVE) {
         const unsigned long long failing = __ballot(!m.fast_stop_ok(mm_max, eps, lambda, H));
         if (failing != 0ull && lane == __ffsll((long long)failing) - 1) atomicOr(&stats[2], 1ull);
     }
@@ -266,6 +283,51 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args 
         }
     }
 
+    if constexpr (RESOLVE) {
+        // ---- the projected-gradient phase (mpc.h:336-345) in the same lane: lane_pg_kernel's iteration.  dlib's v
+        // takes the place of Q_diag in LDS (the coordinate-descent phase is over): v := u where the last
+        // coordinate-descent iteration ran its update (mpc.h:330-334), else a fresh controller's zeros.
+        auto vget = [&](int q) { return s_qd[q][lane]; };
+#pragma unroll
+        for (int q = 0; q < 2 * H; ++q)
+            if ((q & 1) < I) s_qd[q][lane] = vinit ? u[q] : (T)0;
+        const T inv_lambda = (T)1.0 / lambda;                         // mpc.h:342
+        const T sq = tsqrt(lambda);
+        const T beta = (sq - (T)1) / (sq + (T)1);                     // mpc.h:343
+        bool run = !stopped && iter < kn.max_iter;
+#pragma unroll 1
+        while (__ballot(run) != 0ull) {
+            gradient<T, I, H>(m, u, [&](int q) { return s_mm[q][lane]; }, w);
+            T acc[4] = {(T)0, (T)0, (T)0, (T)0};
+#pragma unroll
+            for (int i = 0; i < H; ++i)
+#pragma unroll
+                for (int j = 0; j < I; ++j) {
+                    const T uu = u[2 * i + j], dd = w[2 * i + j];
+                    const T up = (uu <= m.lo(j)) ? (T)0 : dd;      // mpc.h:298-299
+                    const T dn = (uu >= m.hi(j)) ? (T)0 : -dd;
+                    acc[(i * I + j) & 3] = tmax(acc[(i * I + j) & 3], tmax(up, dn));
+                }
+            const T max_df = tmax(tmax(acc[0], acc[1]), tmax(acc[2], acc[3]));
+            if (run && max_df < eps) { run = false; stopped = true; }   // mpc.h:310-311 (before the update)
+            if (run) {
+#pragma unroll
+                for (int i = 0; i < H; ++i)
+#pragma unroll
+                    for (int j = 0; j < I; ++j) {
+                        const int q = 2 * i + j;
+                        const T v_old = s_qd[q][lane];
+                        const T vn = clamp3(u[q] - inv_lambda * w[q], m.lo(j), m.hi(j));   // mpc.h:342
+                        s_qd[q][lane] = vn;
+                        u[q] = clamp3(vn + beta * (vn - v_old), m.lo(j), m.hi(j));         // mpc.h:343
+                    }
+                ++iter;
+                run = iter < kn.max_iter;                                                   // mpc.h:271
+            }
+        }
+        LaneIO<T, I, H, Args>::write(g, k, u, vget, iter);
+        return;
+    }
     T* rec = recs + (int64_t)k * RL;
 #pragma unroll
     for (int q = 0; q < 2 * H; ++q) rec[q] = ((q & 1) < I) ? u[q] : (T)0;

@@ -86,6 +86,16 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
     return e;
 }
 
+// the instances of a batch that ended on the iteration cap, once more in dlib's own arithmetic (lane_cd_kernel, RESOLVE)
+template <typename T, int I, class Model, class Args>
+hipError_t resolve(const Args& a, const Knobs& k, const int32_t* select, const uint32_t* gate, hipStream_t s) {
+    if (a.n <= 0) return hipSuccess;
+    const int grid = (int)((a.n + kWave - 1) / kWave);
+    hipLaunchKernelGGL((lane_cd_kernel<T, I, kH, Model, Args, true>), dim3(grid), dim3(kWave), 0, s, a, k, (T*)nullptr,
+                       (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr, 0, select, gate);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 #define TPC_CAT2(a, b) a##b
@@ -106,6 +116,17 @@ hipError_t TPC_CAT(lane_compact_h, TPC_LANE_H)(int dtype, const CompactArgs& a, 
                                                  const Workspace& ws, hipStream_t s) {
     if (dtype == 0) return run<double, 2, CompactModel<double>, CompactArgs>(a, k, ws, s);
     return run<float, 2, CompactModel<float>, CompactArgs>(a, k, ws, s);
+}
+
+// fp64 only: the re-solve exists to deliver dlib's bits, and dlib is fp64
+hipError_t TPC_CAT(lane_resolve_compact_h, TPC_LANE_H)(const CompactArgs& a, const Knobs& k, const int32_t* select,
+                                                         const uint32_t* gate, hipStream_t s) {
+    return resolve<double, 2, CompactModel<double>, CompactArgs>(a, k, select, gate, s);
+}
+hipError_t TPC_CAT(lane_resolve_general_h, TPC_LANE_H)(int I, const GeneralArgs& a, const Knobs& k, const int32_t* select,
+                                                         const uint32_t* gate, hipStream_t s) {
+    if (I == 2) return resolve<double, 2, GeneralModel<double, 2>, GeneralArgs>(a, k, select, gate, s);
+    return resolve<double, 1, GeneralModel<double, 1>, GeneralArgs>(a, k, select, gate, s);
 }
 
 hipError_t TPC_CAT(lane_general_h, TPC_LANE_H)(int dtype, int I, const GeneralArgs& a, const Knobs& k,

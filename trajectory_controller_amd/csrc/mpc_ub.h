@@ -197,6 +197,14 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void ub_cd_kernel(Compact
     if (vinit) meta |= kMetaVInit;
     if (nonfinite) meta |= kMetaNonFinite;
     store_meta<T>(rec + 2 * H + 1, meta);
+    {   // what a refill pass of the projected-gradient kernel would otherwise compute per instance with a handful of
+        // its lanes -- two divisions and a square root for the step constants (mpc.h:342-343), one for c -- and fetch
+        // from three more arrays: computed here by all 64 lanes at once and left in the record (same operations, same bits)
+        T il0, il1, beta;
+        ub::pg_constants<T>(lambda, m.s0, m.s1, il0, il1, beta);
+        T* ex = rec + LaneRec<T, H>::kExtra;
+        ex[0] = il0; ex[1] = il1; ex[2] = beta; ex[3] = m.a; ex[4] = m.c; ex[5] = ty; ex[6] = tphi;
+    }
     // queue key: as lane_cd_kernel (longest first by lambda, the floor rule, finished instances last)
     const bool finished = stopped || iter >= kn.max_iter;
     const T lambda_floor = (r0 + r1) * (T)H;
@@ -415,24 +423,36 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
                 } else {
                     k = rank < n_stat ? (int64_t)k_dealt : (int64_t)order[t];
                     const T* rec = recs + k * RL;
-                    const T vk = ((const T*)g.v)[k], ty = ((const T*)g.dy)[k], tphi = ((const T*)g.dphi)[k];
+                    const T* ex = rec + LaneRec<T, H>::kExtra;   // (left by ub_cd_kernel)
 #pragma unroll
                     for (int q = 0; q < 2 * H; ++q) x[q] = rec[q];
-                    const T lambda = rec[2 * H];
                     const uint64_t meta = load_meta<T>(rec + 2 * H + 1);
+                    // The step constants (two divisions and a square root) and the model scalars (one division) come from
+                    // the record, where ub_cd_kernel left them, instead of being recomputed by the few lanes of a pass.
+                    // Measured (PG kernel, 262 144 instances, recomputed / from the record): fp64 N = 4: 0.155 / 0.148 ms,
+                    // N = 10: 0.887 / 0.875, N = 40: 52.6 / 52.4, fp32 N = 20: 5.35 / 5.26 -- and fp64 N = 20: 5.45 / 5.57 (three
+                    // interleaved rounds; its pass is bounded by three dependent memory round trips, which the divisions
+                    // used to fill), so that one kernel keeps recomputing.
+#ifdef TPC_UB_REFILL_RECORD
+                    constexpr bool kFromRecord = TPC_UB_REFILL_RECORD != 0;
+#else
+                    constexpr bool kFromRecord = !(sizeof(T) == 8 && H == 20);
+#endif
                     iter = (uint32_t)meta;
                     if (meta & kMetaNonFinite) flags |= 0x1u;
                     const bool vinit = (meta & kMetaVInit) != 0;   // mpc.h:330-334, else a fresh v = 0
 #pragma unroll
                     for (int q = 0; q < 2 * H; ++q) v_put(q, vinit ? x[q] : m.xz(q & 1));
-                    m.set_instance((T)g.step, (T)g.wheelbase, vk, ty, tphi);
+                    if constexpr (kFromRecord) m.set_instance_ac(ex[3], ex[4], ex[5], ex[6]);
+                    else m.set_instance((T)g.step, (T)g.wheelbase, ((const T*)g.v)[k], ((const T*)g.dy)[k], ((const T*)g.dphi)[k]);
                     if ((meta & kMetaStopped) || iter >= kn.max_iter) {
                         // (the coordinate-descent kernel publishes these itself; kept for a queue that holds one)
                         if (!(meta & kMetaStopped)) flags |= 0x2u;
                         if (meta & kMetaNonFinite) { ((T*)g.front)[k] = (T)0; ((T*)g.rear)[k] = (T)0; if (g.iters) g.iters[k] = (int32_t)iter; }
                         else publish(x[0], x[1], iter);
                     } else {
-                        ub::pg_constants<T>(lambda, m.s0, m.s1, il[0], il[1], beta);   // mpc.h:342-343
+                        if constexpr (kFromRecord) { il[0] = ex[0]; il[1] = ex[1]; beta = ex[2]; }   // mpc.h:342-343 (ub::pg_constants)
+                        else ub::pg_constants<T>(rec[2 * H], m.s0, m.s1, il[0], il[1], beta);
                         have = true;
                     }
                 }

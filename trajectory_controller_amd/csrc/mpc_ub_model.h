@@ -144,6 +144,15 @@ template <typename T, bool EQB, bool UBOX = UnitBox<T>::value> struct Unit {
         z0 = (T)0 - ty;
         q1th = gq1 * (lo1 + tphi);
     }
+    // the same from a and c themselves (a refill pass reads them from the instance's record instead of dividing again)
+    TPC_HD void set_instance_ac(T a_, T c_, T ty, T tphi) {
+        a = a_;
+        c = c_;
+        as1 = a * s1; cs0 = c * s0; cs1 = c * s1;
+        dlt = c * (lo0 - lo1);
+        z0 = (T)0 - ty;
+        q1th = gq1 * (lo1 + tphi);
+    }
     TPC_HD bool nonfinite_inputs(T ty, T tphi) const {
         const T big = sizeof(T) == 8 ? (T)1.7976931348623157e308 : (T)3.4028234663852886e38;
         return !(abs_(a) <= big && abs_(c) <= big && abs_(ty) <= big && abs_(tphi) <= big);

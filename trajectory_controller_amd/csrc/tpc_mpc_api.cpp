@@ -15,6 +15,8 @@ namespace tpc {
 #define TPC_DECL_H(h)                                                                             \
     hipError_t lane_compact_h##h(int, const CompactArgs&, const Knobs&, const Workspace&, hipStream_t); \
     hipError_t lane_general_h##h(int, int, const GeneralArgs&, const Knobs&, const Workspace&, hipStream_t); \
+    hipError_t lane_resolve_compact_h##h(const CompactArgs&, const Knobs&, const int32_t*, const uint32_t*, hipStream_t); \
+    hipError_t lane_resolve_general_h##h(int, const GeneralArgs&, const Knobs&, const int32_t*, const uint32_t*, hipStream_t); \
     hipError_t wave_compact_h##h(int, const CompactArgs&, const Knobs&, const Workspace&, hipStream_t); \
     hipError_t wave_general_h##h(int, int, const GeneralArgs&, const Knobs&, const Workspace&, hipStream_t); \
     hipError_t ub_compact_h##h(int, int, const CompactArgs&, const Knobs&, const Workspace&, hipStream_t); \
@@ -223,6 +225,38 @@ hipError_t dispatch_general(int algo, int I, int H, int dtype, const GeneralArgs
     return hipErrorInvalidValue;
 }
 
+// AUTO's parity guarantee (include/tpc_mpc.h): where AUTO picked a tolerance family, the instances that family left on
+// the iteration cap are solved once more by the bit-exact LANE arithmetic and published with dlib's bits.  fp64, the
+// specialised horizons, cold starts; a host opts out with TPC_MPC_PARAM_FAST_CAPPED.
+bool wants_cap_resolve(const tpc_mpc_params* p, int algo_ran) {
+    return p->algo == TPC_MPC_ALGO_AUTO && p->dtype == TPC_MPC_F64 && p->max_iter > 0 &&
+           (p->options & TPC_MPC_PARAM_FAST_CAPPED) == 0 && horizon_specialised(p->horizon) &&
+           (algo_ran == TPC_MPC_ALGO_WAVE || algo_ran == TPC_MPC_ALGO_LANE_FMA || algo_ran == TPC_MPC_ALGO_GROUP);
+}
+// where the first pass leaves its iteration counts when the caller did not ask for them
+int cap_iters_buffer(tpc_mpc_context* h, int64_t n, int32_t** out) {
+    int rc = ensure(h, &h->cap_iters, &h->cap_iters_bytes, pad256(n * 4));
+    if (rc) return rc;
+    *out = (int32_t*)h->cap_iters;
+    return TPC_MPC_OK;
+}
+hipError_t resolve_compact(int H, const CompactArgs& a, const Knobs& k, hipStream_t s) {
+    switch (H) {
+#define X(h) case h: return lane_resolve_compact_h##h(a, k, a.iters, a.flags, s);
+        X(4) X(5) X(10) X(20) X(30) X(40)
+#undef X
+    }
+    return hipErrorInvalidValue;
+}
+hipError_t resolve_general(int I, int H, const GeneralArgs& a, const Knobs& k, hipStream_t s) {
+    switch (H) {
+#define X(h) case h: return lane_resolve_general_h##h(I, a, k, a.iters, a.flags, s);
+        X(4) X(5) X(10) X(20) X(30) X(40)
+#undef X
+    }
+    return hipErrorInvalidValue;
+}
+
 int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n, Workspace* ws) {
     ws->state = nullptr;
     ws->ticket = h->ws_words;
@@ -306,6 +340,7 @@ int check_common(tpc_mpc_context* h, const tpc_mpc_params* p) {
     if (p->dtype != TPC_MPC_F64 && p->dtype != TPC_MPC_F32) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad dtype");
     if (p->algo < TPC_MPC_ALGO_AUTO || p->algo > TPC_MPC_ALGO_GROUP) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad algo");
     if (!(p->eps > 0)) return fail(h, TPC_MPC_ERR_BAD_EPS, "eps must be > 0 (mpc.h:202)");
+    if (p->options & ~TPC_MPC_PARAM_FAST_CAPPED) return fail(h, TPC_MPC_ERR_BAD_ARG, "unknown bits in tpc_mpc_params.options");
     if (p->max_iter > 0x7fffffffull || p->smo_iters > 0x7fffffffull)
         return fail(h, TPC_MPC_ERR_BAD_ARG, "max_iter / smo_iters must fit in 31 bits");
     return TPC_MPC_OK;
@@ -394,10 +429,15 @@ int general_launch(tpc_mpc_context* h, const tpc_mpc_params* p, const tpc_mpc_ge
     a.u0 = io->u0; a.iters = io->iters;
     a.flags = h->ws_words + 1;
     a.work_hint = take_hint(h, n);
+    const bool fix = wants_cap_resolve(p, algo) && !a.controls && !a.v;
+    int rc = TPC_MPC_OK;
+    if (fix && !a.iters) rc = cap_iters_buffer(h, n, &a.iters);
+    if (rc) return rc;
     Workspace ws;
-    int rc = prepare_workspace(h, algo, H, p->dtype, n, &ws);
+    rc = prepare_workspace(h, algo, H, p->dtype, n, &ws);
     if (rc) return rc;
     hipError_t e = dispatch_general(algo, I, H, p->dtype, a, knobs_of(p), ws, s);
+    if (e == hipSuccess && fix) e = resolve_general(I, H, a, knobs_of(p), s);
     if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
     return TPC_MPC_OK;
 }
@@ -424,10 +464,15 @@ int compact_launch(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const
     a.q[0] = p->weight_y; a.q[1] = p->weight_phi;
     a.r[0] = p->weight_steering_front; a.r[1] = p->weight_steering_rear;
     a.lo[0] = p->lower[0]; a.lo[1] = p->lower[1]; a.hi[0] = p->upper[0]; a.hi[1] = p->upper[1];
+    const bool fix = wants_cap_resolve(p, algo) && a.flags;
+    int rc = TPC_MPC_OK;
+    if (fix && !a.iters) rc = cap_iters_buffer(h, n, &a.iters);
+    if (rc) return rc;
     Workspace ws;
-    int rc = prepare_workspace(h, algo, p->horizon, p->dtype, n, &ws);
+    rc = prepare_workspace(h, algo, p->horizon, p->dtype, n, &ws);
     if (rc) return rc;
     hipError_t e = dispatch_compact(algo, p->horizon, p->dtype, a, knobs_of(p), ws, s);
+    if (e == hipSuccess && fix) e = resolve_compact(p->horizon, a, knobs_of(p), s);
     if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
     return TPC_MPC_OK;
 }
@@ -515,6 +560,7 @@ int tpc_mpc_destroy(tpc_mpc_handle h) {
         if (h->ws_words) (void)hipFree(h->ws_words);
         if (h->stage) (void)hipFree(h->stage);
         if (h->roll) (void)hipFree(h->roll);
+        if (h->cap_iters) (void)hipFree(h->cap_iters);
         if (h->mix) (void)hipFree(h->mix);
         if (h->hint_own) (void)hipFree(h->hint_own);
         if (h->pin_host) (void)hipHostFree(h->pin_host);
@@ -662,12 +708,18 @@ int tpc_mpc_solve_batch_general(tpc_mpc_handle h, const tpc_mpc_params* p,
         }
         a.flags = h->ws_words + 1;
         a.work_hint = take_hint(h, n);
+        const bool fix = wants_cap_resolve(p, algo) && !a.controls && !a.v;
+        if (fix && !a.iters) {
+            rc = cap_iters_buffer(h, n, &a.iters);
+            if (rc) return rc;
+        }
 
         Workspace ws;
         rc = prepare_workspace(h, algo, H, p->dtype, n, &ws);
         if (rc) return rc;
         HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
         hipError_t e = dispatch_general(algo, I, H, p->dtype, a, knobs_of(p), ws, s);
+        if (e == hipSuccess && fix) e = resolve_general(I, H, a, knobs_of(p), s);
         if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
         if (mem == TPC_MPC_HOST) {
             const int64_t hp = io->ld * es, dp = lds * es, w = n * es;
@@ -923,11 +975,17 @@ int tpc_mpc_follow_batch_horizon(tpc_mpc_handle h, const tpc_mpc_params* p, cons
         a.A = fh.A; a.B = fh.B; a.C = fh.C; a.Q = fh.Q; a.R = fh.R; a.lo = fh.lo_out; a.hi = fh.hi_out;
         a.x0 = fh.x0; a.targets = fh.targets; a.u0 = w + off[9]; a.iters = iters;
         a.flags = h->ws_words + 1;
+        const bool fix = wants_cap_resolve(p, algo);
+        if (fix && !a.iters) {
+            rc = cap_iters_buffer(h, n, &a.iters);
+            if (rc) return rc;
+        }
         Workspace ws;
         rc = prepare_workspace(h, algo, H, TPC_MPC_F64, n, &ws);
         if (rc) return rc;
         HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
         e = dispatch_general(algo, I, H, TPC_MPC_F64, a, knobs_of(p), ws, s);
+        if (e == hipSuccess && fix) e = resolve_general(I, H, a, knobs_of(p), s);
         if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
         // u0[2][ldw] -> (front, rear), then the crossing rule
         HIP_TRY(h, hipMemcpyAsync(steering_front, w + off[9], n * 8, hipMemcpyDeviceToDevice, s));

@@ -39,6 +39,9 @@ struct tpc_mpc_context {
     // working set of tpc_mpc_rollout / tpc_mpc_follow_batch* (model copy, state, targets, controller memory)
     void* roll = nullptr;
     int64_t roll_bytes = 0;
+    // iteration counts of a tolerance family's pass when the caller asked for none (AUTO re-solves what ended on the cap)
+    void* cap_iters = nullptr;
+    int64_t cap_iters_bytes = 0;
     // mixed-horizon batches: bin-contiguous copies of the inputs and outputs, permutation, counters
     void* mix = nullptr;
     int64_t mix_bytes = 0;

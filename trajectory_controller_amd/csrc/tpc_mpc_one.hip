@@ -407,6 +407,15 @@ int one_shot_solve(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double
     h->one_flags = (uint32_t)(info >> 32);
     h->one_iters = (int32_t)(uint32_t)info;
     h->one_valid = true;
+    // AUTO's guarantee (include/tpc_mpc.h): a solve the resident wavefront (WAVE arithmetic) left on the iteration cap is
+    // solved once more in dlib's own operation order -- one LANE launch; the flag came with the answer, so it costs
+    // nothing to know
+    if ((h->one_flags & TPC_MPC_FLAG_MAX_ITER) && p->algo == TPC_MPC_ALGO_AUTO && p->max_iter > 0 &&
+        (p->options & TPC_MPC_PARAM_FAST_CAPPED) == 0) {
+        tpc_mpc_params q = *p;
+        q.algo = TPC_MPC_ALGO_LANE;
+        return launch_path(h, &q, v, dy, dphi, front, rear);
+    }
     return TPC_MPC_OK;
 }
 

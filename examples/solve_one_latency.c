@@ -4,10 +4,12 @@
  *     gcc -std=c99 -O2 -Iinclude examples/solve_one_latency.c -Ltrajectory_controller_amd/lib -ltpc_mpc
  * Prints, per horizon: the resident path (default) with a new speed in every call and with the speed held (the
  * wave then reuses the model-only part of its set-up), the same with max_iter = 0 (mailbox round trip + set-up only,
- * no iterations) and the launch path (tpc_mpc_set_resident(h, 0)). */
+ * no iterations) and the launch path (tpc_mpc_set_resident(h, 0)).
+ *     ./a.out [reps] host      the host path only: a handle created with TPC_MPC_DEVICE_NONE (no GPU needed) */
 #define _POSIX_C_SOURCE 199309L
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <time.h>
 
 #include "tpc_mpc.h"
@@ -47,6 +49,17 @@ static void run(tpc_mpc_handle h, const tpc_mpc_params* p, int reps, const char*
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 2000;
     tpc_mpc_handle h;
+    if (argc > 2 && strcmp(argv[2], "host") == 0) {   /* the calling thread solves: csrc/tpc_mpc_host.cpp */
+        const int hh[] = {4, 5, 10, 20};
+        if (tpc_mpc_create(TPC_MPC_DEVICE_NONE, &h) != TPC_MPC_OK) { fprintf(stderr, "tpc_mpc_create: %s\n", tpc_mpc_last_error(NULL)); return 3; }
+        for (int k = 0; k < 4; ++k) {
+            tpc_mpc_params p;
+            tpc_mpc_default_params(&p, hh[k]);
+            run(h, &p, reps, "host path, new v per call", 1);
+        }
+        tpc_mpc_destroy(h);
+        return 0;
+    }
     if (tpc_mpc_create(0, &h) != TPC_MPC_OK) { fprintf(stderr, "tpc_mpc_create: %s\n", tpc_mpc_last_error(NULL)); return 3; }
     const int hs[] = {4, 10, 20, 30, 40};
     for (int k = 0; k < 5; ++k) {

@@ -84,12 +84,33 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
  *          with the linear term kept, scaled, as dlib keeps it: 1.2 - 1.5x LANE.  Requests it cannot
  *          take (controller state in or out, general form at N = 30 / 40, degenerate compact bounds, other
  *          horizons) run LANE.
- *   AUTO : the fastest family that meets the 1e-6 parity target: WAVE below a measured crossover, from
- *          there up LANE_FMA where it exists (above) and LANE elsewhere.  On a 256-CU part the
- *          crossover lies between 21 504 and 32 768 instances (the largest batch the WAVE work queue takes)
- *          depending on horizon, dtype and form -- compact form, fp64: 28 672 at N = 4, 5, 26 624 at N = 10,
- *          21 504 at N = 20, 32 768 at N = 30, 40; general form at N = 40: 19 456 -- and scales with the CU count.  A host
- *          that needs dlib's bits asks for LANE. */
+ *   GROUP : G lanes per instance (2, 4 or 8; TPC_MPC_OPT_GROUP_LANES pins it), 64 / G instances per wavefront: the
+ *          family between WAVE and LANE_FMA, for batches too large for a wavefront each and too small to give every
+ *          lane of the chip an instance.  LANE_FMA's arithmetic with the horizon cut into G chunks: each lane runs
+ *          its chunk's part of the two recurrences of mpc.h:275-281 in registers, and the chunks are joined by an
+ *          exclusive scan over the lanes of the group (the recurrences are affine with a constant matrix, so joining
+ *          costs log2 G steps of DPP moves and fused multiply-adds).  Persistent wavefronts, one per SIMD, groups
+ *          refilled from LANE_FMA's longest-first queue; the coordinate-descent phase and the records are LANE_FMA's
+ *          own.  Compact form, N = 10, 20, 30, 40 (chunks padded where G does not divide N), the requests LANE_FMA
+ *          takes; anything else runs LANE_FMA / LANE.  Same statement as LANE_FMA: max |du| vs dlib ~2e-13 at N = 20,
+ *          ~1.5e-12 at N = 40, identical iteration counts.  16 384 instances of N = 20: 1.5 ms (WAVE 2.9, LANE_FMA
+ *          3.5); of N = 40: 4.8 ms (15.0 / 30.6).
+ *   AUTO : the fastest family that meets the 1e-6 parity target, and it GUARANTEES that target where a guarantee is
+ *          possible.  Family: WAVE below a crossover measured per dtype and horizon, then GROUP with 8, 4, 2 lanes
+ *          per instance, then LANE_FMA (csrc/auto_table.h, generated by scripts/measure_crossover.py on a 256-CU
+ *          part and scaled by the CU count: at N = 20 in fp64 WAVE below 7 094 instances, GROUP up to 160 530,
+ *          LANE_FMA beyond); LANE where none of them takes the request.  Guarantee (fp64, the specialised horizons,
+ *          cold starts -- every compact entry point and the general form without controls_inout / v_inout): an
+ *          instance that ends on max_iter has not converged, and over thousands of iterations of an ill-conditioned
+ *          problem the tolerance families' rounding differences grow (2.3e-5 seen under adversarial parameters), so
+ *          such instances are solved ONCE MORE by the bit-exact LANE kernels in the same call and come back with
+ *          dlib's bits; every other instance took dlib's decisions on quantities that differ from dlib's by rounding
+ *          (<= 1e-9 asserted, ~1e-12 observed).  The second pass costs three empty launches when nothing ended on
+ *          the cap; when something did, it lasts max_iter iterations at one lane's pace (N = 40, max_iter 10 000:
+ *          50 ms -- BASELINE config 5, where a tenth of the N = 40 instances end there: 58 ms with it, 7 ms without).
+ *          A host that prefers the tolerance families' answer for capped instances sets TPC_MPC_PARAM_FAST_CAPPED in
+ *          tpc_mpc_params.options; an explicitly demanded family is taken at its word; a host that needs dlib's bits
+ *          everywhere asks for LANE. */
 typedef enum tpc_mpc_algo {
     TPC_MPC_ALGO_AUTO = 0, TPC_MPC_ALGO_WAVE = 1, TPC_MPC_ALGO_LANE = 2, TPC_MPC_ALGO_LANE_FMA = 3, TPC_MPC_ALGO_GROUP = 4
 } tpc_mpc_algo;
@@ -138,7 +159,15 @@ typedef struct tpc_mpc_params {
 /* Fill *p with the defaults above for horizon H, fp64, algo AUTO. */
 int tpc_mpc_default_params(tpc_mpc_params* p, int horizon);
 
-/* Create a solver bound to HIP device `device` (>= 0).  Owns device scratch; no other state. */
+/* Create a solver bound to HIP device `device` (>= 0).  Owns device scratch; no other state.
+ * device == TPC_MPC_DEVICE_NONE creates a HOST-ONLY handle: no GPU is looked for or touched, and the one call it serves
+ * is tpc_mpc_solve_one -- on the calling thread, in the LANE_FMA family's arithmetic (csrc/tpc_mpc_host.cpp; fp64, the
+ * specialised horizons, finite bounds with upper > lower, a CPU with fused multiply-add) -- which is what a host that
+ * solves one short-horizon problem per cycle wants ("usable from any single thread without a GPU"): at
+ * the reference's N = 4 a core needs ~3 us where the GPU round trip needs ~10.  Every batch entry point returns
+ * TPC_MPC_ERR_NO_DEVICE on such a handle.  AUTO's re-solve of capped instances needs the GPU: a host-only handle
+ * returns the tolerance answer and raises TPC_MPC_FLAG_MAX_ITER. */
+#define TPC_MPC_DEVICE_NONE (-1)
 int tpc_mpc_create(int device, tpc_mpc_handle* out);
 int tpc_mpc_destroy(tpc_mpc_handle h);
 
@@ -165,7 +194,8 @@ const char* tpc_mpc_build_info(void);
  * (delta_y, delta_phi) for all steps, x0 = 0, cold start, and returns u0.  `v` is the speed AFTER
  * the module's velocity lookup (src/...follower.cpp:323).  One instance on the GPU (WAVE kernel),
  * served by a resident wavefront that takes requests through a mailbox (see tpc_mpc_set_resident),
- * so the call costs no kernel launch and no synchronisation call. */
+ * so the call costs no kernel launch and no synchronisation call -- or, on a host-only handle (TPC_MPC_DEVICE_NONE)
+ * and for the horizons TPC_MPC_OPT_HOST_SOLVE_ONE names, on the calling thread (csrc/tpc_mpc_host.cpp). */
 int tpc_mpc_solve_one(tpc_mpc_handle h, const tpc_mpc_params* p, double v, double delta_y,
                       double delta_phi, double* steering_front, double* steering_rear);
 
@@ -357,8 +387,18 @@ int tpc_mpc_reserve(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n, int me
  *                            1 = strictly one, 2 / 4 = pairs / fours where they fit.  Same arithmetic per instance.
  *   TPC_MPC_OPT_MAILBOX_HOST 1 = tpc_mpc_solve_one's request lines live in pinned host memory even where the
  *                            CPU could write device memory through the BAR (0, default: device memory where
- *                            hipDeviceAttributeIsLargeBar says so).  Restarts the resident wavefront. */
-typedef enum tpc_mpc_option { TPC_MPC_OPT_WAVE_GROUP = 1, TPC_MPC_OPT_MAILBOX_HOST = 2, TPC_MPC_OPT_GROUP_LANES = 3 } tpc_mpc_option;
+ *                            hipDeviceAttributeIsLargeBar says so).  Restarts the resident wavefront (the idle
+ *                            timeout and "resident off" of tpc_mpc_set_resident are kept).
+ *   TPC_MPC_OPT_GROUP_LANES  lanes per instance of the GROUP family: 0 (default) = the measured best for the batch
+ *                            size (csrc/auto_table.h), 2 / 4 / 8 where that size is built for the horizon (N = 10:
+ *                            2, 4; N = 20, 30: 2, 4, 8; N = 40: 4, 8).
+ *   TPC_MPC_OPT_HOST_SOLVE_ONE  tpc_mpc_solve_one on the CALLING THREAD for horizons up to this value (0, default:
+ *                            never): the host path of csrc/tpc_mpc_host.cpp, as on a handle created with
+ *                            TPC_MPC_DEVICE_NONE.  For a module that solves one short-horizon problem per cycle --
+ *                            the reference's own N = 4 -- set it to 5: a core needs ~3 us where the round trip to the
+ *                            resident wavefront needs ~10. */
+typedef enum tpc_mpc_option { TPC_MPC_OPT_WAVE_GROUP = 1, TPC_MPC_OPT_MAILBOX_HOST = 2, TPC_MPC_OPT_GROUP_LANES = 3,
+                              TPC_MPC_OPT_HOST_SOLVE_ONE = 4 } tpc_mpc_option;
 int tpc_mpc_set_option(tpc_mpc_handle h, int option, int64_t value);
 
 /* ---- measurement ------------------------------------------------------------------------------ */

@@ -584,6 +584,37 @@ def test_resident_off_survives_a_mailbox_restart(torch_cuda):
         assert abs(f - 0.28258865451261717) <= 1e-12 and abs(r - 0.059891817493776013) <= 1e-12
 
 
+def test_solve_one_host_option_on_a_gpu_handle(torch_cuda, oracle):
+    """TPC_MPC_OPT_HOST_SOLVE_ONE: a GPU handle solves single instances up to the named horizon on the calling thread
+    (csrc/tpc_mpc_host.cpp) -- the same bits a host-only handle returns, within 1e-9 of the resident wavefront's and of
+    the oracle's, longer horizons still go to the GPU, and a solve that ends on the cap under AUTO comes back with
+    dlib's bits (the bit-exact LANE kernels)."""
+    from trajectory_controller_amd import FLAG_MAX_ITER, MpcSolver, capi
+    from trajectory_controller_amd.synth import compact_inputs
+    with _solver(4, "auto") as g, MpcSolver(horizon=4, device=capi.DEVICE_NONE) as hst, _solver(4, "auto") as res:
+        g.set_option(capi.OPT_HOST_SOLVE_ONE, 10)
+        g.set_profiling(True)
+        for H in (4, 10):
+            v, dy, dphi = compact_inputs(H, 60, first=5150 + H)
+            of, orr, oit = oracle.solve_compact(H, v, dy, dphi)
+            for k in range(60):
+                a = g.solve_one(v[k], dy[k], dphi[k], horizon=H)
+                assert a == hst.solve_one(v[k], dy[k], dphi[k], horizon=H)
+                assert g.last_solve_one_flags() == (0, int(oit[k]))
+                b = res.solve_one(v[k], dy[k], dphi[k], horizon=H)
+                assert abs(a[0] - b[0]) <= 1e-9 and abs(a[1] - b[1]) <= 1e-9
+                assert abs(a[0] - of[k]) <= 1e-9 and abs(a[1] - orr[k]) <= 1e-9
+        # beyond the option's horizon: the GPU as before
+        f, r = g.solve_one(2.0, -0.2, 0.1, horizon=20)
+        assert abs(f + 0.34544297733739515) <= 1e-12 and abs(r + 0.21765810887303699) <= 1e-12
+        # on the cap under AUTO: dlib's bits, through one LANE launch (the only launch this handle has made)
+        of, orr, oit = oracle.solve_compact(4, [50.0], [0.3], [0.2])
+        assert oit[0] == 10000
+        f, r = g.solve_one(50.0, 0.3, 0.2, horizon=4)
+        assert bits_equal([f, r], [of[0], orr[0]]) and g.last_solve_one_flags() == (FLAG_MAX_ITER, 10000)
+        assert g.last_kernel_times()[2] == capi.ALGO_LANE
+
+
 def test_last_flags_before_any_solve_one(torch_cuda):
     from trajectory_controller_amd import TpcMpcError
     with _solver(4, "auto") as s:

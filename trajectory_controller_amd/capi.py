@@ -17,7 +17,8 @@ OK = 0
 F64, F32 = 0, 1
 HOST, DEVICE = 0, 1
 ALGO_AUTO, ALGO_WAVE, ALGO_LANE, ALGO_LANE_FMA, ALGO_GROUP = 0, 1, 2, 3, 4
-OPT_WAVE_GROUP, OPT_MAILBOX_HOST, OPT_GROUP_LANES = 1, 2, 3
+OPT_WAVE_GROUP, OPT_MAILBOX_HOST, OPT_GROUP_LANES, OPT_HOST_SOLVE_ONE = 1, 2, 3, 4
+DEVICE_NONE = -1   # tpc_mpc_create: a host-only handle
 FLAG_NONFINITE, FLAG_MAX_ITER, FLAG_BAD_MODEL = 0x1, 0x2, 0x4
 PARAM_FAST_CAPPED = 0x1   # tpc_mpc_params.options
 

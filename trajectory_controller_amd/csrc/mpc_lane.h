@@ -138,16 +138,17 @@ template <typename T, int H> struct CdOcc {
 };
 
 //
-// RESOLVE = true is the same kernel carried through to the end of the solve -- the projected-gradient phase of
-// lane_pg_kernel behind the coordinate-descent phase, one lane per instance, no queue -- for the instances of a batch
-// that a tolerance family (WAVE, LANE_FMA, GROUP) left on the iteration cap: `select[k] == max_iter` picks them,
-// `gate` (the batch's flag word) says whether there is any.  Those instances have not converged, and over
-// thousands of iterations of an ill-conditioned problem the tolerance families' rounding differences grow
-// (2.3e-5 seen under adversarial parameters, profiles/r03_fuzz_lane_fma.txt): AUTO re-solves them here, in dlib's
-// own operation order, and publishes dlib's bits (tpc_mpc_api.cpp, resolve_capped).  They all run the same
-// max_iter iterations, so there is nothing for a refill queue to balance.
+// RESOLVE = true restricts the kernel to the instances of a batch that a tolerance family (WAVE, LANE_FMA, GROUP) left
+// on the iteration cap: `select[k] == max_iter` picks them, `gate` (the batch's flag word) says whether there is any,
+// and instead of a sort key each picked instance is appended to the queue the fused projected-gradient kernel reads
+// (`keys` = the queue, `key_hist` = its length; the order is irrelevant: they all run max_iter iterations).  Those
+// instances have not converged, and over thousands of iterations of an ill-conditioned problem the tolerance
+// families' rounding differences grow (2.3e-5 seen under adversarial parameters, profiles/r03_fuzz_lane_fma.txt): AUTO
+// solves them once more here and in lane_pg_fused_kernel, in dlib's own operation order, and publishes dlib's bits
+// (tpc_mpc_api.cpp, wants_cap_resolve).  With the gate closed -- the usual case -- every wavefront leaves at once, the
+// queue stays empty and the projected-gradient kernels return on their first look at it.
 template <typename T, int I, int H, class Model, class Args, bool RESOLVE = false>
-__global__ __launch_bounds__(64, (RESOLVE ? 1 : CdOcc<T, H>::value)) void lane_cd_kernel(Args g, Knobs kn, T* __restrict__ recs,
+__global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args g, Knobs kn, T* __restrict__ recs,
                                                          uint32_t* __restrict__ keys,
                                                          uint32_t* __restrict__ key_rank,
                                                          uint32_t* __restrict__ key_hist,
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(64, (RESOLVE ? 1 : CdOcc<T, H>::value)) void lane_c
     // fused PG kernel (stats[2], read by both builds at launch; see lane_pg_fused_kernel)
     // (one atomic per wavefront at most: when the failing condition is batch-wide -- bounds that do
     // not straddle zero, a huge eps -- every lane fails, and n atomics on one word would serialise)
-    if constexpr (Model::kFastStop && !RESOLVE) {
+    if constexpr (Model::kFastStop) {
         const unsigned long long failing = __ballot(!m.fast_stop_ok(mm_max, eps, lambda, H));
         if (failing != 0ull && lane == __ffsll((long long)failing) - 1) atomicOr(&stats[2], 1ull);
     }
@@ -283,51 +284,6 @@ __global__ __launch_bounds__(64, (RESOLVE ? 1 : CdOcc<T, H>::value)) void lane_c
         }
     }
 
-    if constexpr (RESOLVE) {
-        // ---- the projected-gradient phase (mpc.h:336-345) in the same lane: lane_pg_kernel's iteration.  dlib's v
-        // takes the place of Q_diag in LDS (the coordinate-descent phase is over): v := u where the last
-        // coordinate-descent iteration ran its update (mpc.h:330-334), else a fresh controller's zeros.
-        auto vget = [&](int q) { return s_qd[q][lane]; };
-#pragma unroll
-        for (int q = 0; q < 2 * H; ++q)
-            if ((q & 1) < I) s_qd[q][lane] = vinit ? u[q] : (T)0;
-        const T inv_lambda = (T)1.0 / lambda;                         // mpc.h:342
-        const T sq = tsqrt(lambda);
-        const T beta = (sq - (T)1) / (sq + (T)1);                     // mpc.h:343
-        bool run = !stopped && iter < kn.max_iter;
-#pragma unroll 1
-        while (__ballot(run) != 0ull) {
-            gradient<T, I, H>(m, u, [&](int q) { return s_mm[q][lane]; }, w);
-            T acc[4] = {(T)0, (T)0, (T)0, (T)0};
-#pragma unroll
-            for (int i = 0; i < H; ++i)
-#pragma unroll
-                for (int j = 0; j < I; ++j) {
-                    const T uu = u[2 * i + j], dd = w[2 * i + j];
-                    const T up = (uu <= m.lo(j)) ? (T)0 : dd;      // mpc.h:298-299
-                    const T dn = (uu >= m.hi(j)) ? (T)0 : -dd;
-                    acc[(i * I + j) & 3] = tmax(acc[(i * I + j) & 3], tmax(up, dn));
-                }
-            const T max_df = tmax(tmax(acc[0], acc[1]), tmax(acc[2], acc[3]));
-            if (run && max_df < eps) { run = false; stopped = true; }   // mpc.h:310-311 (before the update)
-            if (run) {
-#pragma unroll
-                for (int i = 0; i < H; ++i)
-#pragma unroll
-                    for (int j = 0; j < I; ++j) {
-                        const int q = 2 * i + j;
-                        const T v_old = s_qd[q][lane];
-                        const T vn = clamp3(u[q] - inv_lambda * w[q], m.lo(j), m.hi(j));   // mpc.h:342
-                        s_qd[q][lane] = vn;
-                        u[q] = clamp3(vn + beta * (vn - v_old), m.lo(j), m.hi(j));         // mpc.h:343
-                    }
-                ++iter;
-                run = iter < kn.max_iter;                                                   // mpc.h:271
-            }
-        }
-        LaneIO<T, I, H, Args>::write(g, k, u, vget, iter);
-        return;
-    }
     T* rec = recs + (int64_t)k * RL;
 #pragma unroll
     for (int q = 0; q < 2 * H; ++q) rec[q] = ((q & 1) < I) ? u[q] : (T)0;
@@ -374,6 +330,11 @@ __global__ __launch_bounds__(64, (RESOLVE ? 1 : CdOcc<T, H>::value)) void lane_c
         if (nonfinite) f |= 0x1u;
         if (badmodel) f |= 0x4u;
         if (!stopped) f |= 0x2u;          // ran into max_iter inside this phase
+    }
+    if constexpr (RESOLVE) {
+        (void)key;
+        if (!finished) keys[atomicAdd(key_hist, 1u)] = (uint32_t)k;   // the queue of lane_pg_fused_kernel, in any order
+        return;
     }
     raise_flags(g.flags, f);              // (every lane of the wavefront gets here)
     keys[k] = key;

@@ -86,13 +86,30 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
     return e;
 }
 
-// the instances of a batch that ended on the iteration cap, once more in dlib's own arithmetic (lane_cd_kernel, RESOLVE)
+// The instances of a batch that ended on the iteration cap, once more in dlib's own arithmetic: lane_cd_kernel
+// (RESOLVE) leaves their records and queues them, the fused projected-gradient kernel finishes them.  `gate` closed
+// (no instance on the cap): one 32-byte memset and three kernels that leave at once.
 template <typename T, int I, class Model, class Args>
-hipError_t resolve(const Args& a, const Knobs& k, const int32_t* select, const uint32_t* gate, hipStream_t s) {
+hipError_t resolve(const Args& a, const Knobs& k, const Workspace& ws, const int32_t* select, const uint32_t* gate, hipStream_t s) {
     if (a.n <= 0) return hipSuccess;
+    T* recs = (T*)ws.state;
+    // ticket, queue length and statistics of this stage sit side by side (resolve_workspace, tpc_mpc_api.cpp): one memset
+    uint32_t* queue_len = ws.ticket + 1;
+    hipError_t e = hipMemsetAsync(ws.ticket, 0, 32, s);
+    if (e != hipSuccess) return e;
     const int grid = (int)((a.n + kWave - 1) / kWave);
-    hipLaunchKernelGGL((lane_cd_kernel<T, I, kH, Model, Args, true>), dim3(grid), dim3(kWave), 0, s, a, k, (T*)nullptr,
-                       (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr, 0, select, gate);
+    hipLaunchKernelGGL((lane_cd_kernel<T, I, kH, Model, Args, true>), dim3(grid), dim3(kWave), 0, s, a, k, recs, ws.order,
+                       (uint32_t*)nullptr, queue_len, ws.stats, 1, select, gate);
+    constexpr int bt = kWave * FusedOcc<T, kH>::value;
+    const int64_t need = (a.n + bt - 1) / bt;
+    if constexpr (Model::kFastStop) {
+        const int fast_cap = pg_grid<TagFast>(lane_pg_fused_kernel<T, I, kH, Model, Args, true>, bt);
+        hipLaunchKernelGGL((lane_pg_fused_kernel<T, I, kH, Model, Args, true>), dim3((unsigned)(need < fast_cap ? need : fast_cap)),
+                           dim3(bt), 0, s, a, k, (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats, (const uint32_t*)queue_len);
+    }
+    const int grid_cap = pg_grid<TagExact>(lane_pg_fused_kernel<T, I, kH, Model, Args, false>, bt);
+    hipLaunchKernelGGL((lane_pg_fused_kernel<T, I, kH, Model, Args, false>), dim3((unsigned)(need < grid_cap ? need : grid_cap)),
+                       dim3(bt), 0, s, a, k, (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats, (const uint32_t*)queue_len);
     return hipGetLastError();
 }
 
@@ -119,14 +136,14 @@ hipError_t TPC_CAT(lane_compact_h, TPC_LANE_H)(int dtype, const CompactArgs& a, 
 }
 
 // fp64 only: the re-solve exists to deliver dlib's bits, and dlib is fp64
-hipError_t TPC_CAT(lane_resolve_compact_h, TPC_LANE_H)(const CompactArgs& a, const Knobs& k, const int32_t* select,
-                                                         const uint32_t* gate, hipStream_t s) {
-    return resolve<double, 2, CompactModel<double>, CompactArgs>(a, k, select, gate, s);
+hipError_t TPC_CAT(lane_resolve_compact_h, TPC_LANE_H)(const CompactArgs& a, const Knobs& k, const Workspace& ws,
+                                                         const int32_t* select, const uint32_t* gate, hipStream_t s) {
+    return resolve<double, 2, CompactModel<double>, CompactArgs>(a, k, ws, select, gate, s);
 }
-hipError_t TPC_CAT(lane_resolve_general_h, TPC_LANE_H)(int I, const GeneralArgs& a, const Knobs& k, const int32_t* select,
-                                                         const uint32_t* gate, hipStream_t s) {
-    if (I == 2) return resolve<double, 2, GeneralModel<double, 2>, GeneralArgs>(a, k, select, gate, s);
-    return resolve<double, 1, GeneralModel<double, 1>, GeneralArgs>(a, k, select, gate, s);
+hipError_t TPC_CAT(lane_resolve_general_h, TPC_LANE_H)(int I, const GeneralArgs& a, const Knobs& k, const Workspace& ws,
+                                                         const int32_t* select, const uint32_t* gate, hipStream_t s) {
+    if (I == 2) return resolve<double, 2, GeneralModel<double, 2>, GeneralArgs>(a, k, ws, select, gate, s);
+    return resolve<double, 1, GeneralModel<double, 1>, GeneralArgs>(a, k, ws, select, gate, s);
 }
 
 hipError_t TPC_CAT(lane_general_h, TPC_LANE_H)(int dtype, int I, const GeneralArgs& a, const Knobs& k,

@@ -15,8 +15,8 @@ namespace tpc {
 #define TPC_DECL_H(h)                                                                             \
     hipError_t lane_compact_h##h(int, const CompactArgs&, const Knobs&, const Workspace&, hipStream_t); \
     hipError_t lane_general_h##h(int, int, const GeneralArgs&, const Knobs&, const Workspace&, hipStream_t); \
-    hipError_t lane_resolve_compact_h##h(const CompactArgs&, const Knobs&, const int32_t*, const uint32_t*, hipStream_t); \
-    hipError_t lane_resolve_general_h##h(int, const GeneralArgs&, const Knobs&, const int32_t*, const uint32_t*, hipStream_t); \
+    hipError_t lane_resolve_compact_h##h(const CompactArgs&, const Knobs&, const Workspace&, const int32_t*, const uint32_t*, hipStream_t); \
+    hipError_t lane_resolve_general_h##h(int, const GeneralArgs&, const Knobs&, const Workspace&, const int32_t*, const uint32_t*, hipStream_t); \
     hipError_t wave_compact_h##h(int, const CompactArgs&, const Knobs&, const Workspace&, hipStream_t); \
     hipError_t wave_general_h##h(int, int, const GeneralArgs&, const Knobs&, const Workspace&, hipStream_t); \
     hipError_t ub_compact_h##h(int, int, const CompactArgs&, const Knobs&, const Workspace&, hipStream_t); \
@@ -63,6 +63,16 @@ const int32_t* take_hint(tpc_mpc_context* h, int64_t n) {
     h->hint = nullptr;
     h->hint_n = 0;
     return p;
+}
+
+// the host path's translation unit is built with -mfma: only on a CPU that has the instruction
+bool host_path_usable() {
+#if defined(__x86_64__)
+    static const bool ok = __builtin_cpu_supports("fma");
+    return ok;
+#else
+    return true;   // (aarch64: fused multiply-add is baseline)
+#endif
 }
 
 // Lanes per instance of the GROUP family for horizon H: what TPC_MPC_OPT_GROUP_LANES pins if it divides H, else the
@@ -240,17 +250,17 @@ int cap_iters_buffer(tpc_mpc_context* h, int64_t n, int32_t** out) {
     *out = (int32_t*)h->cap_iters;
     return TPC_MPC_OK;
 }
-hipError_t resolve_compact(int H, const CompactArgs& a, const Knobs& k, hipStream_t s) {
+hipError_t resolve_compact(int H, const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
     switch (H) {
-#define X(h) case h: return lane_resolve_compact_h##h(a, k, a.iters, a.flags, s);
+#define X(h) case h: return lane_resolve_compact_h##h(a, k, ws, a.iters, a.flags, s);
         X(4) X(5) X(10) X(20) X(30) X(40)
 #undef X
     }
     return hipErrorInvalidValue;
 }
-hipError_t resolve_general(int I, int H, const GeneralArgs& a, const Knobs& k, hipStream_t s) {
+hipError_t resolve_general(int I, int H, const GeneralArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
     switch (H) {
-#define X(h) case h: return lane_resolve_general_h##h(I, a, k, a.iters, a.flags, s);
+#define X(h) case h: return lane_resolve_general_h##h(I, a, k, ws, a.iters, a.flags, s);
         X(4) X(5) X(10) X(20) X(30) X(40)
 #undef X
     }
@@ -305,6 +315,23 @@ int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n,
     return TPC_MPC_OK;
 }
 
+// Workspace of the re-solve of capped instances (the LANE layout in the handle's scratch).  resolve_reserve() grows the
+// scratch BEFORE the first pass is launched -- growing frees, and nothing may be freed under a running kernel's feet --
+// resolve_workspace() carves it afterwards; ticket, statistics and events of the first pass stay what they are
+// (tpc_mpc_last_lane_stats / _kernel_times describe the family that solved the batch).
+int resolve_reserve(tpc_mpc_context* h, int H, int dtype, int64_t n) { return reserve_lane_workspace(h, H, dtype, n); }
+int resolve_workspace(tpc_mpc_context* h, int H, int dtype, int64_t n, Workspace* ws) {
+    const bool ev_valid = h->ev_valid;
+    const int last_algo = h->last_algo;
+    const int rc = prepare_workspace(h, TPC_MPC_ALGO_LANE, H, dtype, n, ws);
+    h->ev_valid = ev_valid;
+    h->last_algo = last_algo;
+    ws->ev = nullptr;
+    ws->ticket = h->ws_words + 16;   // ticket | queue length | statistics: 32 contiguous bytes (mpc_lane_inst.hip, resolve)
+    ws->stats = (unsigned long long*)(h->ws_words + 18);
+    return rc;
+}
+
 // Copy `rows` rows of `width` bytes between arrays of different leading dimensions (pitches in bytes).
 hipError_t copy_rows(void* dst, int64_t dpitch, const void* src, int64_t spitch, int64_t width, int64_t rows,
                      hipMemcpyKind kind, hipStream_t s) {
@@ -332,8 +359,11 @@ bool group_applicable(const tpc_mpc_context* h, const tpc_mpc_params* p, int H) 
     return (p->algo == TPC_MPC_ALGO_AUTO || p->algo == TPC_MPC_ALGO_GROUP) && fma_usable(p) && group_lanes(h, H) > 0;
 }
 
-int check_common(tpc_mpc_context* h, const tpc_mpc_params* p) {
+// `host_ok`: the entry point also serves a host-only handle (tpc_mpc_solve_one); every other one needs the device
+int check_common(tpc_mpc_context* h, const tpc_mpc_params* p, bool host_ok) {
     if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+    if (h->host_only && !host_ok)
+        return fail(h, TPC_MPC_ERR_NO_DEVICE, "host-only handle (TPC_MPC_DEVICE_NONE): only tpc_mpc_solve_one is served");
     if (!p) return fail(h, TPC_MPC_ERR_BAD_ARG, "null params");
     if (!horizon_ok(p->horizon))
         return fail(h, TPC_MPC_ERR_BAD_HORIZON, "horizon %d outside 1 .. %d", p->horizon, kMaxHorizon);
@@ -400,8 +430,8 @@ int context_new(int device, int cu_count, tpc_mpc_context** out) {
     h->device = device;
     h->cu_count = cu_count;
     hipError_t e = hipSetDevice(device);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->ws_words, 64);
-    if (e == hipSuccess) e = hipMemset(h->ws_words, 0, 64);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->ws_words, 128);
+    if (e == hipSuccess) e = hipMemset(h->ws_words, 0, 128);
     if (e == hipSuccess) e = hipHostMalloc(&h->pin_host, 512, hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) e = hipHostGetDevicePointer(&h->pin_dev, h->pin_host, 0);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->done_ev, hipEventDisableTiming);
@@ -432,12 +462,18 @@ int general_launch(tpc_mpc_context* h, const tpc_mpc_params* p, const tpc_mpc_ge
     const bool fix = wants_cap_resolve(p, algo) && !a.controls && !a.v;
     int rc = TPC_MPC_OK;
     if (fix && !a.iters) rc = cap_iters_buffer(h, n, &a.iters);
+    if (!rc && fix) rc = resolve_reserve(h, H, p->dtype, n);
     if (rc) return rc;
     Workspace ws;
     rc = prepare_workspace(h, algo, H, p->dtype, n, &ws);
     if (rc) return rc;
     hipError_t e = dispatch_general(algo, I, H, p->dtype, a, knobs_of(p), ws, s);
-    if (e == hipSuccess && fix) e = resolve_general(I, H, a, knobs_of(p), s);
+    if (e == hipSuccess && fix) {
+        Workspace ws2;
+        rc = resolve_workspace(h, H, p->dtype, n, &ws2);
+        if (rc) return rc;
+        e = resolve_general(I, H, a, knobs_of(p), ws2, s);
+    }
     if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
     return TPC_MPC_OK;
 }
@@ -467,12 +503,18 @@ int compact_launch(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const
     const bool fix = wants_cap_resolve(p, algo) && a.flags;
     int rc = TPC_MPC_OK;
     if (fix && !a.iters) rc = cap_iters_buffer(h, n, &a.iters);
+    if (!rc && fix) rc = resolve_reserve(h, p->horizon, p->dtype, n);
     if (rc) return rc;
     Workspace ws;
     rc = prepare_workspace(h, algo, p->horizon, p->dtype, n, &ws);
     if (rc) return rc;
     hipError_t e = dispatch_compact(algo, p->horizon, p->dtype, a, knobs_of(p), ws, s);
-    if (e == hipSuccess && fix) e = resolve_compact(p->horizon, a, knobs_of(p), s);
+    if (e == hipSuccess && fix) {
+        Workspace ws2;
+        rc = resolve_workspace(h, p->horizon, p->dtype, n, &ws2);
+        if (rc) return rc;
+        e = resolve_compact(p->horizon, a, knobs_of(p), ws2, s);
+    }
     if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
     return TPC_MPC_OK;
 }
@@ -528,6 +570,14 @@ int tpc_mpc_create(int device, tpc_mpc_handle* out) {
     return guarded(nullptr, [&]() -> int {
         if (!out) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null out pointer");
         *out = nullptr;
+        if (device == TPC_MPC_DEVICE_NONE) {   // host-only: no HIP call, here or ever
+            tpc_mpc_context* h = new (std::nothrow) tpc_mpc_context;
+            if (!h) return fail(nullptr, TPC_MPC_ERR_ALLOC, "out of host memory");
+            h->device = -1;
+            h->host_only = true;
+            *out = h;
+            return TPC_MPC_OK;
+        }
         int count = 0;
         hipError_t e = hipGetDeviceCount(&count);
         if (e != hipSuccess || count <= 0)
@@ -547,6 +597,7 @@ int tpc_mpc_create(int device, tpc_mpc_handle* out) {
 int tpc_mpc_destroy(tpc_mpc_handle h) {
     if (!h) return TPC_MPC_OK;
     return guarded(nullptr, [&]() -> int {
+        if (h->host_only) { delete h; return TPC_MPC_OK; }
         (void)hipSetDevice(h->device);
         one_shot_destroy(h);   // stops the resident kernel before its mailbox goes away
         comm_destroy(h);
@@ -625,10 +676,35 @@ int tpc_mpc_solve_one(tpc_mpc_handle h, const tpc_mpc_params* p, double v, doubl
     return guarded(h, [&]() -> int {
         if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
         if (!steering_front || !steering_rear) return fail(h, TPC_MPC_ERR_BAD_ARG, "null output pointer");
-        int rc = check_common(h, p);
+        int rc = check_common(h, p, true);
         if (rc) return rc;
         rc = check_compact_model(h, p);
         if (rc) return rc;
+        // the host path (csrc/tpc_mpc_host.cpp): a host-only handle always, a GPU handle up to the horizon its option names
+        if (h->host_only || p->horizon <= h->opt_host_horizon) {
+            const bool takes = p->dtype == TPC_MPC_F64 && (p->algo == TPC_MPC_ALGO_AUTO || p->algo == TPC_MPC_ALGO_LANE_FMA) &&
+                               fma_usable(p) && horizon_specialised(p->horizon) && host_path_usable();
+            if (takes) {
+                int iters = 0;
+                unsigned flags = 0;
+                if (host_solve_one(p, v, delta_y, delta_phi, steering_front, steering_rear, &iters, &flags) == 0) {
+                    h->one_flags = flags;
+                    h->one_iters = iters;
+                    h->one_valid = true;
+                    // AUTO's guarantee for a solve that ended on the cap: dlib's bits need the bit-exact LANE kernels
+                    if ((flags & TPC_MPC_FLAG_MAX_ITER) && !h->host_only && p->algo == TPC_MPC_ALGO_AUTO && p->max_iter > 0 &&
+                        (p->options & TPC_MPC_PARAM_FAST_CAPPED) == 0) {
+                        tpc_mpc_params q = *p;
+                        q.algo = TPC_MPC_ALGO_LANE;
+                        return one_shot_solve(h, &q, v, delta_y, delta_phi, steering_front, steering_rear);
+                    }
+                    return TPC_MPC_OK;
+                }
+            }
+            if (h->host_only)
+                return fail(h, TPC_MPC_ERR_NO_DEVICE, "host-only handle: the host path takes fp64, AUTO or LANE_FMA, horizons 4 5 10 20 30 40, "
+                                                      "finite bounds with upper > lower, on a CPU with fused multiply-add");
+        }
         // (no HIP call on the resident path: the parts of one_shot_solve that launch or wait select the device themselves)
         return one_shot_solve(h, p, v, delta_y, delta_phi, steering_front, steering_rear);
     });
@@ -713,13 +789,22 @@ int tpc_mpc_solve_batch_general(tpc_mpc_handle h, const tpc_mpc_params* p,
             rc = cap_iters_buffer(h, n, &a.iters);
             if (rc) return rc;
         }
+        if (fix) {
+            rc = resolve_reserve(h, H, p->dtype, n);
+            if (rc) return rc;
+        }
 
         Workspace ws;
         rc = prepare_workspace(h, algo, H, p->dtype, n, &ws);
         if (rc) return rc;
         HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
         hipError_t e = dispatch_general(algo, I, H, p->dtype, a, knobs_of(p), ws, s);
-        if (e == hipSuccess && fix) e = resolve_general(I, H, a, knobs_of(p), s);
+        if (e == hipSuccess && fix) {
+            Workspace ws2;
+            rc = resolve_workspace(h, H, p->dtype, n, &ws2);
+            if (rc) return rc;
+            e = resolve_general(I, H, a, knobs_of(p), ws2, s);
+        }
         if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
         if (mem == TPC_MPC_HOST) {
             const int64_t hp = io->ld * es, dp = lds * es, w = n * es;
@@ -980,12 +1065,21 @@ int tpc_mpc_follow_batch_horizon(tpc_mpc_handle h, const tpc_mpc_params* p, cons
             rc = cap_iters_buffer(h, n, &a.iters);
             if (rc) return rc;
         }
+        if (fix) {
+            rc = resolve_reserve(h, H, TPC_MPC_F64, n);
+            if (rc) return rc;
+        }
         Workspace ws;
         rc = prepare_workspace(h, algo, H, TPC_MPC_F64, n, &ws);
         if (rc) return rc;
         HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
         e = dispatch_general(algo, I, H, TPC_MPC_F64, a, knobs_of(p), ws, s);
-        if (e == hipSuccess && fix) e = resolve_general(I, H, a, knobs_of(p), s);
+        if (e == hipSuccess && fix) {
+            Workspace ws2;
+            rc = resolve_workspace(h, H, TPC_MPC_F64, n, &ws2);
+            if (rc) return rc;
+            e = resolve_general(I, H, a, knobs_of(p), ws2, s);
+        }
         if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
         // u0[2][ldw] -> (front, rear), then the crossing rule
         HIP_TRY(h, hipMemcpyAsync(steering_front, w + off[9], n * 8, hipMemcpyDeviceToDevice, s));
@@ -1021,6 +1115,7 @@ int tpc_mpc_reserve(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n, int me
 int tpc_mpc_x_set_work_hint(tpc_mpc_handle h, const int32_t* hint, int64_t n, int mem) {
     return guarded(h, [&]() -> int {
         if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+        if (h->host_only) return fail(h, TPC_MPC_ERR_NO_DEVICE, "host-only handle");
         h->hint = nullptr;
         h->hint_n = 0;
         if (!hint || n == 0) return TPC_MPC_OK;   // cleared
@@ -1065,7 +1160,12 @@ int tpc_mpc_set_option(tpc_mpc_handle h, int option, int64_t value) {
                     return fail(h, TPC_MPC_ERR_BAD_ARG, "TPC_MPC_OPT_GROUP_LANES takes 0, 2, 4 or 8");
                 h->opt_group_lanes = (int)value;
                 return TPC_MPC_OK;
+            case TPC_MPC_OPT_HOST_SOLVE_ONE:
+                if (value < 0 || value > kMaxHorizon) return fail(h, TPC_MPC_ERR_BAD_ARG, "TPC_MPC_OPT_HOST_SOLVE_ONE takes a horizon, 0 .. 64");
+                h->opt_host_horizon = (int)value;
+                return TPC_MPC_OK;
             case TPC_MPC_OPT_MAILBOX_HOST:
+                if (h->host_only) return fail(h, TPC_MPC_ERR_NO_DEVICE, "host-only handle");
                 HIP_TRY(h, hipSetDevice(h->device));
                 one_shot_destroy(h);   // the next solve_one sets its mailbox up again, where this option says
                 h->opt_mailbox_host = value != 0;
@@ -1078,6 +1178,7 @@ int tpc_mpc_set_option(tpc_mpc_handle h, int option, int64_t value) {
 int tpc_mpc_set_profiling(tpc_mpc_handle h, int enable) {
     return guarded(h, [&]() -> int {
         if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+        if (h->host_only) return fail(h, TPC_MPC_ERR_NO_DEVICE, "host-only handle");
         HIP_TRY(h, hipSetDevice(h->device));
         if (enable)
             for (auto& e : h->ev) if (!e) HIP_TRY(h, hipEventCreate(&e));
@@ -1107,6 +1208,7 @@ int tpc_mpc_last_kernel_times(tpc_mpc_handle h, double* first_ms, double* second
 int tpc_mpc_last_lane_stats(tpc_mpc_handle h, uint64_t* wave_iterations, uint64_t* refill_blocks) {
     return guarded(h, [&]() -> int {
         if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+        if (h->host_only) return fail(h, TPC_MPC_ERR_NO_DEVICE, "host-only handle");
         if (h->last_algo == kAlgoMixed)
             return fail(h, TPC_MPC_ERR_BAD_ARG, "the last solve was a mixed-horizon batch: its bins ran on child handles");
         HIP_TRY(h, hipSetDevice(h->device));

@@ -138,6 +138,7 @@ int tpc_mpc_comm_unique_id(void* id, size_t len) {
 int tpc_mpc_comm_init_rank(tpc_mpc_handle h, const void* id, size_t len, int rank, int world) {
     return guarded(h, [&]() -> int {
         if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+        if (h->host_only) return fail(h, TPC_MPC_ERR_NO_DEVICE, "host-only handle");
         if (world < 1 || rank < 0 || rank >= world) return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= rank < world");
         comm_destroy(h);
         // a world of one needs no communicator -- unless a test asked for one (tpc_mpc_comm_test_mode: lets a

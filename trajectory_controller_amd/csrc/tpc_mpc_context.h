@@ -32,7 +32,8 @@ struct tpc_mpc_context {
     // device scratch (grown on demand, never shrunk)
     void* ws_state = nullptr;
     int64_t ws_bytes = 0;
-    uint32_t* ws_words = nullptr;   // [0] ticket, [1] flags, [4..] lane statistics
+    uint32_t* ws_words = nullptr;   // [0] ticket, [1] flags, [4..] lane statistics; [16..23] the same for the re-solve of capped
+                                    // instances: [16] ticket, [17] queue length, [18..23] statistics (one memset)
     // staging for TPC_MPC_HOST batches
     void* stage = nullptr;
     int64_t stage_bytes = 0;
@@ -86,6 +87,8 @@ struct tpc_mpc_context {
     bool opt_mailbox_host = false;   // solve_one's request lines in pinned host memory
     int64_t one_idle_us = 20000;     // tpc_mpc_set_resident: idle timeout of the resident wavefront; <= 0 = resident mode off
     int opt_group_lanes = 0;         // GROUP: 0 auto, 2 / 4 / 8 lanes per instance
+    int opt_host_horizon = 0;        // tpc_mpc_solve_one on the calling thread for horizons up to this (0: never)
+    bool host_only = false;          // created with TPC_MPC_DEVICE_NONE: no HIP state at all
     int max_waves = 0;               // persistent-grid limit of this handle's GROUP solves (child handles of a mixed batch: their share of the chip)
 };
 
@@ -148,7 +151,7 @@ inline int ensure(tpc_mpc_context* h, void** buf, int64_t* have, int64_t need) {
 }
 
 // ---- shared between the C-ABI translation units (defined in tpc_mpc_api.cpp) --------------------
-int check_common(tpc_mpc_context* h, const tpc_mpc_params* p);
+int check_common(tpc_mpc_context* h, const tpc_mpc_params* p, bool host_ok = false);
 int check_compact_model(tpc_mpc_context* h, const tpc_mpc_params* p);
 int stream_order_begin(tpc_mpc_context* h, hipStream_t s);
 int stream_order_end(tpc_mpc_context* h, hipStream_t s);
@@ -181,6 +184,9 @@ int context_new(int device, int cu_count, tpc_mpc_context** out);
 int one_shot_solve(tpc_mpc_context* h, const tpc_mpc_params* p, double v, double dy, double dphi, double* front,
                    double* rear);
 void one_shot_destroy(tpc_mpc_context* h);
+// tpc_mpc_host.cpp: one compact instance on the calling thread (0 = solved, -1 = not a request it takes)
+int host_solve_one(const tpc_mpc_params* p, double v, double dy, double dphi, double* front, double* rear, int* iters,
+                   unsigned* flags);
 // tpc_mpc_comm.cpp
 void comm_destroy(tpc_mpc_context* h);
 

@@ -426,6 +426,7 @@ using namespace tpc;
 extern "C" int tpc_mpc_set_resident(tpc_mpc_handle h, int64_t idle_timeout_us) {
     return guarded(h, [&]() -> int {
         if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+        if (h->host_only) return fail(h, TPC_MPC_ERR_NO_DEVICE, "host-only handle");
         if (idle_timeout_us > 10 * 1000 * 1000) return fail(h, TPC_MPC_ERR_BAD_ARG, "idle timeout above 10 s");
         HIP_TRY(h, hipSetDevice(h->device));
         return one_shot_configure(h, idle_timeout_us);

@@ -10,7 +10,7 @@ MI355X_MICROARCH.md (HBM) asks:
 Kernels with no calibration of their own get k = 1 and say so."""
 import csv, json, os, sys
 src = sys.argv[1] if len(sys.argv) > 1 else "profiles"
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
 CONFIGS = {   # tag -> (kernel in the csv, bench key, k, note)
     "headline": ("tpc::ub_pg_kernel<fast>", "ub_pg_kernel_f64_H20_n262144", 1, "strided record reads: k=1 (as calibrated on the LANE kernel's identical access pattern)"),
     "bitexact": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_f64_H20_n262144", 1, "strided record reads: k=1 (calibrated)"),
@@ -19,6 +19,10 @@ CONFIGS = {   # tag -> (kernel in the csv, bench key, k, note)
     "h30": ("tpc::ub_pg_kernel<fast>", "ub_pg_kernel_f64_H30_n262144", 1, "strided record reads: k=1"),
     "h40": ("tpc::ub_pg_kernel<fast>", "ub_pg_kernel_f64_H40_n262144", 1, "strided record reads: k=1"),
     "general": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_general_I2_f64_H20_n262144", 1, "strided record reads + SoA model loads: k=1"),
+    "group_h20": ("tpc::group_pg_kernel", "group_pg_kernel_f64_H20_n16384", 1, "chunked record reads, 8 lanes per record: k=1 (uncalibrated)"),
+    "group_h20_64k": ("tpc::group_pg_kernel", "group_pg_kernel_f64_H20_n65536", 1, "chunked record reads: k=1 (uncalibrated)"),
+    "group_h40": ("tpc::group_pg_kernel", "group_pg_kernel_f64_H40_n16384", 1, "chunked record reads: k=1 (uncalibrated)"),
+    "group_h10": ("tpc::group_pg_kernel", "group_pg_kernel_f64_H10_n32768", 1, "chunked record reads: k=1 (uncalibrated)"),
     "generalfma": ("tpc::ubg_pg_kernel<fast>", "ubg_pg_kernel_general_I2_f64_H20_n262144", 1, "strided record reads + SoA model loads: k=1"),
 }
 import hashlib

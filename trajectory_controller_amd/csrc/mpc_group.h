@@ -107,6 +107,7 @@ __global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel
     const int64_t n_queue = (int64_t)__builtin_nontemporal_load(queue_len);
     // the screened stop test only: a batch the coordinate-descent kernel's screen refused is LANE_FMA's exact build's
     if (__builtin_nontemporal_load(&stats[2]) != 0ull) return;
+    if (n_queue <= 0) return;
 
     const int lane = threadIdx.x;
     const int p = lane & (G - 1);                 // chunk of this lane

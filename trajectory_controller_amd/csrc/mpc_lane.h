@@ -184,9 +184,15 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args 
     // fused PG kernel (stats[2], read by both builds at launch; see lane_pg_fused_kernel)
     // (one atomic per wavefront at most: when the failing condition is batch-wide -- bounds that do
     // not straddle zero, a huge eps -- every lane fails, and n atomics on one word would serialise)
-    if constexpr (Model::kFastStop) {
+    if constexpr (Model::kFastStop && !RESOLVE) {
         const unsigned long long failing = __ballot(!m.fast_stop_ok(mm_max, eps, lambda, H));
         if (failing != 0ull && lane == __ffsll((long long)failing) - 1) atomicOr(&stats[2], 1ull);
+    }
+    // (RESOLVE: the exact-stop-test build of the fused kernel is the only one launched behind this kernel -- one launch
+    // fewer on every call that has nothing to re-solve -- so every wavefront that got here asks for it)
+    if constexpr (RESOLVE) {
+        const unsigned long long here = __ballot(true);
+        if (lane == __ffsll((long long)here) - 1) atomicOr(&stats[2], 1ull);
     }
     const uint32_t cd_iters = kn.smo_iters < kn.max_iter ? kn.smo_iters : kn.max_iter;
     uint32_t iter = 0;
@@ -591,6 +597,7 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
     if constexpr (Model::kFastStop) {
         const bool need_exact = __builtin_nontemporal_load(&stats[2]) != 0ull;
         if (need_exact == FAST) return;
+        if (n_queue <= 0) return;   // (nothing queued: no wavefront should go and ask the ticket -- a thousand returning atomics on one address take 35 us)
     }
     // FusedOcc waves per workgroup, each wave an independent solver using its own 64 columns (no
     // barrier anywhere): one 40 KB workgroup per SIMD pair is what the CU is known to co-schedule.

@@ -88,7 +88,7 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
 
 // The instances of a batch that ended on the iteration cap, once more in dlib's own arithmetic: lane_cd_kernel
 // (RESOLVE) leaves their records and queues them, the fused projected-gradient kernel finishes them.  `gate` closed
-// (no instance on the cap): one 32-byte memset and three kernels that leave at once.
+// (no instance on the cap): one 32-byte memset and two kernels that leave at once.
 template <typename T, int I, class Model, class Args>
 hipError_t resolve(const Args& a, const Knobs& k, const Workspace& ws, const int32_t* select, const uint32_t* gate, hipStream_t s) {
     if (a.n <= 0) return hipSuccess;
@@ -102,11 +102,8 @@ hipError_t resolve(const Args& a, const Knobs& k, const Workspace& ws, const int
                        (uint32_t*)nullptr, queue_len, ws.stats, 1, select, gate);
     constexpr int bt = kWave * FusedOcc<T, kH>::value;
     const int64_t need = (a.n + bt - 1) / bt;
-    if constexpr (Model::kFastStop) {
-        const int fast_cap = pg_grid<TagFast>(lane_pg_fused_kernel<T, I, kH, Model, Args, true>, bt);
-        hipLaunchKernelGGL((lane_pg_fused_kernel<T, I, kH, Model, Args, true>), dim3((unsigned)(need < fast_cap ? need : fast_cap)),
-                           dim3(bt), 0, s, a, k, (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats, (const uint32_t*)queue_len);
-    }
+    // the exact-stop-test build only (bit-exact like the other one; lane_cd_kernel raises stats[2] for it where it
+    // queued anything): one launch fewer on the many calls that have nothing to re-solve
     const int grid_cap = pg_grid<TagExact>(lane_pg_fused_kernel<T, I, kH, Model, Args, false>, bt);
     hipLaunchKernelGGL((lane_pg_fused_kernel<T, I, kH, Model, Args, false>), dim3((unsigned)(need < grid_cap ? need : grid_cap)),
                        dim3(bt), 0, s, a, k, (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats, (const uint32_t*)queue_len);

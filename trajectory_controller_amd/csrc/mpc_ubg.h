@@ -232,6 +232,7 @@ __global__ __launch_bounds__((64 * UbgPlan<T, H>::occ), (UbgPlan<T, H>::occ)) vo
     {
         const bool need_exact = __builtin_nontemporal_load(&stats[2]) != 0ull;
         if (need_exact == FAST) return;
+        if (n_queue <= 0) return;   // (nothing queued: no wavefront should go and ask the ticket -- a thousand returning atomics on one address take 35 us)
     }
     constexpr int BT = kWave * P::occ;
     constexpr bool REGS = P::regs;

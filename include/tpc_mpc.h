@@ -391,7 +391,7 @@ int tpc_mpc_reserve(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n, int me
  *                            timeout and "resident off" of tpc_mpc_set_resident are kept).
  *   TPC_MPC_OPT_GROUP_LANES  lanes per instance of the GROUP family: 0 (default) = the measured best for the batch
  *                            size (csrc/auto_table.h), 2 / 4 / 8 where that size is built for the horizon (N = 10:
- *                            2, 4; N = 20, 30: 2, 4, 8; N = 40: 4, 8).
+ *                            2, 4; N = 20, 30, 40: 2, 4, 8).
  *   TPC_MPC_OPT_HOST_SOLVE_ONE  tpc_mpc_solve_one on the CALLING THREAD for horizons up to this value (0, default:
  *                            never): the host path of csrc/tpc_mpc_host.cpp, as on a handle created with
  *                            TPC_MPC_DEVICE_NONE.  For a module that solves one short-horizon problem per cycle --

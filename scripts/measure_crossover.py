@@ -17,7 +17,7 @@ from trajectory_controller_amd import MpcSolver, capi
 from trajectory_controller_amd.synth import compact_inputs
 
 LADDER = [1024, 1536, 2048, 3072, 4096, 6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536, 98304, 131072, 196608, 262144]
-BUILT = {10: (4, 2), 20: (8, 4, 2), 30: (8, 4, 2), 40: (8, 4)}
+BUILT = {10: (4, 2), 20: (8, 4, 2), 30: (8, 4, 2), 40: (8, 4, 2)}
 args = sys.argv[1:]
 write = "--write" in args
 out_path = None

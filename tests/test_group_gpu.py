@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 GROUP_ATOL = 1e-9
 GROUP = 4          # tpc_mpc_algo
 LANE_FMA = 3
-BUILT = [(10, 2), (10, 4), (20, 2), (20, 4), (20, 8), (30, 2), (30, 4), (30, 8), (40, 4), (40, 8)]
+BUILT = [(10, 2), (10, 4), (20, 2), (20, 4), (20, 8), (30, 2), (30, 4), (30, 8), (40, 2), (40, 4), (40, 8)]
 
 
 @pytest.fixture(scope="module")

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel
     for (int s = 0; s < KS; ++s) cf[s] = cb[s] = (T)0;
     T zst = (T)0, yst = (T)0, la = (T)0;
 
-    T x[2 * L], v[2 * L];
+    T x[2 * L], v[2 * L], v2[2 * L];
     T x0_prev[2] = {(T)0, (T)0};
     T il[2] = {(T)0, (T)0}, beta = (T)0;
     int64_t k = 0;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel
     uint32_t flags = 0;
     uint32_t wave_iters = 0, refills = 0;
 #pragma unroll
-    for (int q = 0; q < 2 * L; ++q) { x[q] = (T)0; v[q] = (T)0; }
+    for (int q = 0; q < 2 * L; ++q) { x[q] = (T)0; v[q] = (T)0; v2[q] = (T)0; }
 
     auto publish = [&](T a0, T a1, uint32_t it) {   // chunk 0 holds step 0
         if (p == 0) {
@@ -229,9 +229,12 @@ __global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel
             continue;
         }
 
-        bool stop = false, cap = false;
-#pragma unroll 1
-        do {
+        // One iteration.  dlib's momentum vector is read from `vi` and written to `vo`: the loop below alternates two
+        // arrays, because an array updated in place costs a register copy per element at the loop's back edge (the new v
+        // is defined while the old one is still needed by the momentum step, so the two cannot share a register).
+        // Returns true when the loop must be left (a refill pass is due, or no group has an instance any more).
+        auto iteration = [&](T (&vi)[2 * L], T (&vo)[2 * L]) -> bool {
+            bool stop = false, cap = false;
             // ---- forward recurrence of the chunk from its local start (mpc.h:275-277)
             T wz[L], wy[L];
             T Z = zst, Y = yst;
@@ -317,8 +320,8 @@ __global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel
                         const T g_lo = m.gap_lo(j, xx, huge), g_hi = m.gap_hi(j, xx, huge);
                         acc = tmax(acc, tabs((T)med3_neglo((float)dd, (float)g_hi, (float)g_lo)));
                     }
-                    x[q] = m.template project<true>(ub::fma_(beta, vn - v[q], vn), j);           // mpc.h:343 (difference form)
-                    v[q] = vn;
+                    x[q] = m.template project<true>(ub::fma_(beta, vn - vi[q], vn), j);          // mpc.h:343 (difference form)
+                    vo[q] = vn;
                 }
             }
             const int go = group_or<G>(tmax(acc0, acc1) >= geps ? 1 : 0);
@@ -331,8 +334,18 @@ __global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel
                 if (stop) { publish(x0_prev[0], x0_prev[1], iter - 1); have = false; }
                 if (cap) { flags |= 0x2u; publish(x[0], x[1], iter); have = false; }
                 const unsigned long long waiting = ballot_b(!have && !exhausted);
-                if (__popcll(waiting) >= GroupRefillBatch<G>::value * G || ballot_b(have) == 0ull) break;
+                if (__popcll(waiting) >= GroupRefillBatch<G>::value * G || ballot_b(have) == 0ull) return true;
             }
+            return false;
+        };
+#pragma unroll 1
+        do {
+            if (iteration(v, v2)) {
+#pragma unroll
+                for (int q = 0; q < 2 * L; ++q) v[q] = v2[q];   // (outside this loop `v` is the current array)
+                break;
+            }
+            if (iteration(v2, v)) break;
         } while (true);
     }
     raise_flags(g.flags, flags);

@@ -36,9 +36,9 @@ inline int device_cus() {
 }
 template <typename T, int G, bool EQB> struct Tag {};
 
-// group sizes built per horizon (measured useful: chunks of 3 .. 10 steps)
+// group sizes built per horizon (chunks of 3 .. 20 steps)
 constexpr bool group_built(int H, int G) {
-    return H == 10 ? (G == 2 || G == 4) : (H == 20 || H == 30) ? (G == 2 || G == 4 || G == 8) : (H == 40 && (G == 4 || G == 8));
+    return H == 10 ? (G == 2 || G == 4) : (H == 20 || H == 30 || H == 40) && (G == 2 || G == 4 || G == 8);
 }
 
 template <typename T, int G, bool EQB>

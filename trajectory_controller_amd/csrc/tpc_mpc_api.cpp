@@ -79,8 +79,8 @@ bool host_path_usable() {
 // measured best; 0 where the family has no kernel (N = 4, 5 and the non-specialised horizons).
 int group_lanes(const tpc_mpc_context* h, int H, int dtype = 0, int64_t n = 0) {
     if (H != 10 && H != 20 && H != 30 && H != 40) return 0;
-    // (what mpc_group_inst.hip builds: chunks of 3 .. 10 steps, padded where G does not divide H)
-    auto built = [&](int G) { return H == 10 ? (G == 2 || G == 4) : H == 40 ? (G == 4 || G == 8) : (G == 2 || G == 4 || G == 8); };
+    // (what mpc_group_inst.hip builds: chunks of 3 .. 20 steps, padded where G does not divide H)
+    auto built = [&](int G) { return H == 10 ? (G == 2 || G == 4) : (G == 2 || G == 4 || G == 8); };
     const int want = h->opt_group_lanes;
     if (want > 0 && built(want)) return want;
     // the measured best for this batch size (auto_table.h); where a row names a size that is not built, the next one down

@@ -75,67 +75,121 @@ template <int CTRL> TPC_DEV float dpp_shr0(float x) {
 // states before a DPP read, so the block opens with them (x may come straight out of an ALU op).
 // Two accumulators: alternate v_fmacs depend on each other at distance 2, ~2 x 4.8 cycles of issue
 // against 8.6 of latency.  S: stride of the entries in k (2 where a lane's row interleaves two inputs).
+// The blocks are spelled by the preprocessor from ONE instruction template (TPC_FM_I): entry q of the row goes to
+// accumulator q & 1, takes its multiplier from asm operand 3 + q and its broadcast lane either as the literal q
+// (fmac_row) or from the immediate operand behind the multipliers (fmac_row8).
+#define TPC_FM_I(SFX, ACC, KOP, BC) "v_fmac_" SFX "_dpp %" #ACC ", %2, %" #KOP " row_newbcast:" BC " row_mask:0xf bank_mask:0xf\n\t"
+#define TPC_FM_1(S) TPC_FM_I(S, 0, 3, "0")
+#define TPC_FM_2(S) TPC_FM_1(S) TPC_FM_I(S, 1, 4, "1")
+#define TPC_FM_3(S) TPC_FM_2(S) TPC_FM_I(S, 0, 5, "2")
+#define TPC_FM_4(S) TPC_FM_3(S) TPC_FM_I(S, 1, 6, "3")
+#define TPC_FM_5(S) TPC_FM_4(S) TPC_FM_I(S, 0, 7, "4")
+#define TPC_FM_6(S) TPC_FM_5(S) TPC_FM_I(S, 1, 8, "5")
+#define TPC_FM_7(S) TPC_FM_6(S) TPC_FM_I(S, 0, 9, "6")
+#define TPC_FM_8(S) TPC_FM_7(S) TPC_FM_I(S, 1, 10, "7")
+#define TPC_FM_9(S) TPC_FM_8(S) TPC_FM_I(S, 0, 11, "8")
+#define TPC_FM_10(S) TPC_FM_9(S) TPC_FM_I(S, 1, 12, "9")
+#define TPC_FM_11(S) TPC_FM_10(S) TPC_FM_I(S, 0, 13, "10")
+#define TPC_FM_12(S) TPC_FM_11(S) TPC_FM_I(S, 1, 14, "11")
+#define TPC_FM_13(S) TPC_FM_12(S) TPC_FM_I(S, 0, 15, "12")
+#define TPC_FM_14(S) TPC_FM_13(S) TPC_FM_I(S, 1, 16, "13")
+#define TPC_FM_15(S) TPC_FM_14(S) TPC_FM_I(S, 0, 17, "14")
+#define TPC_FM_16(S) TPC_FM_15(S) TPC_FM_I(S, 1, 18, "15")
+#define TPC_FK_1 "v"(k[S * 0])
+#define TPC_FK_2 TPC_FK_1, "v"(k[S * 1])
+#define TPC_FK_3 TPC_FK_2, "v"(k[S * 2])
+#define TPC_FK_4 TPC_FK_3, "v"(k[S * 3])
+#define TPC_FK_5 TPC_FK_4, "v"(k[S * 4])
+#define TPC_FK_6 TPC_FK_5, "v"(k[S * 5])
+#define TPC_FK_7 TPC_FK_6, "v"(k[S * 6])
+#define TPC_FK_8 TPC_FK_7, "v"(k[S * 7])
+#define TPC_FK_9 TPC_FK_8, "v"(k[S * 8])
+#define TPC_FK_10 TPC_FK_9, "v"(k[S * 9])
+#define TPC_FK_11 TPC_FK_10, "v"(k[S * 10])
+#define TPC_FK_12 TPC_FK_11, "v"(k[S * 11])
+#define TPC_FK_13 TPC_FK_12, "v"(k[S * 12])
+#define TPC_FK_14 TPC_FK_13, "v"(k[S * 13])
+#define TPC_FK_15 TPC_FK_14, "v"(k[S * 14])
+#define TPC_FK_16 TPC_FK_15, "v"(k[S * 15])
+#define TPC_FMAC_ROW(N, SFX) if constexpr (CNT == N) asm volatile("s_nop 1\n\t" TPC_FM_##N(SFX) : "+v"(a0), "+v"(a1) : "v"(x), TPC_FK_##N)
 template <int CNT, int S = 1> TPC_DEV void fmac_row(double& a0, double& a1, double x, const double* k) {
     static_assert(CNT >= 1 && CNT <= 16, "one 16-lane row");
-    if constexpr (CNT == 1) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]));
-    else if constexpr (CNT == 2) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]));
-    else if constexpr (CNT == 3) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]));
-    else if constexpr (CNT == 4) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]));
-    else if constexpr (CNT == 5) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]));
-    else if constexpr (CNT == 6) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]));
-    else if constexpr (CNT == 7) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]));
-    else if constexpr (CNT == 8) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]));
-    else if constexpr (CNT == 9) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]));
-    else if constexpr (CNT == 10) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]));
-    else if constexpr (CNT == 11) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]));
-    else if constexpr (CNT == 12) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]), "v"(k[S * 11]));
-    else if constexpr (CNT == 13) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]), "v"(k[S * 11]), "v"(k[S * 12]));
-    else if constexpr (CNT == 14) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]), "v"(k[S * 11]), "v"(k[S * 12]), "v"(k[S * 13]));
-    else if constexpr (CNT == 15) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]), "v"(k[S * 11]), "v"(k[S * 12]), "v"(k[S * 13]), "v"(k[S * 14]));
-    else if constexpr (CNT == 16) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]), "v"(k[S * 11]), "v"(k[S * 12]), "v"(k[S * 13]), "v"(k[S * 14]), "v"(k[S * 15]));
+    TPC_FMAC_ROW(1, "f64");
+    TPC_FMAC_ROW(2, "f64");
+    TPC_FMAC_ROW(3, "f64");
+    TPC_FMAC_ROW(4, "f64");
+    TPC_FMAC_ROW(5, "f64");
+    TPC_FMAC_ROW(6, "f64");
+    TPC_FMAC_ROW(7, "f64");
+    TPC_FMAC_ROW(8, "f64");
+    TPC_FMAC_ROW(9, "f64");
+    TPC_FMAC_ROW(10, "f64");
+    TPC_FMAC_ROW(11, "f64");
+    TPC_FMAC_ROW(12, "f64");
+    TPC_FMAC_ROW(13, "f64");
+    TPC_FMAC_ROW(14, "f64");
+    TPC_FMAC_ROW(15, "f64");
+    TPC_FMAC_ROW(16, "f64");
 }
 template <int CNT, int S = 1> TPC_DEV void fmac_row(float& a0, float& a1, float x, const float* k) {
     static_assert(CNT >= 1 && CNT <= 16, "one 16-lane row");
-    if constexpr (CNT == 1) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]));
-    else if constexpr (CNT == 2) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]));
-    else if constexpr (CNT == 3) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]));
-    else if constexpr (CNT == 4) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]));
-    else if constexpr (CNT == 5) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]));
-    else if constexpr (CNT == 6) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]));
-    else if constexpr (CNT == 7) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]));
-    else if constexpr (CNT == 8) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]));
-    else if constexpr (CNT == 9) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]));
-    else if constexpr (CNT == 10) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]));
-    else if constexpr (CNT == 11) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]));
-    else if constexpr (CNT == 12) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]), "v"(k[S * 11]));
-    else if constexpr (CNT == 13) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]), "v"(k[S * 11]), "v"(k[S * 12]));
-    else if constexpr (CNT == 14) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]), "v"(k[S * 11]), "v"(k[S * 12]), "v"(k[S * 13]));
-    else if constexpr (CNT == 15) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]), "v"(k[S * 11]), "v"(k[S * 12]), "v"(k[S * 13]), "v"(k[S * 14]));
-    else if constexpr (CNT == 16) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "v"(k[S * 8]), "v"(k[S * 9]), "v"(k[S * 10]), "v"(k[S * 11]), "v"(k[S * 12]), "v"(k[S * 13]), "v"(k[S * 14]), "v"(k[S * 15]));
+    TPC_FMAC_ROW(1, "f32");
+    TPC_FMAC_ROW(2, "f32");
+    TPC_FMAC_ROW(3, "f32");
+    TPC_FMAC_ROW(4, "f32");
+    TPC_FMAC_ROW(5, "f32");
+    TPC_FMAC_ROW(6, "f32");
+    TPC_FMAC_ROW(7, "f32");
+    TPC_FMAC_ROW(8, "f32");
+    TPC_FMAC_ROW(9, "f32");
+    TPC_FMAC_ROW(10, "f32");
+    TPC_FMAC_ROW(11, "f32");
+    TPC_FMAC_ROW(12, "f32");
+    TPC_FMAC_ROW(13, "f32");
+    TPC_FMAC_ROW(14, "f32");
+    TPC_FMAC_ROW(15, "f32");
+    TPC_FMAC_ROW(16, "f32");
 }
 
 // ... up to eight entries of a row starting at lane OFF (the broadcast lane is an immediate operand here)
+#define TPC_F8_1(S) TPC_FM_I(S, 0, 3, "%c4")
+#define TPC_F8_2(S) TPC_FM_I(S, 0, 3, "%c5") TPC_FM_I(S, 1, 4, "%c6")
+#define TPC_F8_3(S) TPC_FM_I(S, 0, 3, "%c6") TPC_FM_I(S, 1, 4, "%c7") TPC_FM_I(S, 0, 5, "%c8")
+#define TPC_F8_4(S) TPC_FM_I(S, 0, 3, "%c7") TPC_FM_I(S, 1, 4, "%c8") TPC_FM_I(S, 0, 5, "%c9") TPC_FM_I(S, 1, 6, "%c10")
+#define TPC_F8_5(S) TPC_FM_I(S, 0, 3, "%c8") TPC_FM_I(S, 1, 4, "%c9") TPC_FM_I(S, 0, 5, "%c10") TPC_FM_I(S, 1, 6, "%c11") TPC_FM_I(S, 0, 7, "%c12")
+#define TPC_F8_6(S) TPC_FM_I(S, 0, 3, "%c9") TPC_FM_I(S, 1, 4, "%c10") TPC_FM_I(S, 0, 5, "%c11") TPC_FM_I(S, 1, 6, "%c12") TPC_FM_I(S, 0, 7, "%c13") TPC_FM_I(S, 1, 8, "%c14")
+#define TPC_F8_7(S) TPC_FM_I(S, 0, 3, "%c10") TPC_FM_I(S, 1, 4, "%c11") TPC_FM_I(S, 0, 5, "%c12") TPC_FM_I(S, 1, 6, "%c13") TPC_FM_I(S, 0, 7, "%c14") TPC_FM_I(S, 1, 8, "%c15") TPC_FM_I(S, 0, 9, "%c16")
+#define TPC_F8_8(S) TPC_FM_I(S, 0, 3, "%c11") TPC_FM_I(S, 1, 4, "%c12") TPC_FM_I(S, 0, 5, "%c13") TPC_FM_I(S, 1, 6, "%c14") TPC_FM_I(S, 0, 7, "%c15") TPC_FM_I(S, 1, 8, "%c16") TPC_FM_I(S, 0, 9, "%c17") TPC_FM_I(S, 1, 10, "%c18")
+#define TPC_FN_1 "n"(OFF + 0)
+#define TPC_FN_2 TPC_FN_1, "n"(OFF + 1)
+#define TPC_FN_3 TPC_FN_2, "n"(OFF + 2)
+#define TPC_FN_4 TPC_FN_3, "n"(OFF + 3)
+#define TPC_FN_5 TPC_FN_4, "n"(OFF + 4)
+#define TPC_FN_6 TPC_FN_5, "n"(OFF + 5)
+#define TPC_FN_7 TPC_FN_6, "n"(OFF + 6)
+#define TPC_FN_8 TPC_FN_7, "n"(OFF + 7)
+#define TPC_FMAC_ROW8(N, SFX) if constexpr (CNT == N) asm volatile("s_nop 1\n\t" TPC_F8_##N(SFX) : "+v"(a0), "+v"(a1) : "v"(x), TPC_FK_##N, TPC_FN_##N)
 template <int CNT, int OFF, int S> TPC_DEV void fmac_row8(double& a0, double& a1, double x, const double* k) {
     static_assert(CNT >= 1 && CNT <= 8 && OFF + CNT <= 16, "part of one 16-lane row");
-    if constexpr (CNT == 1) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%c4 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "n"(OFF + 0));
-    else if constexpr (CNT == 2) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%c5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%c6 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "n"(OFF + 0), "n"(OFF + 1));
-    else if constexpr (CNT == 3) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%c6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%c7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:%c8 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2));
-    else if constexpr (CNT == 4) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%c7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%c8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:%c9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:%c10 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3));
-    else if constexpr (CNT == 5) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%c8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%c9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:%c10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:%c11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:%c12 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3), "n"(OFF + 4));
-    else if constexpr (CNT == 6) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%c9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%c10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:%c11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:%c12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:%c13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:%c14 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3), "n"(OFF + 4), "n"(OFF + 5));
-    else if constexpr (CNT == 7) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%c10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%c11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:%c12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:%c13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:%c14 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:%c15 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:%c16 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3), "n"(OFF + 4), "n"(OFF + 5), "n"(OFF + 6));
-    else if constexpr (CNT == 8) asm volatile("s_nop 1\n\t" "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%c11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%c12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %5 row_newbcast:%c13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %6 row_newbcast:%c14 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %7 row_newbcast:%c15 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %8 row_newbcast:%c16 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %0, %2, %9 row_newbcast:%c17 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %1, %2, %10 row_newbcast:%c18 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3), "n"(OFF + 4), "n"(OFF + 5), "n"(OFF + 6), "n"(OFF + 7));
+    TPC_FMAC_ROW8(1, "f64");
+    TPC_FMAC_ROW8(2, "f64");
+    TPC_FMAC_ROW8(3, "f64");
+    TPC_FMAC_ROW8(4, "f64");
+    TPC_FMAC_ROW8(5, "f64");
+    TPC_FMAC_ROW8(6, "f64");
+    TPC_FMAC_ROW8(7, "f64");
+    TPC_FMAC_ROW8(8, "f64");
 }
 template <int CNT, int OFF, int S> TPC_DEV void fmac_row8(float& a0, float& a1, float x, const float* k) {
     static_assert(CNT >= 1 && CNT <= 8 && OFF + CNT <= 16, "part of one 16-lane row");
-    if constexpr (CNT == 1) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:%c4 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "n"(OFF + 0));
-    else if constexpr (CNT == 2) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:%c5 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:%c6 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "n"(OFF + 0), "n"(OFF + 1));
-    else if constexpr (CNT == 3) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:%c6 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:%c7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:%c8 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2));
-    else if constexpr (CNT == 4) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:%c7 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:%c8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:%c9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:%c10 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3));
-    else if constexpr (CNT == 5) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:%c8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:%c9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:%c10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:%c11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:%c12 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3), "n"(OFF + 4));
-    else if constexpr (CNT == 6) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:%c9 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:%c10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:%c11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:%c12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:%c13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:%c14 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3), "n"(OFF + 4), "n"(OFF + 5));
-    else if constexpr (CNT == 7) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:%c10 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:%c11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:%c12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:%c13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:%c14 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:%c15 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:%c16 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3), "n"(OFF + 4), "n"(OFF + 5), "n"(OFF + 6));
-    else if constexpr (CNT == 8) asm volatile("s_nop 1\n\t" "v_fmac_f32_dpp %0, %2, %3 row_newbcast:%c11 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %4 row_newbcast:%c12 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %5 row_newbcast:%c13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %6 row_newbcast:%c14 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %7 row_newbcast:%c15 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %8 row_newbcast:%c16 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %9 row_newbcast:%c17 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %2, %10 row_newbcast:%c18 row_mask:0xf bank_mask:0xf\n\t" : "+v"(a0), "+v"(a1) : "v"(x), "v"(k[S * 0]), "v"(k[S * 1]), "v"(k[S * 2]), "v"(k[S * 3]), "v"(k[S * 4]), "v"(k[S * 5]), "v"(k[S * 6]), "v"(k[S * 7]), "n"(OFF + 0), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3), "n"(OFF + 4), "n"(OFF + 5), "n"(OFF + 6), "n"(OFF + 7));
+    TPC_FMAC_ROW8(1, "f32");
+    TPC_FMAC_ROW8(2, "f32");
+    TPC_FMAC_ROW8(3, "f32");
+    TPC_FMAC_ROW8(4, "f32");
+    TPC_FMAC_ROW8(5, "f32");
+    TPC_FMAC_ROW8(6, "f32");
+    TPC_FMAC_ROW8(7, "f32");
+    TPC_FMAC_ROW8(8, "f32");
 }
 
 // v_permlane16_swap: (a, b) -> a' = rows (a0, b0, a2, b2), b' = rows (a1, b1, a3, b3);

@@ -24,6 +24,10 @@ namespace tpc {
     const char* lane_build_h##h();
 TPC_DECL_H(4) TPC_DECL_H(5) TPC_DECL_H(10) TPC_DECL_H(20) TPC_DECL_H(30) TPC_DECL_H(40)
 #undef TPC_DECL_H
+// ... and for the general model (mpc_groupg_inst.hip): N = 10, 20, cold starts
+#define TPC_DECL_H(h) hipError_t groupg_general_h##h(int, int, int, const GeneralArgs&, const Knobs&, const Workspace&, hipStream_t);
+TPC_DECL_H(10) TPC_DECL_H(20)
+#undef TPC_DECL_H
 // LANE_FMA for the general model (mpc_ubg_inst.hip): N <= 20
 #define TPC_DECL_H(h) hipError_t ub_general_h##h(int, int, const GeneralArgs&, const Knobs&, const Workspace&, hipStream_t);
 TPC_DECL_H(4) TPC_DECL_H(5) TPC_DECL_H(10) TPC_DECL_H(20)
@@ -113,7 +117,7 @@ int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n, int d
     if (algo == TPC_MPC_ALGO_LANE) return algo;
     if (algo == TPC_MPC_ALGO_LANE_FMA) return lane;
     // GROUP is LANE_FMA's arithmetic with G lanes per instance: the same requests, the horizons a group divides
-    if (algo == TPC_MPC_ALGO_GROUP) return (fma_ok && compact && group_lanes(h, H) > 0) ? algo : lane;
+    if (algo == TPC_MPC_ALGO_GROUP) return (fma_ok && group_lanes(h, H) > 0 && (compact || H == 10 || H == 20)) ? algo : lane;
     const int64_t lanes = (int64_t)h->cu_count * 4 * kWave;
     // (N = 40 with two inputs: the two-variables-per-lane WAVE kernel against a LANE pass that lasts as long
     // as its slowest instance, 50 ms whatever the batch: 42.0 against 50.0 ms at 16 384, 62.4 against 49.9 at 24 576)
@@ -218,6 +222,14 @@ hipError_t dispatch_compact(int algo, int H, int dtype, const CompactArgs& a, co
 hipError_t dispatch_general(int algo, int I, int H, int dtype, const GeneralArgs& a, const Knobs& k,
                             const Workspace& ws, hipStream_t s) {
     if (algo == kAlgoGeneric) return generic_launch(ws, s, [&] { return generic_general(dtype, I, H, a, k, ws.state, s); });
+    if (algo == TPC_MPC_ALGO_GROUP) {
+        switch (H) {
+#define X(h) case h: return groupg_general_h##h(dtype, I, ws.group_lanes, a, k, ws, s);
+            X(10) X(20)
+#undef X
+        }
+        return hipErrorInvalidValue;
+    }
     if (algo == TPC_MPC_ALGO_LANE_FMA) {
         switch (H) {
 #define X(h) case h: return ub_general_h##h(dtype, I, a, k, ws, s);
@@ -1100,9 +1112,15 @@ int tpc_mpc_reserve(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n, int me
         if (mem != TPC_MPC_HOST && mem != TPC_MPC_DEVICE) return fail(h, TPC_MPC_ERR_BAD_ARG, "bad memory kind");
         if (n == 0) return TPC_MPC_OK;
         HIP_TRY(h, hipSetDevice(h->device));
-        // the larger of the two kernel families' needs, so that either choice of AUTO is covered
+        // the larger of the kernel families' needs, so that every choice of AUTO is covered -- and the buffer the
+        // re-solve of capped instances reads its iteration counts from when the caller passes none
         rc = reserve_lane_workspace(h, p->horizon, p->dtype, n);
         if (rc) return rc;
+        if (p->algo == TPC_MPC_ALGO_AUTO && p->dtype == TPC_MPC_F64) {
+            int32_t* unused = nullptr;
+            rc = cap_iters_buffer(h, n, &unused);
+            if (rc) return rc;
+        }
         if (mem == TPC_MPC_HOST) {
             const int64_t col = pad256(n * (int64_t)esize(p->dtype)), icol = pad256(n * 4);
             rc = ensure(h, &h->stage, &h->stage_bytes, 5 * col + icol);

@@ -38,7 +38,9 @@ __global__ __launch_bounds__(64, 1) void groupg_pg_kernel(GeneralArgs g, Knobs k
     using P = GroupPlan<T, H, G>;
     constexpr int L = P::L, RL = LaneRec<T, H>::kLen, NV = I * L;
     constexpr bool D64 = sizeof(T) == 8;
-    const int64_t n_queue = (int64_t)__builtin_nontemporal_load(queue_len);
+    // (STATE: the coordinate-descent kernel publishes nothing itself -- the caller wants controls and v of every instance --
+    // so the whole queue is this kernel's, finished instances included)
+    const int64_t n_queue = STATE ? g.n : (int64_t)__builtin_nontemporal_load(queue_len);
     if (__builtin_nontemporal_load(&stats[2]) != 0ull) return;   // the screen refused the batch: the exact build's
     if (n_queue <= 0) return;
 

@@ -354,8 +354,10 @@ template <typename T, int I, int H, class Model, class Args>
 __global__ __launch_bounds__(64, 1) void lane_pg_kernel(Args g, Knobs kn, const T* __restrict__ recs,
                                                          const uint32_t* __restrict__ order,
                                                          uint32_t* __restrict__ ticket,
-                                                         unsigned long long* __restrict__ stats) {
+                                                         unsigned long long* __restrict__ stats, int only_if_refused = 0) {
     constexpr int RL = LaneRec<T, H>::kLen;
+    // (behind the general-form GROUP kernel, mpc_groupg_inst.hip: only for a batch the stop-test screen refused)
+    if (only_if_refused && __builtin_nontemporal_load(&stats[2]) == 0ull) return;
     __shared__ T s_mm[2 * H][kWave];   // MM[i](j) of lane l at s_mm[2*i + j][l]
     __shared__ T s_v[2 * H][kWave];    // v[i](j)   (mpc.h:250)
     const int lane = threadIdx.x;

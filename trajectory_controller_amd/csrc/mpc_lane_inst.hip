@@ -42,9 +42,10 @@ struct TagState {}; struct TagFast {}; struct TagExact {};
 inline bool wants_state(const CompactArgs&) { return false; }
 inline bool wants_state(const GeneralArgs& a) { return a.controls != nullptr || a.v != nullptr; }
 
+// coordinate descent + queue order (also the front half of the general-form GROUP kernels where the caller passes the
+// controller state or the horizon has no LANE_FMA kernel: mpc_groupg_inst.hip)
 template <typename T, int I, class Model, class Args>
-hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
-    if (a.n <= 0) return hipSuccess;
+hipError_t phase1(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
     T* recs = (T*)ws.state;
     hipError_t e = hipMemsetAsync(ws.ticket, 0, sizeof(uint32_t), s);
     if (e == hipSuccess) e = hipMemsetAsync(ws.stats, 0, 3 * sizeof(unsigned long long), s);
@@ -59,11 +60,19 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
     e = order_finish(ws.keys, ws.rank, ws.order, a.n, ws.sort_temp, s);
     if (e != hipSuccess) return e;
     if (ws.ev) (void)hipEventRecord(ws.ev[1], s);
+    return hipSuccess;
+}
+// the projected-gradient launches; `only_if_refused`: behind a GROUP kernel, i.e. only the build(s) that serve a batch
+// the stop-test screen refused
+template <typename T, int I, class Model, class Args>
+hipError_t phase2(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s, bool only_if_refused) {
+    T* recs = (T*)ws.state;
     if (wants_state(a)) {
         const int grid_cap = pg_grid<TagState>(lane_pg_kernel<T, I, kH, Model, Args>, kWave);
         const int64_t need = (a.n + kWave - 1) / kWave;
         hipLaunchKernelGGL((lane_pg_kernel<T, I, kH, Model, Args>), dim3((unsigned)(need < grid_cap ? need : grid_cap)),
-                           dim3(kWave), 0, s, a, k, (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats);
+                           dim3(kWave), 0, s, a, k, (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats,
+                           only_if_refused ? 1 : 0);
     } else {
         constexpr int bt = kWave * FusedOcc<T, kH>::value;
         const int64_t need = (a.n + bt - 1) / bt;
@@ -71,17 +80,27 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
         const uint32_t* queue_len = order_queue_len(ws.sort_temp);
         if constexpr (Model::kFastStop) {
             // both builds go out; the one the CD kernel's screen did not pick returns at once
-            const int fast_cap = pg_grid<TagFast>(lane_pg_fused_kernel<T, I, kH, Model, Args, true>, bt);
-            hipLaunchKernelGGL((lane_pg_fused_kernel<T, I, kH, Model, Args, true>),
-                               dim3((unsigned)(need < fast_cap ? need : fast_cap)), dim3(bt), 0, s, a, k,
-                               (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats, queue_len);
+            if (!only_if_refused) {
+                const int fast_cap = pg_grid<TagFast>(lane_pg_fused_kernel<T, I, kH, Model, Args, true>, bt);
+                hipLaunchKernelGGL((lane_pg_fused_kernel<T, I, kH, Model, Args, true>),
+                                   dim3((unsigned)(need < fast_cap ? need : fast_cap)), dim3(bt), 0, s, a, k,
+                                   (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats, queue_len);
+            }
         }
         const int grid_cap = pg_grid<TagExact>(lane_pg_fused_kernel<T, I, kH, Model, Args, false>, bt);
         hipLaunchKernelGGL((lane_pg_fused_kernel<T, I, kH, Model, Args, false>),
                            dim3((unsigned)(need < grid_cap ? need : grid_cap)), dim3(bt), 0, s, a, k,
                            (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats, queue_len);
     }
-    e = hipGetLastError();
+    return hipGetLastError();
+}
+
+template <typename T, int I, class Model, class Args>
+hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
+    if (a.n <= 0) return hipSuccess;
+    hipError_t e = phase1<T, I, Model, Args>(a, k, ws, s);
+    if (e != hipSuccess) return e;
+    e = phase2<T, I, Model, Args>(a, k, ws, s, false);
     if (ws.ev) (void)hipEventRecord(ws.ev[2], s);
     return e;
 }
@@ -141,6 +160,17 @@ hipError_t TPC_CAT(lane_resolve_general_h, TPC_LANE_H)(int I, const GeneralArgs&
                                                          const int32_t* select, const uint32_t* gate, hipStream_t s) {
     if (I == 2) return resolve<double, 2, GeneralModel<double, 2>, GeneralArgs>(a, k, ws, select, gate, s);
     return resolve<double, 1, GeneralModel<double, 1>, GeneralArgs>(a, k, ws, select, gate, s);
+}
+
+// the halves the general-form GROUP kernels borrow (fp64; mpc_groupg_inst.hip): coordinate descent + queue order, and
+// the bit-exact projected-gradient kernels for a batch the stop-test screen refused
+hipError_t TPC_CAT(lane_general_phase1_h, TPC_LANE_H)(int I, const GeneralArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
+    if (I == 2) return phase1<double, 2, GeneralModel<double, 2>, GeneralArgs>(a, k, ws, s);
+    return phase1<double, 1, GeneralModel<double, 1>, GeneralArgs>(a, k, ws, s);
+}
+hipError_t TPC_CAT(lane_general_refused_h, TPC_LANE_H)(int I, const GeneralArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
+    if (I == 2) return phase2<double, 2, GeneralModel<double, 2>, GeneralArgs>(a, k, ws, s, true);
+    return phase2<double, 1, GeneralModel<double, 1>, GeneralArgs>(a, k, ws, s, true);
 }
 
 hipError_t TPC_CAT(lane_general_h, TPC_LANE_H)(int dtype, int I, const GeneralArgs& a, const Knobs& k,

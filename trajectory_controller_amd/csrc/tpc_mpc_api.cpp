@@ -24,9 +24,9 @@ namespace tpc {
     const char* lane_build_h##h();
 TPC_DECL_H(4) TPC_DECL_H(5) TPC_DECL_H(10) TPC_DECL_H(20) TPC_DECL_H(30) TPC_DECL_H(40)
 #undef TPC_DECL_H
-// ... and for the general model (mpc_groupg_inst.hip): N = 10, 20, cold starts
+// ... and for the general model (mpc_groupg_inst.hip)
 #define TPC_DECL_H(h) hipError_t groupg_general_h##h(int, int, int, const GeneralArgs&, const Knobs&, const Workspace&, hipStream_t);
-TPC_DECL_H(10) TPC_DECL_H(20)
+TPC_DECL_H(10) TPC_DECL_H(20) TPC_DECL_H(30) TPC_DECL_H(40)
 #undef TPC_DECL_H
 // LANE_FMA for the general model (mpc_ubg_inst.hip): N <= 20
 #define TPC_DECL_H(h) hipError_t ub_general_h##h(int, int, const GeneralArgs&, const Knobs&, const Workspace&, hipStream_t);
@@ -109,7 +109,7 @@ int group_lanes(const tpc_mpc_context* h, int H, int dtype = 0, int64_t n = 0) {
 // `fma_ok`: the request is one the LANE_FMA family takes (compact form with usable bounds: fma_usable(); general form:
 // fma_general_usable()); `compact`: the compact form (its WAVE / LANE_FMA crossovers were measured separately).
 int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n, int dtype, bool fma_ok = false,
-              bool compact = true) {
+              bool compact = true, bool group_general = false) {
     if (!horizon_specialised(H)) return algo == TPC_MPC_ALGO_WAVE ? -1 : kAlgoGeneric;
     const bool wave_ok = I * H <= kWave || (I == 2 && H <= kWave);   // (two variables per lane past 64)
     const int lane = fma_ok ? TPC_MPC_ALGO_LANE_FMA : TPC_MPC_ALGO_LANE;   // the throughput family of AUTO
@@ -117,7 +117,7 @@ int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n, int d
     if (algo == TPC_MPC_ALGO_LANE) return algo;
     if (algo == TPC_MPC_ALGO_LANE_FMA) return lane;
     // GROUP is LANE_FMA's arithmetic with G lanes per instance: the same requests, the horizons a group divides
-    if (algo == TPC_MPC_ALGO_GROUP) return (fma_ok && group_lanes(h, H) > 0 && (compact || H == 10 || H == 20)) ? algo : lane;
+    if (algo == TPC_MPC_ALGO_GROUP) return (compact ? (fma_ok && group_lanes(h, H) > 0) : group_general) ? algo : lane;
     const int64_t lanes = (int64_t)h->cu_count * 4 * kWave;
     // (N = 40 with two inputs: the two-variables-per-lane WAVE kernel against a LANE pass that lasts as long
     // as its slowest instance, 50 ms whatever the batch: 42.0 against 50.0 ms at 16 384, 62.4 against 49.9 at 24 576)
@@ -165,6 +165,14 @@ bool fma_usable(const tpc_mpc_params* p) {
     for (int j = 0; j < 2; ++j)
         if (!(std::isfinite(p->lower[j]) && std::isfinite(p->upper[j]) && p->upper[j] > p->lower[j])) return false;
     return true;
+}
+
+// General form, GROUP (mpc_groupg_inst.hip): N = 10, 20, 30, 40; fp32 only where the general-form LANE_FMA unit stands
+// in front of it (cold starts at N <= 20), fp64 also with the controller state in or out and at N = 30, 40.
+bool group_general_usable(int dtype, int H, const void* controls, const void* v) {
+    if (H != 10 && H != 20 && H != 30 && H != 40) return false;
+    const bool via_lane = controls || v || H > 20;
+    return !via_lane || dtype == TPC_MPC_F64;
 }
 
 // General form: the LANE_FMA kernels exist for N <= 20 and start cold (the controller state in or out is LANE's).
@@ -225,7 +233,7 @@ hipError_t dispatch_general(int algo, int I, int H, int dtype, const GeneralArgs
     if (algo == TPC_MPC_ALGO_GROUP) {
         switch (H) {
 #define X(h) case h: return groupg_general_h##h(dtype, I, ws.group_lanes, a, k, ws, s);
-            X(10) X(20)
+            X(10) X(20) X(30) X(40)
 #undef X
         }
         return hipErrorInvalidValue;
@@ -461,7 +469,8 @@ int context_new(int device, int cu_count, tpc_mpc_context** out) {
 int general_launch(tpc_mpc_context* h, const tpc_mpc_params* p, const tpc_mpc_general_io* io, hipStream_t s) {
     const int I = io->inputs, H = p->horizon;
     const int64_t n = io->n;
-    const int algo = pick_algo(h, p->algo, I, H, n, p->dtype, fma_general_usable(H, io->controls_inout, io->v_inout), false);
+    const int algo = pick_algo(h, p->algo, I, H, n, p->dtype, fma_general_usable(H, io->controls_inout, io->v_inout), false,
+                                   group_general_usable(p->dtype, H, io->controls_inout, io->v_inout));
     if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel exists for the specialised horizons with inputs*horizon <= 64 only; use LANE or AUTO");
     GeneralArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -749,7 +758,8 @@ int tpc_mpc_solve_batch_general(tpc_mpc_handle h, const tpc_mpc_params* p,
         const int64_t es = (int64_t)esize(p->dtype);
         const int I = io->inputs, H = p->horizon;
         const int64_t n = io->n;
-        const int algo = pick_algo(h, p->algo, I, H, n, p->dtype, fma_general_usable(H, io->controls_inout, io->v_inout), false);
+        const int algo = pick_algo(h, p->algo, I, H, n, p->dtype, fma_general_usable(H, io->controls_inout, io->v_inout), false,
+                                   group_general_usable(p->dtype, H, io->controls_inout, io->v_inout));
         if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel exists for the specialised horizons with inputs*horizon <= 64 only; use LANE or AUTO");
         StreamOrderScope order(h, s);
         rc = order.begin();
@@ -852,7 +862,7 @@ int tpc_mpc_rollout(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mpc_gen
         const int64_t es = (int64_t)esize(p->dtype);
         const int I = io->inputs, H = p->horizon;
         const int64_t n = io->n, ld = io->ld;
-        const int algo = pick_algo(h, p->algo, I, H, n, p->dtype);
+        const int algo = pick_algo(h, p->algo, I, H, n, p->dtype, false, false, group_general_usable(p->dtype, H, (const void*)1, (const void*)1));
         if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel exists for the specialised horizons with inputs*horizon <= 64 only; use LANE or AUTO");
         StreamOrderScope order(h, s);
         rc = order.begin();
@@ -1037,7 +1047,7 @@ int tpc_mpc_follow_batch_horizon(tpc_mpc_handle h, const tpc_mpc_params* p, cons
         hipStream_t s = (hipStream_t)stream;
         const int64_t n = t->n;
         const int H = p->horizon, I = 2;
-        const int algo = pick_algo(h, p->algo, I, H, n, p->dtype, fma_general_usable(H, nullptr, nullptr), false);
+        const int algo = pick_algo(h, p->algo, I, H, n, p->dtype, fma_general_usable(H, nullptr, nullptr), false, group_general_usable(p->dtype, H, nullptr, nullptr));
         if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel exists for the specialised horizons with inputs*horizon <= 64 only; use LANE or AUTO");
         StreamOrderScope order(h, s);
         rc = order.begin();

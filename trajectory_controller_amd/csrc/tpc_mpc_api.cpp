@@ -81,15 +81,21 @@ bool host_path_usable() {
 
 // Lanes per instance of the GROUP family for horizon H: what TPC_MPC_OPT_GROUP_LANES pins if it divides H, else the
 // measured best; 0 where the family has no kernel (N = 4, 5 and the non-specialised horizons).
-int group_lanes(const tpc_mpc_context* h, int H, int dtype = 0, int64_t n = 0) {
+int group_lanes(const tpc_mpc_context* h, int H, int dtype = 0, int64_t n = 0, int form = 0) {
     if (H != 10 && H != 20 && H != 30 && H != 40) return 0;
-    // (what mpc_group_inst.hip builds: chunks of 3 .. 20 steps, padded where G does not divide H)
-    auto built = [&](int G) { return H == 10 ? (G == 2 || G == 4) : (G == 2 || G == 4 || G == 8); };
+    // (what mpc_group_inst.hip / mpc_groupg_inst.hip build: chunks of 3 .. 20 steps -- 3 .. 10 for the general model --
+    // padded where G does not divide H)
+    auto built = [&](int G) {
+        if (H == 10) return G == 2 || G == 4;
+        if (form == 1 && H >= 30) return G == 4 || G == 8;
+        return G == 2 || G == 4 || G == 8;
+    };
+    if (form == 1) dtype = TPC_MPC_F64;   // (the general form's rows were measured in fp64)
     const int want = h->opt_group_lanes;
     if (want > 0 && built(want)) return want;
     // the measured best for this batch size (auto_table.h); where a row names a size that is not built, the next one down
     for (const AutoRow& r : kAutoTable) {
-        if (r.dtype != dtype || r.horizon != H || n <= 0) continue;
+        if (r.form != form || r.dtype != dtype || r.horizon != H || n <= 0) continue;
         auto scaled = [&](int64_t at) { return at * h->cu_count / 256 < at ? at * h->cu_count / 256 : at; };
         int g = n < scaled(r.group8_below) ? 8 : (n < scaled(r.group4_below) ? 4 : 2);
         while (g > 2 && !built(g)) g /= 2;
@@ -145,7 +151,7 @@ int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n, int d
         const bool d = dtype == TPC_MPC_F64;
         auto scaled = [&](int64_t at) { return at * h->cu_count / 256 < at ? at * h->cu_count / 256 : at; };
         for (const AutoRow& r : kAutoTable) {
-            if (r.dtype != dtype || r.horizon != H) continue;
+            if (r.form != 0 || r.dtype != dtype || r.horizon != H) continue;
             if (n < scaled(r.wave_below) && n <= kWaveQueueMaxInstances) return TPC_MPC_ALGO_WAVE;
             if (n < scaled(r.group2_below)) return TPC_MPC_ALGO_GROUP;
             return lane;
@@ -155,6 +161,16 @@ int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n, int d
         if (!d && H == 4) at = 24576;
         if (!d && H == 5) at = 21504;
         crossover = scaled(at);
+    }
+    if (!compact && group_general) {
+        // general form with group kernels: the same three-way split, from the rows measured for it (two inputs, fp64)
+        auto scaled = [&](int64_t at) { return at * h->cu_count / 256 < at ? at * h->cu_count / 256 : at; };
+        for (const AutoRow& r : kAutoTable) {
+            if (r.form != 1 || r.horizon != H) continue;
+            if (wave_ok && n < scaled(r.wave_below) && n <= kWaveQueueMaxInstances) return TPC_MPC_ALGO_WAVE;
+            if (n < scaled(r.group2_below)) return TPC_MPC_ALGO_GROUP;
+            return lane;
+        }
     }
     return (n >= crossover || !wave_ok) ? lane : TPC_MPC_ALGO_WAVE;
 }
@@ -287,14 +303,14 @@ hipError_t resolve_general(int I, int H, const GeneralArgs& a, const Knobs& k, c
     return hipErrorInvalidValue;
 }
 
-int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n, Workspace* ws) {
+int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n, Workspace* ws, int form = 0) {
     ws->state = nullptr;
     ws->ticket = h->ws_words;
     ws->stats = (unsigned long long*)(h->ws_words + 4);
     ws->capacity_bytes = 0;
     ws->ev = h->profiling ? h->ev : nullptr;
     ws->wave_group = h->opt_wave_group;
-    ws->group_lanes = group_lanes(h, H, dtype, n);
+    ws->group_lanes = group_lanes(h, H, dtype, n, form);
     ws->max_waves = h->max_waves;
     h->ev_valid = h->profiling;
     h->last_algo = algo;
@@ -486,7 +502,7 @@ int general_launch(tpc_mpc_context* h, const tpc_mpc_params* p, const tpc_mpc_ge
     if (!rc && fix) rc = resolve_reserve(h, H, p->dtype, n);
     if (rc) return rc;
     Workspace ws;
-    rc = prepare_workspace(h, algo, H, p->dtype, n, &ws);
+    rc = prepare_workspace(h, algo, H, p->dtype, n, &ws, 1);
     if (rc) return rc;
     hipError_t e = dispatch_general(algo, I, H, p->dtype, a, knobs_of(p), ws, s);
     if (e == hipSuccess && fix) {
@@ -817,7 +833,7 @@ int tpc_mpc_solve_batch_general(tpc_mpc_handle h, const tpc_mpc_params* p,
         }
 
         Workspace ws;
-        rc = prepare_workspace(h, algo, H, p->dtype, n, &ws);
+        rc = prepare_workspace(h, algo, H, p->dtype, n, &ws, 1);
         if (rc) return rc;
         HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
         hipError_t e = dispatch_general(algo, I, H, p->dtype, a, knobs_of(p), ws, s);
@@ -931,7 +947,7 @@ int tpc_mpc_rollout(tpc_mpc_handle h, const tpc_mpc_params* p, const tpc_mpc_gen
         r.iters_step = a.iters; r.iters_out = d_iters;
 
         Workspace ws;
-        rc = prepare_workspace(h, algo, H, p->dtype, n, &ws);
+        rc = prepare_workspace(h, algo, H, p->dtype, n, &ws, 1);
         if (rc) return rc;
         HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
         const Knobs kn = knobs_of(p);
@@ -1092,7 +1108,7 @@ int tpc_mpc_follow_batch_horizon(tpc_mpc_handle h, const tpc_mpc_params* p, cons
             if (rc) return rc;
         }
         Workspace ws;
-        rc = prepare_workspace(h, algo, H, TPC_MPC_F64, n, &ws);
+        rc = prepare_workspace(h, algo, H, TPC_MPC_F64, n, &ws, 1);
         if (rc) return rc;
         HIP_TRY(h, hipMemsetAsync(h->ws_words + 1, 0, sizeof(uint32_t), s));
         e = dispatch_general(algo, I, H, TPC_MPC_F64, a, knobs_of(p), ws, s);

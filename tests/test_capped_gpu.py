@@ -101,13 +101,14 @@ def test_no_capped_instance_no_change(torch_cuda, oracle):
     assert flags == 0 and np.array_equal(f, f2) and np.array_equal(r, r2) and np.array_equal(it, it2)
 
 
-@pytest.mark.parametrize("I", [1, 2])
-def test_general_form_capped_instances(torch_cuda, oracle, I):
-    """The general form (per-instance model, per-step targets, cold start) through AUTO: WAVE at this size."""
+@pytest.mark.parametrize("I,n,family", [(1, 2000, WAVE), (2, 2000, WAVE), (2, 16384, GROUP), (1, 300000, LANE_FMA)])
+def test_general_form_capped_instances(torch_cuda, oracle, I, n, family):
+    """The general form (per-instance model, per-step targets, cold start) through AUTO, at batch sizes that send it to
+    each of its tolerance families."""
     import torch
     from trajectory_controller_amd import MpcSolver
     from trajectory_controller_amd.synth import general_inputs
-    H, n, cap = 20, 2000, 400
+    H, cap = 20, 400
     names = ["A", "B", "C", "Q", "R", "lo", "hi", "x0", "targets"]
     g = general_inputs(H, n, I=I, first=4711)
     ou0, _, oit = oracle.solve_general(I, H, *[g[k] for k in names], max_iter=cap, nthreads=8)
@@ -115,8 +116,10 @@ def test_general_form_capped_instances(torch_cuda, oracle, I):
     assert 0 < capped.sum() < n
     dev = [torch.from_numpy(np.ascontiguousarray(g[k].reshape(n, -1).T)).to("cuda:0") for k in names]
     with MpcSolver(horizon=H, device=0, max_iter=cap) as s:
+        s.set_profiling(True)
         u0, it = s.solve_batch_general(*dev, inputs=I, want_iters=True)
         torch.cuda.synchronize()
+        assert s.last_kernel_times()[2] == family
     u0, it = u0.cpu().numpy().T, it.cpu().numpy()
     assert np.array_equal(it, oit)
     assert bits_equal(u0[capped], ou0[capped]) and np.abs(u0 - ou0).max() <= 1e-9

@@ -88,6 +88,8 @@ def test_groupg_state_in_and_out(torch_cuda, oracle, I, H, G):
     rng = np.random.default_rng(300 + H + I)
     cin = rng.uniform(-0.3, 0.3, size=(n, H, I))
     vin = rng.uniform(-0.3, 0.3, size=(n, H, I))
+    g["lo"][::2] = -rng.uniform(0.02, 0.6, size=g["lo"][::2].shape)   # half of the boxes random: many warm starts lie OUTSIDE
+    g["hi"][::2] = rng.uniform(0.02, 0.6, size=g["hi"][::2].shape)    # theirs (the stop test must then be dlib's own mask)
     ou0, cout, oit, vout = oracle.solve_general(I, H, *[g[k] for k in GNAMES], controls_in=cin, v_in=vin, want_v=True, nthreads=8)
     controls, vstate = _soa(cin), _soa(vin)
     with _solver(H, G) as s:

@@ -317,7 +317,13 @@ __global__ __launch_bounds__(64, 1) void groupg_pg_kernel(GeneralArgs g, Knobs k
                     if (l >= DL0) dd = dd * live[l - DL0];
                     const T vn = m.template project<true>(ub::fma_(-il, dd, uu), j);            // mpc.h:342
                     T& acc = j == 0 ? acc0 : acc1;
-                    if constexpr (D64) {
+                    if constexpr (STATE) {
+                        // a caller's warm start may lie OUTSIDE the box (the coordinate-descent phase clamps only what
+                        // it updates), where "blocked" cannot be read off the projected step: dlib's own mask (mpc.h:298-299)
+                        const T up = (uu <= m.lo[j]) ? (T)0 : dd;
+                        const T dn = (uu >= m.hi[j]) ? (T)0 : -dd;
+                        acc = tmax(acc, tmax(up, dn));
+                    } else if constexpr (D64) {
                         acc = tmax(acc, tmin(tabs(dd), tabs(uu - vn)));
                     } else {
                         const T g_lo = ub::fma_(uu, huge, -(m.lo[j] * huge)), g_hi = ub::fma_(-huge, uu, m.hi[j] * huge);

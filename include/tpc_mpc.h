@@ -93,8 +93,13 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
  *          refilled from LANE_FMA's longest-first queue; the coordinate-descent phase and the records are LANE_FMA's
  *          own.  Compact form, N = 10, 20, 30, 40 (chunks padded where G does not divide N), the requests LANE_FMA
  *          takes; anything else runs LANE_FMA / LANE.  Same statement as LANE_FMA: max |du| vs dlib ~2e-13 at N = 20,
- *          ~1.5e-12 at N = 40, identical iteration counts.  16 384 instances of N = 20: 1.5 ms (WAVE 2.9, LANE_FMA
+ *          ~1.5e-12 at N = 40, identical iteration counts.  16 384 instances of N = 20: 1.3 ms (WAVE 2.9, LANE_FMA
  *          3.5); of N = 40: 4.8 ms (15.0 / 30.6).
+ *          General form (solve_batch_general, rollout, follow_batch*), fp64, N = 10, 20, 30, 40, one or two inputs:
+ *          the chunks are joined by scans of 2x2 matrix powers (A is the instance's own: A^(L 2^s) computed once per
+ *          refill), controller state in and out (controls_inout / v_inout) included -- behind the bit-exact
+ *          coordinate-descent kernel there, and with dlib's own mask as the stop test, because a warm start may lie
+ *          outside the box.  16 384 instances of N = 40, two inputs: 7.1 ms (WAVE 51, LANE 61).
  *   AUTO : the fastest family that meets the 1e-6 parity target, and it GUARANTEES that target where a guarantee is
  *          possible.  Family: WAVE below a crossover measured per dtype and horizon, then GROUP with 8, 4, 2 lanes
  *          per instance, then LANE_FMA (csrc/auto_table.h, generated by scripts/measure_crossover.py on a 256-CU
@@ -395,8 +400,9 @@ int tpc_mpc_reserve(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n, int me
  *   TPC_MPC_OPT_HOST_SOLVE_ONE  tpc_mpc_solve_one on the CALLING THREAD for horizons up to this value (0, default:
  *                            never): the host path of csrc/tpc_mpc_host.cpp, as on a handle created with
  *                            TPC_MPC_DEVICE_NONE.  For a module that solves one short-horizon problem per cycle --
- *                            the reference's own N = 4 -- set it to 5: a core needs ~3 us where the round trip to the
- *                            resident wavefront needs ~10. */
+ *                            the reference's own N = 4 -- set it to 10: a core needs ~4 us at N = 4 (28 at N = 10) where the
+ *                            round trip to the resident wavefront needs ~10 (30); from N = 20 on the GPU is faster
+ *                            (INTEGRATION.md section 1). */
 typedef enum tpc_mpc_option { TPC_MPC_OPT_WAVE_GROUP = 1, TPC_MPC_OPT_MAILBOX_HOST = 2, TPC_MPC_OPT_GROUP_LANES = 3,
                               TPC_MPC_OPT_HOST_SOLVE_ONE = 4 } tpc_mpc_option;
 int tpc_mpc_set_option(tpc_mpc_handle h, int option, int64_t value);

@@ -16,7 +16,8 @@ g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 args = [g(px), g(py), g(np.cos(ang).astype(np.float32)), g(np.sin(ang).astype(np.float32)),
         g(rng.uniform(0.6, 2.0, size=(P, n)).astype(np.float32)), g(np.full(n, P, dtype=np.int32)),
         g(rng.uniform(0.3, 4.0, size=n).astype(np.float32)), g(rng.uniform(0.2, 2.5, size=n).astype(np.float32))]
-with MpcSolver(horizon=H, algo="lane") as s:
+algo = sys.argv[3] if len(sys.argv) > 3 else "lane"
+with MpcSolver(horizon=H, algo=algo) as s:
     for name, fn in (("follow_batch", s.follow_batch), ("follow_batch_horizon", s.follow_batch_horizon)):
         fn(*args)
         torch.cuda.synchronize()
@@ -25,4 +26,4 @@ with MpcSolver(horizon=H, algo="lane") as s:
             out = fn(*args)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 5
-        print(f"{name} n={n} H={H} P={P}: {dt * 1e3:.3f} ms per batch, {n / dt / 1e6:.2f} M cycles/s")
+        print(f"{name} n={n} H={H} P={P} {algo}: {dt * 1e3:.3f} ms per batch, {n / dt / 1e6:.2f} M cycles/s")

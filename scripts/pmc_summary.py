@@ -15,7 +15,8 @@ def short(name):
     base = head.split("<")[0]
     if "lane_pg_fused_kernel" in base or "ub_pg_kernel" in base or "ubg_pg_kernel" in base:
         args = head[len(base):]
-        base += "<fast>" if args.rstrip(">").rstrip().endswith("true") else "<exact>"
+        last = args.rstrip(">").rstrip().split(",")[-1].strip()   # bool FAST, or ub_pg_kernel's int MODE (0 exact, 1 mask, 2 moved)
+        base += "<fast>" if last in ("true", "2") else ("<mask>" if last == "1" else "<exact>")
     return base
 
 # kernel trace

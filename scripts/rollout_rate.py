@@ -11,7 +11,7 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 g = general_inputs(H, n, I=2)
 soa = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a).reshape(n, -1).T)).cuda()
 dev = [soa(g[k]) for k in ("A", "B", "C", "Q", "R", "lo", "hi", "x0", "targets")]
-for algo in ("lane", "wave"):
+for algo in (sys.argv[4].split(",") if len(sys.argv) > 4 else ("lane", "wave", "group", "auto")):
     with MpcSolver(horizon=H, algo=algo) as s:
         s.rollout(2, *dev, inputs=2, want_iters=True)
         torch.cuda.synchronize(); t0 = time.perf_counter()

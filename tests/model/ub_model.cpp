@@ -20,28 +20,29 @@ namespace {
 
 using namespace tpc::ub;
 
-// the kernels' own choice of stop-test build: the screen of mpc_ub_model.h on one instance
+// the kernels' own choice of stop-test build: the screens of mpc_ub_model.h on one instance (ub_pg_kernel's MODE)
 template <typename T, int H, bool EQB>
-bool screen_one(T v, T ty, T tphi, const T* q, const T* r, double step, double wheelbase, const T* lo, const T* hi, double eps_d) {
+int screen_one(T v, T ty, T tphi, const T* q, const T* r, double step, double wheelbase, const T* lo, const T* hi, double eps_d) {
     Unit<T, EQB> m;
     m.set_uniform((T)1, q, r, lo, hi);
     m.set_instance((T)step, (T)wheelbase, v, ty, tphi);
     const T lambda = ctor_lambda_qdiag<T, H>(m.a, m.c, q[0], q[1], r[0], r[1], [](int, int, T) {});
-    return fast_stop_ok(m, ty, tphi, q[0], q[1], r[0], r[1], (T)eps_d, lambda);
+    if (!fast_stop_ok(m, ty, tphi, q[0], q[1], r[0], r[1], (T)eps_d, lambda)) return 0;
+    return moved_stop_ok(m, (T)eps_d, lambda) ? 2 : 1;
 }
 template <typename T, bool EQB>
-bool screen_dispatch(int H, T v, T ty, T tphi, const T* q, const T* r, double step, double wb, const T* lo, const T* hi, double eps) {
+int screen_dispatch(int H, T v, T ty, T tphi, const T* q, const T* r, double step, double wb, const T* lo, const T* hi, double eps) {
     switch (H) {
 #define X(h) case h: return screen_one<T, h, EQB>(v, ty, tphi, q, r, step, wb, lo, hi, eps);
         X(4) X(5) X(10) X(20) X(30) X(40)
 #undef X
     }
-    return false;
+    return 0;
 }
 
 template <typename T, bool EQB>
 int dispatch(int H, T v, T ty, T tphi, const T* q, const T* r, double step, double wb, const T* lo, const T* hi,
-             double eps, unsigned long mi, unsigned long smo, bool fast, T* fo, T* re, int* it, unsigned* fl) {
+             double eps, unsigned long mi, unsigned long smo, int fast, T* fo, T* re, int* it, unsigned* fl) {
     switch (H) {
 #define X(h) case h: host_solve_compact<T, h, EQB>(v, ty, tphi, q, r, step, wb, lo, hi, eps, mi, smo, fast, fo, re, it, fl); return 0;
         X(4) X(5) X(10) X(20) X(30) X(40)
@@ -56,11 +57,18 @@ int batch(int H, long n, int nthreads, const T* v, const T* dy, const T* dphi, c
           T* front, T* rear, int* iters, unsigned* flags_out) {
     const bool eqb = lo[0] == lo[1] && hi[0] == hi[1];
     const T q[2] = {w4[0], w4[1]}, r[2] = {w4[2], w4[3]};
-    if (fast < 0) {   // auto: what the kernels do -- one instance outside the screen sends the batch to the exact build
-        fast = 1;
-        for (long k = 0; k < n && fast; ++k)
-            fast = (eqb ? screen_dispatch<T, true>(H, v[k], dy[k], dphi[k], q, r, step, wb, lo, hi, eps)
-                        : screen_dispatch<T, false>(H, v[k], dy[k], dphi[k], q, r, step, wb, lo, hi, eps)) ? 1 : 0;
+    // The kernels' batch-wide choice (ub_pg_kernel's MODE): one instance outside the first screen sends the batch to the
+    // exact build (0); in fp32 one instance outside the second sends it to the mask-as-arithmetic build (1); else 2.
+    // fast < 0: both decided here; fast == 1 ("a fast build", as the callers say it): the second decided here.
+    if (fast != 0) {
+        int mode = 2;
+        for (long k = 0; k < n && mode != 0; ++k) {
+            const int one = eqb ? screen_dispatch<T, true>(H, v[k], dy[k], dphi[k], q, r, step, wb, lo, hi, eps)
+                                : screen_dispatch<T, false>(H, v[k], dy[k], dphi[k], q, r, step, wb, lo, hi, eps);
+            if (one == 0) { if (fast < 0) mode = 0; else if (mode > 1) mode = 1; }
+            else if (one < mode) mode = one;
+        }
+        fast = mode;
     }
     std::atomic<long> next(0);
     std::atomic<unsigned> flags(0);
@@ -72,9 +80,9 @@ int batch(int H, long n, int nthreads, const T* v, const T* dy, const T* dphi, c
             if (k0 >= n) break;
             for (long k = k0; k < n && k < k0 + 64; ++k) {
                 const int e = eqb ? dispatch<T, true>(H, v[k], dy[k], dphi[k], q, r, step, wb, lo, hi, eps, mi, smo,
-                                                       fast != 0, front + k, rear + k, iters ? iters + k : nullptr, &f)
+                                                       fast, front + k, rear + k, iters ? iters + k : nullptr, &f)
                                   : dispatch<T, false>(H, v[k], dy[k], dphi[k], q, r, step, wb, lo, hi, eps, mi, smo,
-                                                        fast != 0, front + k, rear + k, iters ? iters + k : nullptr, &f);
+                                                        fast, front + k, rear + k, iters ? iters + k : nullptr, &f);
                 if (e) rc = e;
             }
         }
@@ -150,11 +158,11 @@ void general_one(const T* A, const T* B, const T* C, const T* Q, const T* R, con
     const bool finished = stopped || iter >= max_iter;
     if (finished && !stopped) f |= 2u;
     if (!finished) {
-        const T g = GradScale<T>::g;
+        const T g = tpc::ubg::GradScale<T>::g;
         m.set_scale(g);
         for (int q = 0; q < I * H; ++q) { gmm[q] = g * gmm[q]; v[q] = vinit ? u[q] : (T)0; }
         const T geps = g * eps;
-        const T il = ((T)1 / lambda) * GradScale<T>::inv_g;
+        const T il = ((T)1 / lambda) * tpc::ubg::GradScale<T>::inv_g;
         const T sq = sqrt_(lambda);
         const T beta = (sq - (T)1) / (sq + (T)1);
         const T huge = (T)0x1p100;

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel
     constexpr bool D64 = sizeof(T) == 8;
     const int64_t n_queue = (int64_t)__builtin_nontemporal_load(queue_len);
     // the screened stop test only: a batch the coordinate-descent kernel's screen refused is LANE_FMA's exact build's
-    if (__builtin_nontemporal_load(&stats[2]) != 0ull) return;
+    if ((__builtin_nontemporal_load(&stats[2]) & 1ull) != 0ull) return;   // (bit 1 is LANE_FMA's fp32 choice of stop test: not ours)
     if (n_queue <= 0) return;
 
     const int lane = threadIdx.x;

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64, 1) void groupg_pg_kernel(GeneralArgs g, Knobs k
     const int lane = threadIdx.x;
     const int p = lane & (G - 1);
     const int gbase = lane & ~(G - 1);
-    constexpr T gs = ub::GradScale<T>::g;
+    constexpr T gs = ubg::GradScale<T>::g;
     const T geps = gs * (T)kn.eps;
     T huge = (T)0x1p100;
     asm volatile("" : "+v"(huge));
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64, 1) void groupg_pg_kernel(GeneralArgs g, Knobs k
                         if (!(meta & kMetaStopped)) flags |= 0x2u;
                         publish(x, v, iter);
                     } else {
-                        il = ((T)1 / lambda) * ub::GradScale<T>::inv_g;          // mpc.h:342
+                        il = ((T)1 / lambda) * ubg::GradScale<T>::inv_g;          // mpc.h:342
                         const T sq = tsqrt(lambda);
                         beta = (sq - (T)1) / (sq + (T)1);                        // mpc.h:343
                         // A^L by L - 1 products, then squarings; weights folded in

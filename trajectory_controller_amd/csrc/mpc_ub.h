@@ -100,6 +100,10 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void ub_cd_kernel(Compact
     const bool screen_ok = ub::fast_stop_ok(m, ty, tphi, q0, q1, r0, r1, eps, lambda);
     const unsigned long long failing = __ballot(!screen_ok);
     if (failing != 0ull && lane == __ffsll((long long)failing) - 1) atomicOr(&stats[2], 1ull);
+    if constexpr (sizeof(T) == 4) {   // fp32: may the projected-gradient kernel read its stop test off the projected step?
+        const unsigned long long unmoved = __ballot(!ub::moved_stop_ok(m, eps, lambda));
+        if (unmoved != 0ull && lane == __ffsll((long long)unmoved) - 1) atomicOr(&stats[2], 2ull);
+    }
     const uint32_t cd_iters = kn.smo_iters < kn.max_iter ? kn.smo_iters : kn.max_iter;
     uint32_t iter = 0;
     bool stopped = nonfinite;
@@ -301,16 +305,23 @@ TPC_DEV float fma_opaque(float a, float b, float c) {
     return r;
 }
 
-template <typename T, int H, bool EQB, bool FAST>
+// MODE: which stop test (the coordinate-descent kernel's screens pick one build per batch, stats[2]):
+//   0 exact  dlib's mask by compare and select (mpc.h:298-299); any input
+//   1 mask   fp32 only: dlib's mask as arithmetic (gaps times 2^100, v_med3_f32)
+//   2 moved  min(|g df|, |x - x_new|) on the scaled gradient (fp64: the unit-box form; fp32: where ub::moved_stop_ok holds)
+template <typename T, int H, bool EQB, int MODE>
 __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void ub_pg_kernel(
     CompactArgs g, Knobs kn, const T* __restrict__ recs, const uint32_t* __restrict__ order,
     uint32_t* __restrict__ ticket, unsigned long long* __restrict__ stats, const uint32_t* __restrict__ queue_len) {
     using P = UbPlan<T, H>;
     constexpr int RL = LaneRec<T, H>::kLen;
     const int64_t n_queue = (int64_t)__builtin_nontemporal_load(queue_len);
-    {   // two builds, launched back to back; the coordinate-descent kernel's screen picked one
-        const bool need_exact = __builtin_nontemporal_load(&stats[2]) != 0ull;
-        if (need_exact == FAST) return;
+    constexpr bool FAST = MODE != 0;
+    static_assert(MODE == 0 || MODE == 2 || (MODE == 1 && sizeof(T) == 4), "the mask-as-arithmetic build is fp32's");
+    {   // the builds are launched back to back; the coordinate-descent kernel's screens picked one
+        const unsigned long long sel = __builtin_nontemporal_load(&stats[2]);
+        const int need = (sel & 1ull) ? 0 : ((sizeof(T) == 4 && (sel & 2ull)) ? 1 : 2);
+        if (need != MODE) return;
         if (n_queue <= 0) return;   // (nothing queued: no wavefront should go and ask the ticket -- a thousand returning atomics on one address take 35 us)
     }
     constexpr int BT = kWave * P::occ;
@@ -343,10 +354,10 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
 
     constexpr T gs = ub::GradScale<T>::g;
     const T geps = gs * (T)kn.eps;
-    // fp32 FAST: dlib's mask as arithmetic -- (x - 0) * 2^100 and (1 - x) * 2^100 are zero exactly on
+    // MODE 1 (fp32): dlib's mask as arithmetic -- (x - lo) * 2^100 and (hi - x) * 2^100 are zero exactly on
     // the bound and beyond every admissible eps off it; |med3(df, -g_hi, g_lo)| is dlib's masked |df|
-    // wherever that is below eps.  fp64 FAST reads the mask off the projected step (mpc_ub_model.h).
-    constexpr bool MOVED = FAST && sizeof(T) == 8;
+    // wherever that is below eps.  MODE 2 reads the mask off the projected step (mpc_ub_model.h).
+    constexpr bool MOVED = MODE == 2;
     T huge = (T)0x1p100;
     asm volatile("" : "+v"(huge));
 

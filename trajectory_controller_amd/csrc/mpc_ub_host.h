@@ -14,8 +14,9 @@
 namespace tpc {
 namespace ub {
 
-// fast_stop_in: 1 = the select-free stop test (what the kernels run where ub::fast_stop_ok holds), 0 = dlib's mask,
-// -1 = decided here by that screen on this instance (the kernels decide it per batch).
+// fast_stop_in: the stop test, as ub_pg_kernel's MODE: 0 = dlib's mask by compare and select, 1 = the mask as arithmetic
+// (fp32; in fp64 the same as 2), 2 = read off the projected step (what the kernels run where ub::fast_stop_ok -- and, in
+// fp32, ub::moved_stop_ok -- hold), -1 = decided here by those screens on this instance (the kernels decide per batch).
 // *flags is OR-ed with TPC_MPC_FLAG_NONFINITE (1) / TPC_MPC_FLAG_MAX_ITER (2).
 template <typename T, int H, bool EQB>
 void host_solve_compact(T v, T ty, T tphi, const T* q, const T* r, double step, double wheelbase, const T* lo,
@@ -32,6 +33,7 @@ void host_solve_compact(T v, T ty, T tphi, const T* q, const T* r, double step, 
         iqd[2 * i + j] = val != (T)0 ? (T)1 / (val * m.s(j)) : (T)0;
     });
     const bool fast_stop = fast_stop_in < 0 ? fast_stop_ok(m, ty, tphi, q[0], q[1], r[0], r[1], eps, lambda) : fast_stop_in != 0;
+    const bool moved = fast_stop && (sizeof(T) == 8 || (fast_stop_in < 0 ? moved_stop_ok(m, eps, lambda) : fast_stop_in == 2));
     unsigned long iter = 0;
     bool stopped = nonfinite, vinit = false;
     unsigned f = nonfinite ? 1u : 0u;
@@ -79,7 +81,7 @@ void host_solve_compact(T v, T ty, T tphi, const T* q, const T* r, double step, 
             vv[2 * i] = vinit ? x[2 * i] : m.xz0;
             vv[2 * i + 1] = vinit ? x[2 * i + 1] : m.xz1;
         }
-        const T huge = (T)0x1p100;   // fp32 stop test (two-fma form)
+        const T huge = (T)0x1p100;   // fp32 mask-as-arithmetic stop test (two-fma form)
         while (true) {
             constexpr bool RV = Reverse<T, H>::value;
             T Z, Y;
@@ -103,7 +105,7 @@ void host_solve_compact(T v, T ty, T tphi, const T* q, const T* r, double step, 
                         const T up = (xx <= m.bl(j)) ? (T)0 : d;
                         const T dn = (xx >= m.bh(j)) ? (T)0 : -d;
                         mag = max_(up, dn);
-                    } else if (sizeof(T) == 8) {
+                    } else if (moved) {
                         mag = min_(abs_(d), abs_(xx - vn));
                     } else {
                         const T g_lo = m.gap_lo(j, xx, huge), g_hi = m.gap_hi(j, xx, huge);

@@ -32,8 +32,7 @@ inline int ub_grid(Kernel kernel, int block) {
     if (dev >= 0 && dev < kMaxDev) cache[dev] = cus * per_cu;
     return cus * per_cu;
 }
-template <typename T, bool EQB> struct TagFast {};
-template <typename T, bool EQB> struct TagExact {};
+template <typename T, bool EQB, int MODE> struct TagPg {};
 
 // coordinate descent + queue order: everything up to the projected-gradient launches (also the front half of the
 // GROUP family, mpc_group_inst.hip, which consumes the same records)
@@ -56,12 +55,12 @@ hipError_t phase1(const CompactArgs& a, const Knobs& k, const Workspace& ws, hip
     return hipSuccess;
 }
 // one build of the projected-gradient kernel (it returns at once unless the coordinate-descent kernel's screen picked it)
-template <typename T, bool EQB, bool FAST>
+template <typename T, bool EQB, int MODE>
 hipError_t pg_launch(const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
     constexpr int bt = kWave * UbPlan<T, kH>::occ;
     const int64_t need = (a.n + bt - 1) / bt;
-    const int cap = ub_grid<std::conditional_t<FAST, TagFast<T, EQB>, TagExact<T, EQB>>>(ub_pg_kernel<T, kH, EQB, FAST>, bt);
-    hipLaunchKernelGGL((ub_pg_kernel<T, kH, EQB, FAST>), dim3((unsigned)(need < cap ? need : cap)), dim3(bt), 0, s, a, k,
+    const int cap = ub_grid<TagPg<T, EQB, MODE>>(ub_pg_kernel<T, kH, EQB, MODE>, bt);
+    hipLaunchKernelGGL((ub_pg_kernel<T, kH, EQB, MODE>), dim3((unsigned)(need < cap ? need : cap)), dim3(bt), 0, s, a, k,
                        (const T*)ws.state, (const uint32_t*)ws.order, ws.ticket, ws.stats, order_queue_len(ws.sort_temp));
     return hipGetLastError();
 }
@@ -71,9 +70,12 @@ hipError_t run(const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStr
     if (a.n <= 0) return hipSuccess;
     hipError_t e = phase1<T, EQB>(a, k, ws, s);
     if (e != hipSuccess) return e;
-    // both builds go out; the one the coordinate-descent kernel's screen did not pick returns at once
-    e = pg_launch<T, EQB, true>(a, k, ws, s);
-    if (e == hipSuccess) e = pg_launch<T, EQB, false>(a, k, ws, s);
+    // every build goes out; those the coordinate-descent kernel's screens did not pick return at once
+    e = pg_launch<T, EQB, 2>(a, k, ws, s);
+    if constexpr (sizeof(T) == 4) {
+        if (e == hipSuccess) e = pg_launch<T, EQB, 1>(a, k, ws, s);
+    }
+    if (e == hipSuccess) e = pg_launch<T, EQB, 0>(a, k, ws, s);
     if (ws.ev) (void)hipEventRecord(ws.ev[2], s);
     return e;
 }
@@ -100,8 +102,8 @@ hipError_t TPC_CAT(ub_phase1_h, TPC_UB_H)(int dtype, int equal_bounds, const Com
 }
 hipError_t TPC_CAT(ub_exact_h, TPC_UB_H)(int dtype, int equal_bounds, const CompactArgs& a, const Knobs& k,
                                           const Workspace& ws, hipStream_t s) {
-    if (dtype == 0) return equal_bounds ? pg_launch<double, true, false>(a, k, ws, s) : pg_launch<double, false, false>(a, k, ws, s);
-    return pg_launch<float, true, false>(a, k, ws, s);
+    if (dtype == 0) return equal_bounds ? pg_launch<double, true, 0>(a, k, ws, s) : pg_launch<double, false, 0>(a, k, ws, s);
+    return pg_launch<float, true, 0>(a, k, ws, s);
 }
 
 }  // namespace tpc

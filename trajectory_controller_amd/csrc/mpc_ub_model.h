@@ -72,9 +72,10 @@ template <typename T> struct GradScale;
 template <> struct GradScale<double> {
     static constexpr double g = 0x1p-600, inv_g = 0x1p600;
 };
-// fp32 has no room for such a scale (and its stop test keeps dlib's mask, see mpc_ub.h)
+// fp32: 2^-40 (round 4; it was 1).  The scale is exact (a power of two; nothing in the projected-gradient phase comes
+// near fp32's range at either end), and it lets fp32 use the same arithmetic stop test wherever ub::moved_stop_ok holds.
 template <> struct GradScale<float> {
-    static constexpr float g = 1.0f, inv_g = 1.0f;
+    static constexpr float g = 0x1p-40f, inv_g = 0x1p40f;
 };
 
 // Unit-box coordinates are an fp64 device.  In fp32 they would cost accuracy: a control near zero sits at
@@ -203,7 +204,7 @@ template <typename T, bool EQB, bool UBOX = UnitBox<T>::value> struct Unit {
 // Screen of the fast stop test (per instance; one failing instance sends the batch through the
 // exact build, like LANE).  Needed: no intermediate can overflow or be NaN, the start point u = 0
 // lies inside the box, and a projected step that vanishes in rounding implies |df| < eps:
-// lambda * s * 2^-50 < eps (mpc_ub_model.h; fp32: finiteness only, its test keeps dlib's mask).
+// lambda * s * 2^-50 < eps (fp32: finiteness only here; its own rounding condition is ub::moved_stop_ok below).
 // fp64 magnitudes with |a|,|c|,|target| <= 1e50, q <= 1e30, r <= 1e100, s,|bound| <= 1e10, H <= 40:
 // |Y| <= 4e61, |Z| <= 2e113, |N0| <= 7e144, |N1| <= 3e196, |df| <= 3e246.
 template <typename T, bool EQB>
@@ -229,6 +230,24 @@ TPC_HD bool fast_stop_ok(const Unit<T, EQB>& m, T ty, T tphi, T q0, T q1, T r0, 
     return ok;
 }
 
+
+// Second screen, fp32 in dlib's coordinates only (the unit-box form has its counterpart inside fast_stop_ok): may the
+// stop test be read off the projected step -- min(|g df|, |x - x_new|) -- instead of dlib's mask as arithmetic?
+// With B = the largest |bound|, b = the smallest:
+//   a free variable with |df| >= eps must MOVE: its step |df| / lambda must exceed half an ulp of x, at most B 2^-24;
+//   and by more than g eps: lambda <= 2^36 (the step is then >= 2^-36 eps, rounding takes at most a third of it);
+//   a step clipped at a bound from inside still shows: the spacing of floats next to a bound, >= b 2^-24, exceeds g eps;
+//   a blocked variable's step is exactly 0 (the clamp returns the bound's own bits).
+// lambda grows with the horizon and the speed (N = 20, v = 4 m/s: 3.0e5, the margin is 1.4; N = 40: 4.9e6, refused),
+// so batches that fail here keep the mask-as-arithmetic build: same decisions, 14 % slower at N = 20.
+template <typename T, bool EQB> TPC_HD bool moved_stop_ok(const Unit<T, EQB>& m, T eps, T lambda) {
+    if (Unit<T, EQB>::kUnitBox) return true;
+    const T bmax = max_(max_(abs_(m.bl0), abs_(m.bl1)), max_(abs_(m.bh0), abs_(m.bh1)));
+    const T bmin = min_(min_(abs_(m.bl0), abs_(m.bl1)), min_(abs_(m.bh0), abs_(m.bh1)));
+    bool ok = lambda * bmax * (T)0x1p-24 < eps * (T)0.999 && lambda <= (T)0x1p36;
+    ok = ok && bmin * (T)0x1p-24 >= (T)2 * GradScale<T>::g * eps;
+    return ok;
+}
 
 // Which (dtype, horizon) regenerate the forward pass in the backward sweep instead of keeping it: part of
 // the family's arithmetic, so it lives here where kernels and model both see it.

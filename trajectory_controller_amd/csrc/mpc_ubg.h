@@ -246,7 +246,7 @@ __global__ __launch_bounds__((64 * UbgPlan<T, H>::occ), (UbgPlan<T, H>::occ)) vo
     auto v_put = [&](int q, T val) { if (q < 2 * KV) r_v[q] = val; else s_all[MMR + q - 2 * KV][threadIdx.x] = val; };
     auto v_get = [&](int q) -> T { if (q < 2 * KV) return r_v[q]; else return s_all[MMR + q - 2 * KV][threadIdx.x]; };
 
-    constexpr T gs = ub::GradScale<T>::g;
+    constexpr T gs = ubg::GradScale<T>::g;
     const T geps = gs * (T)kn.eps;
     constexpr bool MOVED = FAST && sizeof(T) == 8;
     T huge = (T)0x1p100;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__((64 * UbgPlan<T, H>::occ), (UbgPlan<T, H>::occ)) vo
                         ubg::linear_term<T, I, H>(
                             m, [&](int i, int s) { return tg[(int64_t)(2 * i + s) * g.ld]; }, [&](int q, T val) { w[q] = val; },
                             [&](int q) { return w[q]; }, [&](int i, int j, T val) { mm_put(2 * i + j, val); });
-                        il = ((T)1 / lambda) * ub::GradScale<T>::inv_g;          // mpc.h:342
+                        il = ((T)1 / lambda) * ubg::GradScale<T>::inv_g;          // mpc.h:342
                         const T sq = tsqrt(lambda);
                         beta = (sq - (T)1) / (sq + (T)1);                        // mpc.h:343
                         have = true;

@@ -22,7 +22,12 @@ namespace ubg {
 
 using ub::abs_;
 using ub::fma_;
-using ub::GradScale;
+// gradient scale of the projected-gradient phase: the compact form's in fp64; 1 in fp32 (its stop test keeps dlib's mask
+// as arithmetic, mpc_ubg.h -- per-instance bounds may be pinned or infinite, so there is no batch-wide rounding screen)
+template <typename T> struct GradScale : ub::GradScale<T> {};
+template <> struct GradScale<float> {
+    static constexpr float g = 1.0f, inv_g = 1.0f;
+};
 using ub::max_;
 using ub::min_;
 using ub::sqrt_;

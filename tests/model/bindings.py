@@ -50,7 +50,8 @@ class UbModel:
     def solve_compact(self, H, v, dy, dphi, weights=DEFAULT_WEIGHTS, T=0.1, l=0.21,
                       lo=(-ALPHA_MAX, -ALPHA_MAX), hi=(ALPHA_MAX, ALPHA_MAX), eps=0.01, max_iter=10000,
                       smo_iters=50, nthreads=1, fast_stop=True):
-        """fast_stop: True / False = the screened / exact stop-test build; None = decided by the kernels' own screen."""
+        """fast_stop: True / False = a screened build (fp32: which of the two, decided batch-wide by the second screen like the
+        kernels do) / the exact stop-test build; None = decided by the kernels' own screens."""
         a = lambda z: np.ascontiguousarray(z, dtype=self.np)
         p = lambda z: z.ctypes.data_as(self._rp)
         v, dy, dphi, w, lo, hi = a(v), a(dy), a(dphi), a(weights), a(lo), a(hi)
@@ -59,7 +60,7 @@ class UbModel:
         iters = np.empty(n, dtype=np.int32)
         flags = C.c_uint(0)
         rc = self.fn(H, n, nthreads, p(v), p(dy), p(dphi), p(w), T, l, p(lo), p(hi), eps, max_iter, smo_iters,
-                     -1 if fast_stop is None else (1 if fast_stop else 0), p(front), p(rear), iters.ctypes.data_as(C.POINTER(C.c_int)),
+                     -1 if fast_stop is None else int(fast_stop), p(front), p(rear), iters.ctypes.data_as(C.POINTER(C.c_int)),
                      C.byref(flags))
         if rc != 0:
             raise ValueError(f"ub model: unsupported H={H}")

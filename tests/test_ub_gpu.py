@@ -74,6 +74,24 @@ def test_ub_bits_vs_model_f32(torch_cuda, model32, H, n):
     assert bits_equal32(f, mf) and bits_equal32(r, mr)
 
 
+@pytest.mark.parametrize("H,n,vmax,one_fast", [(20, 2500, 8.0, False), (20, 2500, 3.5, True), (10, 3000, 20.0, False), (10, 3000, 6.0, True)])
+def test_ub_f32_stop_test_builds(torch_cuda, model32, H, n, vmax, one_fast):
+    """fp32 has three builds of the projected-gradient kernel (ub_pg_kernel's MODE): the stop test read off the projected
+    step where EVERY instance of the batch passes the rounding screen (ub::moved_stop_ok: lambda * |bound| * 2^-24 < eps --
+    lambda grows with speed and horizon), dlib's mask as arithmetic otherwise.  Speeds beyond the screen, and a batch
+    where a single instance is: bit for bit the model's answer, which takes the same batch-wide decision."""
+    from trajectory_controller_amd.synth import compact_inputs
+    v, dy, dphi = (a.astype(np.float32) for a in compact_inputs(H, n, first=300000))
+    v = (v * np.float32(vmax / 4.0)).astype(np.float32)
+    if one_fast:
+        v[n // 2] = np.float32(4.0 * vmax)   # one instance beyond the screen sends the whole batch to the mask build
+    mf, mr, mit, _ = model32.solve_compact(H, v, dy, dphi, nthreads=8)
+    with _solver(H, dtype="f32") as s:
+        f, r, it = _run(torch_cuda, s, v, dy, dphi)
+    assert np.array_equal(it, mit)
+    assert bits_equal32(f, mf) and bits_equal32(r, mr)
+
+
 @pytest.mark.parametrize("H", [4, 5, 10, 20, 40])
 def test_ub_golden(torch_cuda, H):
     """Real-dlib golden vectors: <= 1e-9, and every control dlib leaves on a bound is on it bit for bit."""

@@ -44,6 +44,22 @@ def test_model_vs_oracle_iters(model, oracle, H, n, fast):
     assert np.array_equal(np.abs(of) == A, np.abs(f) == A) and np.array_equal(np.abs(orr) == A, np.abs(r) == A)
 
 
+@pytest.mark.parametrize("H,n,vmax", [(20, 1200, 4.0), (20, 600, 8.0), (10, 2000, 6.0), (10, 1000, 20.0), (40, 200, 4.0)])
+def test_model_f32_fast_builds_equal_the_exact_one(H, n, vmax):
+    """fp32: whichever screened stop test the batch-wide screens pick (read off the projected step while
+    lambda * |bound| * 2^-24 < eps holds for every instance -- N = 20 up to ~4.8 m/s --, dlib's mask as arithmetic
+    beyond), outputs and iteration counts equal those of dlib's mask by compare and select, bit for bit."""
+    from tests.model.bindings import UbModel
+    from trajectory_controller_amd.synth import compact_inputs
+    m = UbModel("f32")
+    v, dy, dphi = (a.astype(np.float32) for a in compact_inputs(H, n, first=300000))
+    v = (v * np.float32(vmax / 4.0)).astype(np.float32)
+    f1, r1, i1, _ = m.solve_compact(H, v, dy, dphi, nthreads=8, fast_stop=None)
+    f0, r0, i0, _ = m.solve_compact(H, v, dy, dphi, nthreads=8, fast_stop=False)
+    assert np.array_equal(i1, i0)
+    assert np.array_equal(f1.view(np.uint32), f0.view(np.uint32)) and np.array_equal(r1.view(np.uint32), r0.view(np.uint32))
+
+
 def test_model_knobs_and_edges(model, oracle):
     g = load_golden("compact_knobs_H10.npz")
     f, r, it, _ = model.solve_compact(10, g["v"], g["dy"], g["dphi"], eps=float(g["eps"]),

@@ -24,16 +24,17 @@ def _is_torch(x) -> bool:
 
 
 class MpcSolver:
-    """One tpc_mpc_handle bound to a HIP device.  Not thread-safe (like the handle)."""
+    """One tpc_mpc_handle bound to a HIP device (device=None: host-only, TPC_MPC_DEVICE_NONE).  Not thread-safe (like the handle)."""
 
     def __init__(self, horizon: int = 20, device: int = 0, dtype: str = "f64", algo: str = "auto",
                  **params):
         self._lib = capi.load_library()
         self._h = C.c_void_p()
-        rc = self._lib.tpc_mpc_create(int(device), C.byref(self._h))
+        device = capi.DEVICE_NONE if device is None else int(device)   # None: a host-only handle (solve_one only, no GPU touched)
+        rc = self._lib.tpc_mpc_create(device, C.byref(self._h))
         if rc != capi.OK:
             raise capi.TpcMpcError(rc, self._lib.tpc_mpc_last_error(None).decode())
-        self.device = int(device)
+        self.device = device
         self.dtype = {"f64": capi.F64, "f32": capi.F32}[dtype]
         self.algo = {"auto": capi.ALGO_AUTO, "wave": capi.ALGO_WAVE, "lane": capi.ALGO_LANE,
                      "lane_fma": capi.ALGO_LANE_FMA, "group": capi.ALGO_GROUP}[algo]

@@ -514,7 +514,8 @@ def main():
             perm = np.random.default_rng(3).permutation(len(hz))
             c5 = {"workload": "batch 65536 mixed over N in {5,10,20,40}, one call", "unit": "ms per batch",
                   "note": "f64: AUTO as shipped -- the ~10 % of the N=40 instances that end on the 10 000-iteration cap are "
-                          "solved once more bit-exactly (one LANE pass: 10 000 iterations at one lane's pace); "
+                          "solved once more bit-exactly (10 000 iterations of dlib's own arithmetic, eight lanes per instance: "
+                          "csrc/mpc_lanex.h); "
                           "f64_fast_capped: TPC_MPC_PARAM_FAST_CAPPED, the tolerance families' answer kept (<= 1.5e-12 from "
                           "dlib on this workload)"}
             from trajectory_controller_amd import capi

@@ -69,7 +69,12 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
  *          summation).
  *   LANE : one lane per instance, dlib's O(H) recurrences unrolled in registers, 64 instances
  *          per wavefront with dynamic refill of finished lanes.  Bit-identical to the reference
- *          arithmetic in fp64; highest throughput on large batches.
+ *          arithmetic in fp64; the bit-exact family for large batches.  Compact form, fp64, N = 10, 20, 40, batches
+ *          that cannot fill the chip that way (below ~98 000 instances at N = 10 / 20, ~60 000 at N = 40): the
+ *          projected-gradient phase runs G = N / 5 lanes per instance (csrc/mpc_lanex.h) -- dlib's two recurrences stay
+ *          sequential, handed from lane to lane, everything else of an iteration is shared out; the same IEEE
+ *          operations on the same operands, hence the same bits -- 16 384 instances of N = 40: 14.3 ms instead of 49.8,
+ *          N = 20: 3.3 instead of 6.9.
  *   LANE_FMA : LANE's layout (one lane per instance, persistent wavefronts, refill queue) with the
  *          arithmetic rebuilt for the hardware instead of for dlib's rounding: controls in unit-box
  *          coordinates (dlib's clamp is the free [0,1] output clamp of the instruction that produces the
@@ -111,8 +116,10 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
  *          such instances are solved ONCE MORE by the bit-exact LANE kernels in the same call and come back with
  *          dlib's bits; every other instance took dlib's decisions on quantities that differ from dlib's by rounding
  *          (<= 1e-9 asserted, ~1e-12 observed).  The second pass costs three empty launches when nothing ended on
- *          the cap; when something did, it lasts max_iter iterations at one lane's pace (N = 40, max_iter 10 000:
- *          50 ms -- BASELINE config 5, where a tenth of the N = 40 instances end there: 58 ms with it, 7 ms without).
+ *          the cap; when something did, it lasts max_iter bit-exact iterations (compact form at N = 10 / 20 / 40: G
+ *          lanes per instance, 1.4 us per iteration at N = 40 -- 14 ms with dlib's cap of 10 000; BASELINE config 5,
+ *          where a tenth of the N = 40 instances end there: 21.5 ms with it, 7 ms without; N = 30 and the general
+ *          form: one lane per instance, 5 us per iteration at N = 40).
  *          A host that prefers the tolerance families' answer for capped instances sets TPC_MPC_PARAM_FAST_CAPPED in
  *          tpc_mpc_params.options; an explicitly demanded family is taken at its word; a host that needs dlib's bits
  *          everywhere asks for LANE. */

@@ -123,6 +123,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.tpc_mpc_x_set_work_hint.argtypes = [vp, vp, C.c_int64, C.c_int]   # experimental (csrc/tpc_mpc_experimental.h)
     lib.tpc_mpc_set_option.argtypes = [vp, C.c_int, C.c_int64]
     lib.tpc_mpc_x_set_group_share.argtypes = [vp, C.c_int, C.c_int]       # experimental
+    lib.tpc_mpc_x_set_lanex_below.argtypes = [vp, C.c_int64]               # experimental
     lib.tpc_mpc_reserve.argtypes = [vp, C.POINTER(Params), C.c_int64, C.c_int]
     lib.tpc_mpc_build_info.restype = C.c_char_p
     lib.tpc_mpc_set_resident.argtypes = [vp, C.c_int64]

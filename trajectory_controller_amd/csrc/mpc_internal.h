@@ -69,6 +69,8 @@ struct Workspace {
     int wave_group = 0;   // TPC_MPC_OPT_WAVE_GROUP: 0 auto, 1 / 2 / 4 instances per wavefront
     int group_lanes = 0;  // GROUP: lanes per instance (2 / 4 / 8) for this horizon
     int max_waves = 0;    // GROUP: size of the persistent grid (0: one wavefront per SIMD of the device)
+    int64_t lanex_below = -1;   // LANE, compact form, fp64: batches below this take the G-lanes-per-instance kernel (mpc_lanex.h); -1: the measured default, 0: never
+    int cu_count = 0;     // of the device (scales measured crossovers); 0: unknown, take 256
 };
 
 // WAVE work queue (mpc_wave.h): the dynamic part of the queue is dealt out through kQueueTickets counters on

@@ -3,6 +3,7 @@
 #include <cstdint>
 
 #include "mpc_lane.h"
+#include "mpc_lanex.h"
 
 #ifndef TPC_LANE_H
 #error "compile with -DTPC_LANE_H=<horizon>"
@@ -35,7 +36,7 @@ inline int pg_grid(Kernel kernel, int block) {
     if (dev >= 0 && dev < kMaxDev) cache[dev] = cus * per_cu;
     return cus * per_cu;
 }
-struct TagState {}; struct TagFast {}; struct TagExact {};
+struct TagState {}; struct TagFast {}; struct TagExact {}; struct TagLanex {}; template <int I> struct TagLanexG {};
 
 // The fused PG kernel publishes controls[0] only; a caller that wants the controller state back
 // (warm-start chains, tpc_mpc_rollout) gets the kernel that keeps it.
@@ -95,11 +96,46 @@ hipError_t phase2(const Args& a, const Knobs& k, const Workspace& ws, hipStream_
     return hipGetLastError();
 }
 
+// Batch sizes below which the compact fp64 LANE family runs its projected-gradient phase G lanes per instance
+// (mpc_lanex.h), measured on a 256-CU part (profiles/r04_lanex_crossover.txt) and scaled by the CU count.
+inline int64_t lanex_below(const Workspace& ws) {
+    if (ws.lanex_below >= 0) return ws.lanex_below;
+    const int64_t at = kH == 40 ? 60000 : (kH == 20 || kH == 10 ? 98304 : 0);   // (N = 40: 14.3 against 49.8 ms up to 16 384, level at 65 536)
+    const int cus = ws.cu_count > 0 ? ws.cu_count : 256;
+    return at * cus / 256 < at ? at * cus / 256 : at;
+}
+
 template <typename T, int I, class Model, class Args>
 hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
     if (a.n <= 0) return hipSuccess;
     hipError_t e = phase1<T, I, Model, Args>(a, k, ws, s);
     if (e != hipSuccess) return e;
+    if constexpr (std::is_same<Model, CompactModel<T>>::value && sizeof(T) == 8 && LanexPlan<kH>::built) {
+        if (a.n < lanex_below(ws)) {
+            constexpr int ng = LanexPlan<kH>::NG;
+            const int64_t need = (a.n + ng - 1) / ng;
+            const int grid_cap = pg_grid<TagLanex>(lanex_pg_kernel<T, kH>, kWave);
+            hipLaunchKernelGGL((lanex_pg_kernel<T, kH>), dim3((unsigned)(need < grid_cap ? need : grid_cap)), dim3(kWave), 0, s, a, k,
+                               (const T*)ws.state, (const uint32_t*)ws.order, ws.ticket, ws.stats, order_queue_len(ws.sort_temp),
+                               GroupRefillBatch<LanexPlan<kH>::G>::value);
+            e = hipGetLastError();
+            if (ws.ev) (void)hipEventRecord(ws.ev[2], s);
+            return e;
+        }
+    }
+    if constexpr (std::is_same<Args, GeneralArgs>::value && sizeof(T) == 8 && LanexPlan<kH>::built) {
+        if (!wants_state(a) && a.n < lanex_below(ws)) {   // cold start, u0 only: the same kernel family for the general model
+            constexpr int ng = LanexPlan<kH>::NG;
+            const int64_t need = (a.n + ng - 1) / ng;
+            const int grid_cap = pg_grid<TagLanexG<I>>(lanexg_pg_kernel<T, I, kH>, kWave);
+            hipLaunchKernelGGL((lanexg_pg_kernel<T, I, kH>), dim3((unsigned)(need < grid_cap ? need : grid_cap)), dim3(kWave), 0, s, a, k,
+                               (const T*)ws.state, (const uint32_t*)ws.order, ws.ticket, ws.stats, order_queue_len(ws.sort_temp),
+                               GroupRefillBatch<LanexPlan<kH>::G>::value);
+            e = hipGetLastError();
+            if (ws.ev) (void)hipEventRecord(ws.ev[2], s);
+            return e;
+        }
+    }
     e = phase2<T, I, Model, Args>(a, k, ws, s, false);
     if (ws.ev) (void)hipEventRecord(ws.ev[2], s);
     return e;
@@ -119,6 +155,23 @@ hipError_t resolve(const Args& a, const Knobs& k, const Workspace& ws, const int
     const int grid = (int)((a.n + kWave - 1) / kWave);
     hipLaunchKernelGGL((lane_cd_kernel<T, I, kH, Model, Args, true>), dim3(grid), dim3(kWave), 0, s, a, k, recs, ws.order,
                        (uint32_t*)nullptr, queue_len, ws.stats, 1, select, gate);
+    if constexpr (std::is_same<Model, CompactModel<T>>::value && sizeof(T) == 8 && LanexPlan<kH>::built) {
+        // compact form, N = 10, 20, 40: G lanes per instance, the chains handed from chunk to chunk (mpc_lanex.h) -- the
+        // same bits at a third of the iteration's time
+        constexpr int ng = LanexPlan<kH>::NG;
+        const int64_t need = (a.n + ng - 1) / ng;
+        const int grid_cap = pg_grid<TagLanex>(lanex_pg_kernel<T, kH>, kWave);
+        hipLaunchKernelGGL((lanex_pg_kernel<T, kH>), dim3((unsigned)(need < grid_cap ? need : grid_cap)), dim3(kWave), 0, s, a, k,
+                           (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats, (const uint32_t*)queue_len, 1);
+        return hipGetLastError();
+    } else if constexpr (std::is_same<Args, GeneralArgs>::value && sizeof(T) == 8 && LanexPlan<kH>::built) {
+        constexpr int ng = LanexPlan<kH>::NG;
+        const int64_t need = (a.n + ng - 1) / ng;
+        const int grid_cap = pg_grid<TagLanexG<I>>(lanexg_pg_kernel<T, I, kH>, kWave);
+        hipLaunchKernelGGL((lanexg_pg_kernel<T, I, kH>), dim3((unsigned)(need < grid_cap ? need : grid_cap)), dim3(kWave), 0, s, a, k,
+                           (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats, (const uint32_t*)queue_len, 1);
+        return hipGetLastError();
+    } else {
     constexpr int bt = kWave * FusedOcc<T, kH>::value;
     const int64_t need = (a.n + bt - 1) / bt;
     // the exact-stop-test build only (bit-exact like the other one; lane_cd_kernel raises stats[2] for it where it
@@ -127,6 +180,7 @@ hipError_t resolve(const Args& a, const Knobs& k, const Workspace& ws, const int
     hipLaunchKernelGGL((lane_pg_fused_kernel<T, I, kH, Model, Args, false>), dim3((unsigned)(need < grid_cap ? need : grid_cap)),
                        dim3(bt), 0, s, a, k, (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats, (const uint32_t*)queue_len);
     return hipGetLastError();
+    }
 }
 
 }  // namespace

@@ -312,6 +312,8 @@ int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n,
     ws->wave_group = h->opt_wave_group;
     ws->group_lanes = group_lanes(h, H, dtype, n, form);
     ws->max_waves = h->max_waves;
+    ws->lanex_below = h->opt_lanex_below;
+    ws->cu_count = h->cu_count;
     h->ev_valid = h->profiling;
     h->last_algo = algo;
     ws->keys = ws->rank = ws->order = nullptr;
@@ -1186,6 +1188,15 @@ int tpc_mpc_x_set_group_share(tpc_mpc_handle h, int waves, int cu_count) {
         if (waves < 0 || cu_count < 0) return fail(h, TPC_MPC_ERR_BAD_ARG, "need waves >= 0, cu_count >= 0");
         h->max_waves = waves;
         if (cu_count > 0) h->cu_count = cu_count;
+        return TPC_MPC_OK;
+    });
+}
+
+int tpc_mpc_x_set_lanex_below(tpc_mpc_handle h, int64_t below) {
+    return guarded(h, [&]() -> int {
+        if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+        if (below < -1) return fail(h, TPC_MPC_ERR_BAD_ARG, "need below >= -1");
+        h->opt_lanex_below = below;
         return TPC_MPC_OK;
     });
 }

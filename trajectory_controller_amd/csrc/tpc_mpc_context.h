@@ -89,6 +89,7 @@ struct tpc_mpc_context {
     int opt_group_lanes = 0;         // GROUP: 0 auto, 2 / 4 / 8 lanes per instance
     int opt_host_horizon = 0;        // tpc_mpc_solve_one on the calling thread for horizons up to this (0: never)
     bool host_only = false;          // created with TPC_MPC_DEVICE_NONE: no HIP state at all
+    int64_t opt_lanex_below = -1;    // tpc_mpc_x_set_lanex_below: -1 the measured default, 0 never, else the batch size below which LANE runs mpc_lanex.h
     int max_waves = 0;               // persistent-grid limit of this handle's GROUP solves (child handles of a mixed batch: their share of the chip)
 };
 

@@ -24,6 +24,12 @@ int tpc_mpc_x_set_work_hint(tpc_mpc_handle h, const int32_t* hint, int64_t n, in
  * the child handles of its bins; exported to measure one bin on a share by itself (scripts/group_share.py). */
 int tpc_mpc_x_set_group_share(tpc_mpc_handle h, int waves, int cu_count);
 
+/* The bit-exact LANE family, compact form, fp64, N = 10 / 20 / 40: batches of fewer than `below` instances run their
+ * projected-gradient phase G lanes per instance (csrc/mpc_lanex.h: same bits, a third of the iteration's latency, a third
+ * of the throughput of a full chip).  -1 (default): the measured crossover; 0: never.  Exported to measure that crossover
+ * (scripts/lanex_crossover.py). */
+int tpc_mpc_x_set_lanex_below(tpc_mpc_handle h, int64_t below);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,8 @@ CONFIGS = {   # tag -> (kernel in the csv, bench key, k, note)
     "group_h40_256k": ("tpc::group_pg_kernel", "group_pg_kernel_f64_H40_n262144", 1, "chunked record reads: k=1 (uncalibrated)"),
     "group_h30_256k": ("tpc::group_pg_kernel", "group_pg_kernel_f64_H30_n262144", 1, "chunked record reads: k=1 (uncalibrated)"),
     "groupg_h40": ("tpc::groupg_pg_kernel", "groupg_pg_kernel_general_I2_f64_H40_n16384", 1, "chunked record reads + SoA model loads: k=1 (uncalibrated)"),
+    "lanex_h40": ("tpc::lanex_pg_kernel", "lanex_pg_kernel_f64_H40_n16384", 1, "chunked record reads: k=1 (uncalibrated)"),
+    "lanex_h20": ("tpc::lanex_pg_kernel", "lanex_pg_kernel_f64_H20_n16384", 1, "chunked record reads: k=1 (uncalibrated)"),
     "groupg_h20": ("tpc::groupg_pg_kernel", "groupg_pg_kernel_general_I2_f64_H20_n16384", 1, "chunked record reads + SoA model loads: k=1 (uncalibrated)"),
     "generalfma": ("tpc::ubg_pg_kernel<fast>", "ubg_pg_kernel_general_I2_f64_H20_n262144", 1, "strided record reads + SoA model loads: k=1"),
 }

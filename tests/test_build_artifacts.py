@@ -6,7 +6,7 @@ dlib to 1e-13 (caught by test_wave_queue_vs_oracle[40] on the GPU).  The cause w
 its precondition is removed instead: NO kernel of the WAVE family -- compact or general form, plain, queue, grouped,
 the queue-order kernel, the resident single-solve kernels -- no screened (fast stop test) projected-gradient
 kernel of the LANE_FMA family, which is what the BASELINE workloads run, no general-model LANE_FMA kernel (ubg_*) and
-no GROUP kernel (group_pg_kernel, groupg_pg_kernel: built for one wavefront per SIMD with the whole register file) may access scratch
+no GROUP kernel and no G-lanes-per-instance LANE kernel (group_pg_kernel, groupg_pg_kernel, lanex_pg_kernel, lanexg_pg_kernel: built for one wavefront per SIMD with the whole register file) may access scratch
 inside a loop.  (The bit-exact LANE kernels at N = 40 -- the state-returning / general long-horizon path -- still
 spill in their loops; they are checked bit for bit against dlib on the GPU and are listed.)"""
 import re
@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 LIB = os.path.join(ROOT, "trajectory_controller_amd", "lib", "libtpc_mpc.so")
 
-MUST_BE_CLEAN = re.compile(r"wave_|one_shot_kernel|ub_pg_kernelI[df]Li\d+ELb[01]ELi[12]EEE|ubg_|group_pg_kernel|groupg_pg_kernel")
+MUST_BE_CLEAN = re.compile(r"wave_|one_shot_kernel|ub_pg_kernelI[df]Li\d+ELb[01]ELi[12]EEE|ubg_|group_pg_kernel|groupg_pg_kernel|lanexg?_pg_kernel")
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"), reason="needs llvm-objdump")

@@ -97,3 +97,59 @@ def test_lanex_equals_one_lane_per_instance(torch_cuda, H, n):
     a = _solve(torch_cuda, H, v, dy, dphi, ALWAYS)
     b = _solve(torch_cuda, H, v, dy, dphi, NEVER)
     assert bits_equal(a[0], b[0]) and bits_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+
+
+# ---------------------------------------------------------------------------------------------
+# general form (lanexg_pg_kernel): per-instance A, B, C, Q, R, bounds, x0, per-step targets; one or two inputs; cold start
+
+GNAMES = ["A", "B", "C", "Q", "R", "lo", "hi", "x0", "targets"]
+
+
+def _solve_general(torch, I, H, g, below, **kw):
+    from trajectory_controller_amd import MpcSolver
+    n = g["A"].shape[0]
+    dev = [torch.from_numpy(np.ascontiguousarray(np.asarray(g[k], dtype=np.float64).reshape(n, -1).T)).to("cuda:0") for k in GNAMES]
+    with MpcSolver(horizon=H, device=0, dtype="f64", algo="lane", **kw) as s:
+        s._check(s._lib.tpc_mpc_x_set_lanex_below(s._h, below))
+        u0, it = s.solve_batch_general(*dev, inputs=I, want_iters=True)
+        torch.cuda.synchronize()
+        return u0.cpu().numpy().T, it.cpu().numpy(), s.last_flags
+
+
+@pytest.mark.parametrize("I", [1, 2])
+@pytest.mark.parametrize("H", [10, 20, 40])
+@pytest.mark.parametrize("below", [ALWAYS, NEVER], ids=["g_lanes", "one_lane"])
+def test_lanex_general_golden(torch_cuda, I, H, below):
+    g = load_golden(f"general_I{I}_H{H}.npz")
+    u0, _, _ = _solve_general(torch_cuda, I, H, g, below)
+    assert bits_equal(u0, g["u0"])
+
+
+@pytest.mark.parametrize("I", [1, 2])
+@pytest.mark.parametrize("H,n", [(10, 1501), (20, 900), (40, 333), (40, 3)])
+def test_lanex_general_vs_oracle(torch_cuda, oracle, I, H, n):
+    from trajectory_controller_amd.synth import general_inputs
+    g = general_inputs(H, n, I=I, first=9100)
+    ou0, _, oit = oracle.solve_general(I, H, *[g[k] for k in GNAMES], nthreads=8)
+    u0, it, _ = _solve_general(torch_cuda, I, H, g, ALWAYS)
+    assert np.array_equal(it, oit)
+    assert bits_equal(u0, ou0)
+
+
+@pytest.mark.parametrize("I", [1, 2])
+@pytest.mark.parametrize("H", [20, 40])
+def test_lanex_general_hostile(torch_cuda, oracle, I, H):
+    """Pinned and one-sided boxes, a dead input column (Q_diag == 0), Q = 0, large targets, a non-trivial A with negative
+    and zero entries: bits and iteration counts against the oracle, and equal to the one-lane-per-instance kernels."""
+    from trajectory_controller_amd.synth import general_inputs
+    from test_ub_model import hostile_general
+    g = hostile_general(general_inputs(H, 300, I=I, first=9300), I)
+    g["A"] = g["A"].copy()
+    g["A"][::7, 2] = -0.05      # a10 != 0
+    g["A"][::11, 0] = -0.9      # a negative diagonal entry
+    g["A"][::13, 3] = 0.0       # a zero one
+    ou0, _, oit = oracle.solve_general(I, H, *[g[k] for k in GNAMES], nthreads=8, max_iter=1500)
+    u0, it, fl = _solve_general(torch_cuda, I, H, g, ALWAYS, max_iter=1500)
+    u1, it1, fl1 = _solve_general(torch_cuda, I, H, g, NEVER, max_iter=1500)
+    assert np.array_equal(it, oit) and bits_equal(u0, ou0)
+    assert np.array_equal(it, it1) and bits_equal(u0, u1) and fl == fl1

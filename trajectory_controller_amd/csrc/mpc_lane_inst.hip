@@ -98,9 +98,12 @@ hipError_t phase2(const Args& a, const Knobs& k, const Workspace& ws, hipStream_
 
 // Batch sizes below which the compact fp64 LANE family runs its projected-gradient phase G lanes per instance
 // (mpc_lanex.h), measured on a 256-CU part (profiles/r04_lanex_crossover.txt) and scaled by the CU count.
-inline int64_t lanex_below(const Workspace& ws) {
+inline int64_t lanex_below(const Workspace& ws, bool general) {
     if (ws.lanex_below >= 0) return ws.lanex_below;
-    const int64_t at = kH == 40 ? 60000 : (kH == 20 || kH == 10 ? 98304 : 0);   // (N = 40: 14.3 against 49.8 ms up to 16 384, level at 65 536)
+    // (compact N = 40: 14.3 against 49.8 ms up to 16 384, level at 65 536; general form, two inputs: 21.6 against 61.4,
+    // level near 60 000 -- one input near 45 000; profiles/r04_lanex_crossover*.txt)
+    const int64_t at = general ? (kH == 40 ? 49152 : (kH == 20 ? 81920 : (kH == 10 ? 98304 : 0)))
+                               : (kH == 40 ? 60000 : (kH == 20 || kH == 10 ? 98304 : 0));
     const int cus = ws.cu_count > 0 ? ws.cu_count : 256;
     return at * cus / 256 < at ? at * cus / 256 : at;
 }
@@ -111,7 +114,7 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
     hipError_t e = phase1<T, I, Model, Args>(a, k, ws, s);
     if (e != hipSuccess) return e;
     if constexpr (std::is_same<Model, CompactModel<T>>::value && sizeof(T) == 8 && LanexPlan<kH>::built) {
-        if (a.n < lanex_below(ws)) {
+        if (a.n < lanex_below(ws, false)) {
             constexpr int ng = LanexPlan<kH>::NG;
             const int64_t need = (a.n + ng - 1) / ng;
             const int grid_cap = pg_grid<TagLanex>(lanex_pg_kernel<T, kH>, kWave);
@@ -124,7 +127,7 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
         }
     }
     if constexpr (std::is_same<Args, GeneralArgs>::value && sizeof(T) == 8 && LanexPlan<kH>::built) {
-        if (!wants_state(a) && a.n < lanex_below(ws)) {   // cold start, u0 only: the same kernel family for the general model
+        if (!wants_state(a) && a.n < lanex_below(ws, true)) {   // cold start, u0 only: the same kernel family for the general model
             constexpr int ng = LanexPlan<kH>::NG;
             const int64_t need = (a.n + ng - 1) / ng;
             const int grid_cap = pg_grid<TagLanexG<I>>(lanexg_pg_kernel<T, I, kH>, kWave);

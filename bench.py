@@ -503,6 +503,16 @@ def main():
                                 "value": 16384 * 20 / dm, "unit": "solves/s", "ms_per_step": dm / 20 * 1e3,
                                 "kernel_ms": {"first": m1, "second": m2},
                                 "alu_frac": mflops / (dm / 20) / 1e12 / FP64_VECTOR_PEAK_TF}
+            # the same batch through the bit-exact family (at this size: G lanes per instance, csrc/mpc_lanex.h)
+            with MpcSolver(horizon=20, device=local_rank, dtype="f64", algo="lane") as sb:
+                for _ in range(2):
+                    sb.solve_batch_compact(*cm, want_flags=False)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    sb.solve_batch_compact(*cm, want_flags=False)
+                torch.cuda.synchronize()
+                out["mid_batch"]["bit_exact_ms_per_step"] = (time.perf_counter() - t1) / 10 * 1e3
         if world == 1 and not a.no_config5 and a.dtype == "f64" and n == 262144 and H == 20:
             # BASELINE config 5 beside the headline: 65 536 instances split evenly over N in {5, 10, 20, 40}, interleaved,
             # ONE tpc_mpc_solve_batch_compact_mixed call per step (binned on the device; under AUTO the bins run one after

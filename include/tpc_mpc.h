@@ -69,9 +69,9 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
  *          summation).
  *   LANE : one lane per instance, dlib's O(H) recurrences unrolled in registers, 64 instances
  *          per wavefront with dynamic refill of finished lanes.  Bit-identical to the reference
- *          arithmetic in fp64; the bit-exact family for large batches.  fp64, N = 10, 20, 40 (compact form, and the
- *          general form without controls_inout / v_inout), batches
- *          that cannot fill the chip that way (below ~98 000 instances at N = 10 / 20, ~60 000 at N = 40): the
+ *          arithmetic in fp64; the bit-exact family for large batches.  fp64, N = 10, 20, 30, 40 (compact form, and the
+ *          general form with or without controller state), batches
+ *          that cannot fill the chip that way (below ~98 000 instances at N = 10 / 20, ~60 000 at N = 30 / 40): the
  *          projected-gradient phase runs G = N / 5 lanes per instance (csrc/mpc_lanex.h) -- dlib's two recurrences stay
  *          sequential, handed from lane to lane, everything else of an iteration is shared out; the same IEEE
  *          operations on the same operands, hence the same bits -- 16 384 instances of N = 40: 14.3 ms instead of 49.8,
@@ -117,10 +117,9 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
  *          such instances are solved ONCE MORE by the bit-exact LANE kernels in the same call and come back with
  *          dlib's bits; every other instance took dlib's decisions on quantities that differ from dlib's by rounding
  *          (<= 1e-9 asserted, ~1e-12 observed).  The second pass costs three empty launches when nothing ended on
- *          the cap; when something did, it lasts max_iter bit-exact iterations (compact form at N = 10 / 20 / 40: G
+ *          the cap; when something did, it lasts max_iter bit-exact iterations (N = 10 / 20 / 30 / 40: G
  *          lanes per instance, 1.4 us per iteration at N = 40 -- 14 ms with dlib's cap of 10 000; BASELINE config 5,
- *          where a tenth of the N = 40 instances end there: 21.5 ms with it, 7 ms without; general form 2.1 us;
- *          N = 30: one lane per instance, 3.5 us per iteration).
+ *          where a tenth of the N = 40 instances end there: 21.5 ms with it, 7 ms without; general form 2.1 us).
  *          A host that prefers the tolerance families' answer for capped instances sets TPC_MPC_PARAM_FAST_CAPPED in
  *          tpc_mpc_params.options; an explicitly demanded family is taken at its word; a host that needs dlib's bits
  *          everywhere asks for LANE. */

@@ -1,5 +1,5 @@
 """The bit-exact LANE family's projected-gradient phase G lanes per instance (csrc/mpc_lanex.h, lanex_pg_kernel): compact
-form, fp64, N = 10 / 20 / 40.  dlib's two recurrences (dlib_files/dlib/control/mpc.h:275-281) stay sequential -- handed from
+form, fp64, N = 10 / 20 / 30 / 40 (at N = 30 six lanes of a group of eight hold a chunk).  dlib's two recurrences (dlib_files/dlib/control/mpc.h:275-281) stay sequential -- handed from
 chunk to chunk, lane to lane -- and everything off them is shared out over the lanes of a group: the SAME IEEE operations on
 the same operands as one lane doing all N steps, so the bar is the LANE family's: bit-exact against real dlib and the
 oracle (signed zeros distinguished), identical iteration counts.  Two users: AUTO's re-solve of instances a tolerance family
@@ -44,7 +44,7 @@ def test_lanex_golden(torch_cuda, H, below):
     assert np.all(it[known] >= g["iters_lb"][known])
 
 
-@pytest.mark.parametrize("H,n", [(10, 3001), (20, 2000), (40, 777), (20, 1), (40, 9), (10, 70)])
+@pytest.mark.parametrize("H,n", [(10, 3001), (20, 2000), (30, 1100), (40, 777), (20, 1), (30, 13), (40, 9), (10, 70)])
 def test_lanex_vs_oracle(torch_cuda, oracle, H, n):
     """Seeded inputs, ragged batch sizes (partial groups and wavefronts): bits and iteration counts against the oracle."""
     from trajectory_controller_amd.synth import compact_inputs
@@ -55,7 +55,7 @@ def test_lanex_vs_oracle(torch_cuda, oracle, H, n):
     assert bits_equal(f, of) and bits_equal(r, orr)
 
 
-@pytest.mark.parametrize("H", [10, 20, 40])
+@pytest.mark.parametrize("H", [10, 20, 30, 40])
 @pytest.mark.parametrize("kw", [dict(eps=1e-4, max_iter=300), dict(eps=0.05, smo_iters=0), dict(max_iter=60, smo_iters=50),
                                 dict(lower=(-0.3, -0.2), upper=(0.25, 0.4)), dict(lower=(0.05, -0.3), upper=(0.3, -0.1)),
                                 dict(weight_y=3.0, weight_phi=200.0, weight_steering_front=1e-6, weight_steering_rear=0.5)],
@@ -88,7 +88,7 @@ def test_lanex_edge_rows(torch_cuda):
     assert bits_equal(f, f1) and bits_equal(r, r1) and np.array_equal(it, it1)
 
 
-@pytest.mark.parametrize("H,n", [(40, 20000), (20, 70000)])
+@pytest.mark.parametrize("H,n", [(40, 20000), (30, 12000), (20, 70000)])
 def test_lanex_equals_one_lane_per_instance(torch_cuda, H, n):
     """More instances than the persistent grid holds groups (refill passes, the longest-first queue): the two layouts
     of the family agree in every bit and every iteration count."""
@@ -117,7 +117,7 @@ def _solve_general(torch, I, H, g, below, **kw):
 
 
 @pytest.mark.parametrize("I", [1, 2])
-@pytest.mark.parametrize("H", [10, 20, 40])
+@pytest.mark.parametrize("H", [10, 20, 30, 40])
 @pytest.mark.parametrize("below", [ALWAYS, NEVER], ids=["g_lanes", "one_lane"])
 def test_lanex_general_golden(torch_cuda, I, H, below):
     g = load_golden(f"general_I{I}_H{H}.npz")
@@ -126,7 +126,7 @@ def test_lanex_general_golden(torch_cuda, I, H, below):
 
 
 @pytest.mark.parametrize("I", [1, 2])
-@pytest.mark.parametrize("H,n", [(10, 1501), (20, 900), (40, 333), (40, 3)])
+@pytest.mark.parametrize("H,n", [(10, 1501), (20, 900), (30, 500), (40, 333), (40, 3)])
 def test_lanex_general_vs_oracle(torch_cuda, oracle, I, H, n):
     from trajectory_controller_amd.synth import general_inputs
     g = general_inputs(H, n, I=I, first=9100)
@@ -137,7 +137,7 @@ def test_lanex_general_vs_oracle(torch_cuda, oracle, I, H, n):
 
 
 @pytest.mark.parametrize("I", [1, 2])
-@pytest.mark.parametrize("H", [20, 40])
+@pytest.mark.parametrize("H", [20, 30, 40])
 def test_lanex_general_hostile(torch_cuda, oracle, I, H):
     """Pinned and one-sided boxes, a dead input column (Q_diag == 0), Q = 0, large targets, a non-trivial A with negative
     and zero entries: bits and iteration counts against the oracle, and equal to the one-lane-per-instance kernels."""
@@ -153,3 +153,29 @@ def test_lanex_general_hostile(torch_cuda, oracle, I, H):
     u1, it1, fl1 = _solve_general(torch_cuda, I, H, g, NEVER, max_iter=1500)
     assert np.array_equal(it, oit) and bits_equal(u0, ou0)
     assert np.array_equal(it, it1) and bits_equal(u0, u1) and fl == fl1
+
+
+@pytest.mark.parametrize("I", [1, 2])
+@pytest.mark.parametrize("H", [10, 20, 30, 40])
+@pytest.mark.parametrize("below", [ALWAYS, NEVER], ids=["g_lanes", "one_lane"])
+def test_lanex_general_state_in_out(torch_cuda, oracle, I, H, below):
+    """controls_inout + v_inout (warm start from random controls -- some outside the box -- and a random v): outputs, the
+    whole solved sequence, dlib's v and the iteration counts against the oracle, bit for bit, in both layouts of the
+    family (G lanes per instance: lanexg_pg_kernel<STATE>; one lane per instance: lane_pg_kernel)."""
+    from trajectory_controller_amd import MpcSolver
+    from trajectory_controller_amd.synth import general_inputs
+    n = 300 if H <= 20 else 121
+    g = general_inputs(H, n, I=I, first=5200 + H)
+    rng = np.random.default_rng(300 + H + I)
+    cin = rng.uniform(-0.45, 0.45, size=(n, H, I))
+    vin = rng.uniform(-0.3, 0.3, size=(n, H, I))
+    ou0, ocout, oit, ovout = oracle.solve_general(I, H, *[g[k] for k in GNAMES], controls_in=cin, v_in=vin, want_v=True, nthreads=8)
+    soa = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(n, -1).T)
+    controls, vstate = soa(cin), soa(vin)
+    with MpcSolver(horizon=H, device=0, dtype="f64", algo="lane") as s:
+        s._check(s._lib.tpc_mpc_x_set_lanex_below(s._h, below))
+        u0, it = s.solve_batch_general(*[soa(g[k]) for k in GNAMES], controls=controls, v_state=vstate, inputs=I, want_iters=True)
+    assert np.array_equal(it, oit)
+    assert bits_equal(u0.T, ou0)
+    assert bits_equal(controls.T.reshape(n, H, I), ocout)
+    assert bits_equal(vstate.T.reshape(n, H, I), ovout)

@@ -102,8 +102,8 @@ inline int64_t lanex_below(const Workspace& ws, bool general) {
     if (ws.lanex_below >= 0) return ws.lanex_below;
     // (compact N = 40: 14.3 against 49.8 ms up to 16 384, level at 65 536; general form, two inputs: 21.6 against 61.4,
     // level near 60 000 -- one input near 45 000; profiles/r04_lanex_crossover*.txt)
-    const int64_t at = general ? (kH == 40 ? 49152 : (kH == 20 ? 81920 : (kH == 10 ? 98304 : 0)))
-                               : (kH == 40 ? 60000 : (kH == 20 || kH == 10 ? 98304 : 0));
+    const int64_t at = general ? (kH == 40 ? 49152 : (kH == 30 ? 57344 : (kH == 20 ? 81920 : (kH == 10 ? 98304 : 0))))
+                               : (kH == 40 ? 60000 : (kH == 30 ? 65536 : (kH == 20 || kH == 10 ? 98304 : 0)));
     const int cus = ws.cu_count > 0 ? ws.cu_count : 256;
     return at * cus / 256 < at ? at * cus / 256 : at;
 }
@@ -127,13 +127,20 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
         }
     }
     if constexpr (std::is_same<Args, GeneralArgs>::value && sizeof(T) == 8 && LanexPlan<kH>::built) {
-        if (!wants_state(a) && a.n < lanex_below(ws, true)) {   // cold start, u0 only: the same kernel family for the general model
+        if (a.n < lanex_below(ws, true)) {   // the same kernel family for the general model
             constexpr int ng = LanexPlan<kH>::NG;
             const int64_t need = (a.n + ng - 1) / ng;
-            const int grid_cap = pg_grid<TagLanexG<I>>(lanexg_pg_kernel<T, I, kH>, kWave);
-            hipLaunchKernelGGL((lanexg_pg_kernel<T, I, kH>), dim3((unsigned)(need < grid_cap ? need : grid_cap)), dim3(kWave), 0, s, a, k,
-                               (const T*)ws.state, (const uint32_t*)ws.order, ws.ticket, ws.stats, order_queue_len(ws.sort_temp),
-                               GroupRefillBatch<LanexPlan<kH>::G>::value);
+            if (wants_state(a)) {            // controller state in / out: every instance through the kernel (lane_pg_kernel's job)
+                const int grid_cap = pg_grid<TagLanexG<I + 2>>(lanexg_pg_kernel<T, I, kH, true>, kWave);
+                hipLaunchKernelGGL((lanexg_pg_kernel<T, I, kH, true>), dim3((unsigned)(need < grid_cap ? need : grid_cap)), dim3(kWave), 0, s,
+                                   a, k, (const T*)ws.state, (const uint32_t*)ws.order, ws.ticket, ws.stats, (const uint32_t*)nullptr,
+                                   GroupRefillBatch<LanexPlan<kH>::G>::value);
+            } else {
+                const int grid_cap = pg_grid<TagLanexG<I>>(lanexg_pg_kernel<T, I, kH>, kWave);
+                hipLaunchKernelGGL((lanexg_pg_kernel<T, I, kH>), dim3((unsigned)(need < grid_cap ? need : grid_cap)), dim3(kWave), 0, s, a, k,
+                                   (const T*)ws.state, (const uint32_t*)ws.order, ws.ticket, ws.stats, order_queue_len(ws.sort_temp),
+                                   GroupRefillBatch<LanexPlan<kH>::G>::value);
+            }
             e = hipGetLastError();
             if (ws.ev) (void)hipEventRecord(ws.ev[2], s);
             return e;

@@ -23,7 +23,8 @@
 // ~47 + the group's verdict = ~720 instructions against ~2 200: 1.9 us instead of 5.5.  N = 20 (G = 4): ~500 against 1 096.
 //
 // Records, queue and refill are lane_pg_fused_kernel's (a group refills like a lane there); persistent, one wavefront per SIMD.
-// fp64 only (the re-solve exists to deliver dlib's bits), compact model, N = 10, 20, 40 (chunks of five steps).
+// fp64 only (the re-solve exists to deliver dlib's bits), N = 10, 20, 30, 40 (chunks of five steps; at N = 30 six lanes of a
+// group of eight hold a chunk and six rounds hand the chains through).
 // Second user: the LANE family itself on batches that cannot fill the chip one lane per instance (mpc_lane_inst.hip, run):
 // there the same trade as GROUP's against LANE_FMA -- a third of the latency for a third of the full-chip throughput.
 #pragma once
@@ -35,9 +36,10 @@ namespace tpc {
 
 template <int H> struct LanexPlan {
     static constexpr int L = 5;                       // horizon steps per lane
-    static constexpr int G = H / L;                   // lanes per instance
-    static constexpr bool built = H == 10 || H == 20 || H == 40;
-    static constexpr int NG = built ? kWave / (G > 0 ? G : 1) : 1;   // instances per wavefront
+    static constexpr int GA = H / L;                  // lanes of a group that hold a chunk
+    static constexpr int G = GA <= 2 ? 2 : (GA <= 4 ? 4 : 8);   // lanes per instance (a power of two: the DPP moves); N = 30: 6 of 8 work
+    static constexpr bool built = H == 10 || H == 20 || H == 30 || H == 40;
+    static constexpr int NG = built ? kWave / G : 1;  // instances per wavefront
 };
 
 template <typename T, int H>
@@ -46,8 +48,8 @@ __global__ __launch_bounds__(64, 1) void lanex_pg_kernel(CompactArgs g, Knobs kn
                                                          unsigned long long* __restrict__ stats,
                                                          const uint32_t* __restrict__ queue_len, int refill_groups) {
     using P = LanexPlan<H>;
-    static_assert(P::built && P::G * P::L == H, "chunks of five steps: N = 10, 20, 40");
-    constexpr int L = P::L, G = P::G, NG = P::NG, RL = LaneRec<T, H>::kLen;
+    static_assert(P::built && P::GA * P::L == H, "chunks of five steps: N = 10, 20, 30, 40");
+    constexpr int L = P::L, G = P::G, GA = P::GA, NG = P::NG, RL = LaneRec<T, H>::kLen;
     const int64_t n_queue = (int64_t)__builtin_nontemporal_load(queue_len);
     if (n_queue <= 0) return;
     // every queued instance fits a group of the first ceil(n_queue / NG) wavefronts at once: the others are not needed
@@ -56,7 +58,8 @@ __global__ __launch_bounds__(64, 1) void lanex_pg_kernel(CompactArgs g, Knobs kn
     const int lane = threadIdx.x;
     const int p = lane & (G - 1);                 // chunk of this lane
     const int gbase = lane & ~(G - 1);            // first lane of its group
-    const bool first_chunk = p == 0, last_chunk = p == G - 1;
+    const bool first_chunk = p == 0, last_chunk = p == GA - 1;
+    const bool active = p < GA;                   // (N = 30: lanes 6 and 7 of a group hold no chunk; they run along on zeros)
     const T eps = (T)kn.eps;
     T nz = -(T)0;                                 // the chains' start state (see above)
     asm volatile("" : "+v"(nz));
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(64, 1) void lanex_pg_kernel(CompactArgs g, Knobs kn
                     const T* rec = recs + k * RL;
                     m.load(g, k);
 #pragma unroll
-                    for (int q = 0; q < 2 * L; ++q) u[q] = rec[2 * L * p + q];
+                    for (int q = 0; q < 2 * L; ++q) u[q] = active ? rec[2 * L * (active ? p : 0) + q] : (T)0;
                     const T lambda = rec[2 * H];
                     const uint64_t meta = load_meta<T>(rec + 2 * H + 1);
                     iter = (uint32_t)meta;
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(64, 1) void lanex_pg_kernel(CompactArgs g, Knobs kn
             }
             T o0 = nz, o1 = nz;   // this lane's state after its last step, as of the previous round
 #pragma unroll
-            for (int r = 0; r < G; ++r) {
+            for (int r = 0; r < GA; ++r) {
                 T i0 = group_mov<GroupDpp<G, 1, false>::ctrl>(o0), i1 = group_mov<GroupDpp<G, 1, false>::ctrl>(o1);
                 i0 = first_chunk ? nz : i0;
                 i1 = first_chunk ? nz : i1;
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(64, 1) void lanex_pg_kernel(CompactArgs g, Knobs kn
             for (int l = 0; l < L; ++l) { p0[l] = w0[l] * m.q0; p1[l] = w1[l] * m.q1; }
             T b0 = nz, b1 = nz;
 #pragma unroll
-            for (int r = 0; r < G; ++r) {
+            for (int r = 0; r < GA; ++r) {
                 T i0 = group_mov<GroupDpp<G, 1, true>::ctrl>(b0), i1 = group_mov<GroupDpp<G, 1, true>::ctrl>(b1);
                 i0 = last_chunk ? nz : i0;
                 i1 = last_chunk ? nz : i1;
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(64, 1) void lanex_pg_kernel(CompactArgs g, Knobs kn
                     vo[q] = vn;
                 }
             }
-            const int go = group_or<G>(acc < eps ? 0 : 1);                               // mpc.h:310-311 (a NaN maximum goes on)
+            const int go = group_or<G>((!active || acc < eps) ? 0 : 1);                   // mpc.h:310-311 (a NaN maximum goes on)
             ++wave_iters;
             ++iter;
             const bool ends = go == 0 || iter >= kn.max_iter;                            // mpc.h:271
@@ -257,23 +260,27 @@ __global__ __launch_bounds__(64, 1) void lanex_pg_kernel(CompactArgs g, Knobs kn
 // operations per pass ((a00 m0 + a01 m1) + s0, (a10 m0 + a11 m1) + s1; p0 + (a00 n0 + a10 n1), p1 + (a01 n0 + a11 n1)),
 // and the chain's start -- M = B u at step 0 (mpc.h:275), N = Q .* M at step H-1 (mpc.h:279) -- is taken by select in
 // the one lane that owns it (an arbitrary A has no |a| trick: its entries may be negative, zero or non-finite).
-template <typename T, int I, int H>
+// STATE = true: the caller wants the controller state back (all controls and dlib's v: warm-start chains,
+// tpc_mpc_rollout) and may hand one in (GeneralArgs::controls, ::v) -- lane_pg_kernel's job: every instance goes through
+// this kernel (queue_len = nullptr: the whole batch, g.n entries of `order`), a lane writes its chunk's part of the state.
+template <typename T, int I, int H, bool STATE = false>
 __global__ __launch_bounds__(64, 1) void lanexg_pg_kernel(GeneralArgs g, Knobs kn, const T* __restrict__ recs,
                                                           const uint32_t* __restrict__ order, uint32_t* __restrict__ ticket,
                                                           unsigned long long* __restrict__ stats,
                                                           const uint32_t* __restrict__ queue_len, int refill_groups) {
     using P = LanexPlan<H>;
-    static_assert(P::built && P::G * P::L == H, "chunks of five steps: N = 10, 20, 40");
+    static_assert(P::built && P::GA * P::L == H, "chunks of five steps: N = 10, 20, 30, 40");
     static_assert(I == 1 || I == 2, "one or two inputs");
-    constexpr int L = P::L, G = P::G, NG = P::NG, RL = LaneRec<T, H>::kLen;
-    const int64_t n_queue = (int64_t)__builtin_nontemporal_load(queue_len);
+    constexpr int L = P::L, G = P::G, GA = P::GA, NG = P::NG, RL = LaneRec<T, H>::kLen;
+    const int64_t n_queue = STATE ? g.n : (int64_t)__builtin_nontemporal_load(queue_len);
     if (n_queue <= 0) return;
     if ((int64_t)blockIdx.x * NG >= n_queue) return;
 
     const int lane = threadIdx.x;
     const int p = lane & (G - 1);
     const int gbase = lane & ~(G - 1);
-    const bool first_chunk = p == 0, last_chunk = p == G - 1;
+    const bool first_chunk = p == 0, last_chunk = p == GA - 1;
+    const bool active = p < GA;                   // (N = 30: lanes 6 and 7 of a group hold no chunk; they run along on zeros)
     const T eps = (T)kn.eps;
 
     GeneralModel<T, I> m;
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(64, 1) void lanexg_pg_kernel(GeneralArgs g, Knobs k
     for (int j = 0; j < I; ++j) { m.b[0][j] = m.b[1][j] = m.r[j] = m.lo_[j] = m.hi_[j] = (T)0; }
     m.targets = nullptr; m.ld = 0;
     T u[I * L], v[I * L], v2[I * L], mm[I * L];   // (index I * l + j)
-    T u0_prev[I];
+    T u0_prev[STATE ? I * L : I];                 // the controls before the speculative update (STATE: the whole chunk)
     T inv_lambda = (T)0, beta = (T)0;
     int64_t k = 0;
     uint32_t iter = 0;
@@ -292,13 +299,32 @@ __global__ __launch_bounds__(64, 1) void lanexg_pg_kernel(GeneralArgs g, Knobs k
 #pragma unroll
     for (int q = 0; q < I * L; ++q) { u[q] = (T)0; v[q] = (T)0; v2[q] = (T)0; mm[q] = (T)0; }
 #pragma unroll
-    for (int j = 0; j < I; ++j) u0_prev[j] = (T)0;
+    for (int j = 0; j < (STATE ? I * L : I); ++j) u0_prev[j] = (T)0;
 
-    auto publish = [&](const T* a, uint32_t it) {   // chunk 0 holds step 0
+    // a = this lane's controls (its chunk; chunk 0 holds step 0), vv = dlib's v of the chunk (STATE)
+    auto publish = [&](const T* a, const T* vv, uint32_t it) {
         if (p == 0) {
 #pragma unroll
             for (int j = 0; j < I; ++j) ((T*)g.u0)[(int64_t)j * g.ld + k] = a[j];
             if (g.iters) g.iters[k] = (int32_t)it;
+        }
+        if constexpr (STATE) {   // LaneIO<..., GeneralArgs>::write, a chunk per lane
+            if (active) {
+                if (g.controls) {
+                    T* cp = (T*)g.controls + k;
+#pragma unroll
+                    for (int l = 0; l < L; ++l)
+#pragma unroll
+                        for (int j = 0; j < I; ++j) cp[(int64_t)((L * p + l) * I + j) * g.ld] = a[I * l + j];
+                }
+                if (g.v) {
+                    T* vp = (T*)g.v + k;
+#pragma unroll
+                    for (int l = 0; l < L; ++l)
+#pragma unroll
+                        for (int j = 0; j < I; ++j) vp[(int64_t)((L * p + l) * I + j) * g.ld] = vv[I * l + j];
+                }
+            }
         }
     };
 
@@ -324,7 +350,7 @@ __global__ __launch_bounds__(64, 1) void lanexg_pg_kernel(GeneralArgs g, Knobs k
 #pragma unroll
                     for (int l = 0; l < L; ++l)
 #pragma unroll
-                        for (int j = 0; j < I; ++j) u[I * l + j] = rec[2 * (L * p + l) + j];
+                        for (int j = 0; j < I; ++j) u[I * l + j] = active ? rec[2 * (L * (active ? p : 0) + l) + j] : (T)0;
                     const T lambda = rec[2 * H];
                     const uint64_t meta = load_meta<T>(rec + 2 * H + 1);
                     iter = (uint32_t)meta;
@@ -332,10 +358,16 @@ __global__ __launch_bounds__(64, 1) void lanexg_pg_kernel(GeneralArgs g, Knobs k
                     if (meta & kMetaBadModel) flags |= 0x4u;
                     const bool vinit = (meta & kMetaVInit) != 0;   // mpc.h:330-334, else a fresh v = 0
 #pragma unroll
-                    for (int q = 0; q < I * L; ++q) v[q] = vinit ? u[q] : (T)0;
+                    for (int l = 0; l < L; ++l)
+#pragma unroll
+                        for (int j = 0; j < I; ++j) {
+                            T v_in = (T)0;   // (LaneIO<..., GeneralArgs>::load_v)
+                            if constexpr (STATE) { if (g.v && active) v_in = ((const T*)g.v + k)[(int64_t)((L * p + l) * I + j) * g.ld]; }
+                            v[I * l + j] = vinit ? u[I * l + j] : v_in;
+                        }
                     if ((meta & kMetaStopped) || iter >= kn.max_iter) {
                         if (!(meta & kMetaStopped)) flags |= 0x2u;
-                        publish(u, iter);
+                        publish(u, v, iter);
                     } else {
                         // the linear term (mpc.h:258-266; linear_term_fn, mpc_model.h): both chains over the whole horizon,
                         // run by every lane of the group, each keeping its chunk
@@ -365,7 +397,7 @@ __global__ __launch_bounds__(64, 1) void lanexg_pg_kernel(GeneralArgs g, Knobs k
             for (int l = 0; l < L; ++l) m.first(s0[l], s1[l], &u[I * l]);
             T o0 = (T)0, o1 = (T)0;
 #pragma unroll
-            for (int r = 0; r < G; ++r) {
+            for (int r = 0; r < GA; ++r) {
                 const T i0 = group_mov<GroupDpp<G, 1, false>::ctrl>(o0), i1 = group_mov<GroupDpp<G, 1, false>::ctrl>(o1);
                 T m0 = (m.a00 * i0 + m.a01 * i1) + s0[0];
                 T m1 = (m.a10 * i0 + m.a11 * i1) + s1[0];
@@ -387,7 +419,7 @@ __global__ __launch_bounds__(64, 1) void lanexg_pg_kernel(GeneralArgs g, Knobs k
             for (int l = 0; l < L; ++l) { p0[l] = w0[l] * m.q0; p1[l] = w1[l] * m.q1; }
             T b0 = (T)0, b1 = (T)0;
 #pragma unroll
-            for (int r = 0; r < G; ++r) {
+            for (int r = 0; r < GA; ++r) {
                 const T i0 = group_mov<GroupDpp<G, 1, true>::ctrl>(b0), i1 = group_mov<GroupDpp<G, 1, true>::ctrl>(b1);
                 T n0 = p0[L - 1] + (m.a00 * i0 + m.a10 * i1);
                 T n1 = p1[L - 1] + (m.a01 * i0 + m.a11 * i1);
@@ -405,7 +437,7 @@ __global__ __launch_bounds__(64, 1) void lanexg_pg_kernel(GeneralArgs g, Knobs k
             }
             // ---- gradient (mpc.h:283), dlib's mask and maximum (mpc.h:298-309), the speculative update (mpc.h:342-343)
 #pragma unroll
-            for (int j = 0; j < I; ++j) u0_prev[j] = u[j];
+            for (int j = 0; j < (STATE ? I * L : I); ++j) u0_prev[j] = u[j];
             T acc = (T)0;
 #pragma unroll
             for (int l = 0; l < L; ++l) {
@@ -422,15 +454,15 @@ __global__ __launch_bounds__(64, 1) void lanexg_pg_kernel(GeneralArgs g, Knobs k
                     vo[q] = vn;
                 }
             }
-            const int go = group_or<G>(acc < eps ? 0 : 1);                               // mpc.h:310-311
+            const int go = group_or<G>((!active || acc < eps) ? 0 : 1);                   // mpc.h:310-311
             ++wave_iters;
             ++iter;
             const bool ends = go == 0 || iter >= kn.max_iter;                            // mpc.h:271
             if (ballot_b(have && ends) != 0ull) {
                 const bool stop = have && go == 0;
                 const bool cap = have && !stop && iter >= kn.max_iter;
-                if (stop) { publish(u0_prev, iter - 1); have = false; }
-                if (cap) { flags |= 0x2u; publish(u, iter); have = false; }
+                if (stop) { publish(u0_prev, vi, iter - 1); have = false; }   // (dlib returns before the update: mpc.h:310-311)
+                if (cap) { flags |= 0x2u; publish(u, vo, iter); have = false; }
                 const unsigned long long waiting = ballot_b(!have && !exhausted);
                 if (__popcll(waiting) >= refill_groups * G || ballot_b(have) == 0ull) return true;
             }

@@ -381,6 +381,15 @@ int tpc_mpc_solve_batch_compact_sharded(tpc_mpc_handle h, const tpc_mpc_params* 
 int tpc_mpc_solve_batch_general_sharded(tpc_mpc_handle h, const tpc_mpc_params* p,
                                         const tpc_mpc_general_io* io_all, uint32_t* flags_out, void* stream);
 
+/* No reference counterpart.  The exchange of the two calls above by itself, for every OTHER entry point a host wants
+ * to shard (tpc_mpc_solve_batch_compact_mixed, tpc_mpc_follow_batch*, tpc_mpc_rollout, ...): each rank calls that entry
+ * for its block -- tpc_mpc_shard_range says which -- with output pointers offset to the block's slot [first, first + count)
+ * of FULL-size arrays, then this.  rows[i] (i < n_rows) is the DEVICE base of one full-size output row of n_total
+ * elements of elem_bytes (4 or 8) each; on return -- in stream order -- every GPU holds every rank's slot of every row
+ * (ncclAllGather when n_total divides evenly, otherwise one in-place ncclBroadcast per owner; one RCCL group).  A handle
+ * without a communicator: a no-op. */
+int tpc_mpc_gather_shards(tpc_mpc_handle h, int64_t n_total, void* const* rows, int n_rows, int elem_bytes, void* stream);
+
 /* ---- memory ------------------------------------------------------------------------------------ */
 
 /* No reference counterpart.  A handle grows its device scratch on demand, and growing frees and

@@ -302,6 +302,43 @@ def test_general_sharded_entry(torch_cuda, oracle, ragged):
     assert bits_equal(want.cpu().numpy().T, ou0) and np.array_equal(it.cpu().numpy(), oit)
 
 
+@pytest.mark.parametrize("ragged", [False, True])
+def test_gather_shards_behind_the_mixed_entry(torch_cuda, ragged):
+    """tpc_mpc_gather_shards: the exchange by itself, for entries that have no sharded form of their own -- here a mixed-
+    horizon batch solved into full-size outputs and exchanged through a real one-rank RCCL communicator (grouped in-place
+    ncclAllGather per row, or the per-owner ncclBroadcast form), fp64 rows and an int32 row (moved as bit patterns).  A
+    world of one must find its rows unchanged; without a communicator the call is a no-op; bad arguments are refused."""
+    from trajectory_controller_amd import MpcSolver, capi
+    from trajectory_controller_amd.synth import compact_inputs
+    torch = torch_cuda
+    n = 4099
+    hz = np.resize(np.array([5, 10, 20], dtype=np.int32), n)
+    v, dy, dphi = (torch.from_numpy(a).cuda() for a in compact_inputs(20, n, first=77))
+    with _solver(20, "auto") as s:
+        f, r, it = s.solve_batch_compact_mixed(hz, v, dy, dphi, want_iters=True)
+        want = (f.clone(), r.clone(), it.clone())
+        s.gather_shards(n, f, r)                       # no communicator: nothing to do
+        assert s.shard_range(n) == (0, n)
+        s.comm_test_mode(True, ragged)
+        s.comm_init(MpcSolver.comm_unique_id(), 0, 1)
+        fr = torch.stack([f, r])                       # a 2-D tensor: its rows are exchanged
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            s.gather_shards(n, fr)
+            s.gather_shards(n, f, r)
+            s.gather_shards(n, it)                     # 4-byte elements
+        stream.synchronize()
+        assert torch.equal(fr[0], want[0]) and torch.equal(fr[1], want[1])
+        assert torch.equal(f, want[0]) and torch.equal(r, want[1]) and torch.equal(it, want[2])
+        with pytest.raises(capi.TpcMpcError):
+            s._check(s._lib.tpc_mpc_gather_shards(s._h, n, None, 2, 8, None))
+        with pytest.raises(capi.TpcMpcError):
+            import ctypes as C
+            table = (C.c_void_p * 1)(f.data_ptr())
+            s._check(s._lib.tpc_mpc_gather_shards(s._h, n, table, 1, 2, None))
+
+
 _RANK_WORKER = r'''
 import os, sys
 sys.path.insert(0, {root!r})

@@ -37,7 +37,7 @@ EXPORTS = ("tpc_mpc_default_params", "tpc_mpc_create", "tpc_mpc_destroy", "tpc_m
            "tpc_mpc_follow_batch_horizon", "tpc_mpc_comm_unique_id", "tpc_mpc_comm_init_rank",
            "tpc_mpc_comm_destroy", "tpc_mpc_group_begin", "tpc_mpc_group_end", "tpc_mpc_shard_range",
            "tpc_mpc_solve_batch_compact_sharded", "tpc_mpc_comm_test_mode",
-           "tpc_mpc_solve_batch_general_sharded", "tpc_mpc_last_flags")
+           "tpc_mpc_solve_batch_general_sharded", "tpc_mpc_last_flags", "tpc_mpc_gather_shards")
 
 
 class Params(C.Structure):
@@ -124,6 +124,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.tpc_mpc_set_option.argtypes = [vp, C.c_int, C.c_int64]
     lib.tpc_mpc_x_set_group_share.argtypes = [vp, C.c_int, C.c_int]       # experimental
     lib.tpc_mpc_x_set_lanex_below.argtypes = [vp, C.c_int64]               # experimental
+    lib.tpc_mpc_gather_shards.argtypes = [vp, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_int, vp]
     lib.tpc_mpc_reserve.argtypes = [vp, C.POINTER(Params), C.c_int64, C.c_int]
     lib.tpc_mpc_build_info.restype = C.c_char_p
     lib.tpc_mpc_set_resident.argtypes = [vp, C.c_int64]

@@ -325,4 +325,47 @@ int tpc_mpc_solve_batch_general_sharded(tpc_mpc_handle h, const tpc_mpc_params* 
     });
 }
 
+int tpc_mpc_gather_shards(tpc_mpc_handle h, int64_t n_total, void* const* rows, int n_rows, int elem_bytes, void* stream) {
+    return guarded(h, [&]() -> int {
+        if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
+        if (h->host_only) return fail(h, TPC_MPC_ERR_NO_DEVICE, "a host-only handle has no device arrays to exchange");
+        if (n_total < 0 || n_total > 0x7fffffffll) return fail(h, TPC_MPC_ERR_BAD_ARG, "need 0 <= n_total < 2^31");
+        if (n_rows < 0 || (n_rows > 0 && !rows)) return fail(h, TPC_MPC_ERR_BAD_ARG, "need n_rows >= 0 and a row table");
+        if (elem_bytes != 4 && elem_bytes != 8) return fail(h, TPC_MPC_ERR_BAD_ARG, "elem_bytes is 4 or 8");
+        for (int i = 0; i < n_rows; ++i)
+            if (!rows[i]) return fail(h, TPC_MPC_ERR_BAD_ARG, "null row pointer");
+        if (n_total == 0 || n_rows == 0 || !h->comm) return TPC_MPC_OK;   // a world of one holds everything already
+        const int rank = h->comm->rank, world = h->comm->world;
+        int64_t first = 0, count = 0;
+        shard_range(n_total, rank, world, &first, &count);
+        HIP_TRY(h, hipSetDevice(h->device));
+        hipStream_t s = (hipStream_t)stream;
+        const int64_t es = elem_bytes;
+        StreamOrderScope order(h, s);   // (the rows were written by this handle's own solve on this or another stream)
+        int rc = order.begin();
+        if (rc) return rc;
+        Rccl* r = rccl();
+        if (!r) return fail(h, TPC_MPC_ERR_COMM, "RCCL is not available in this process: %s", g_rccl.why);
+        const ncclDataType_t dt = elem_bytes == 8 ? ncclFloat64 : ncclFloat32;   // (moved as bit patterns: int32 rows too)
+        ncclComm_t c = h->comm->comm;
+        GroupScope group(r);
+        RCCL_TRY(h, r, group.begin());
+        for (int i = 0; i < n_rows; ++i) {
+            char* row = (char*)rows[i];
+            if (n_total % world == 0 && !h->comm_test_ragged) {
+                RCCL_TRY(h, r, r->AllGather(row + first * es, row, (size_t)count, dt, c, s));
+            } else {
+                for (int q = 0; q < world; ++q) {
+                    int64_t qf = 0, qc = 0;
+                    shard_range(n_total, q, world, &qf, &qc);
+                    if (qc == 0) continue;
+                    RCCL_TRY(h, r, r->Broadcast(row + qf * es, row + qf * es, (size_t)qc, dt, q, c, s));
+                }
+            }
+        }
+        RCCL_TRY(h, r, group.end());
+        return order.end();
+    });
+}
+
 }  // extern "C"

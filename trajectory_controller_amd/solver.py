@@ -280,6 +280,31 @@ class MpcSolver:
         self.last_flags = flags.value
         return (front, rear, iters) if want_iters else (front, rear)
 
+    def shard_range(self, n_total: int):
+        """(first, count) of this rank's contiguous block of a batch of n_total (tpc_mpc_shard_range)."""
+        first, count = C.c_int64(), C.c_int64()
+        self._lib.tpc_mpc_shard_range(int(n_total), self.rank, self.world, C.byref(first), C.byref(count))
+        return first.value, count.value
+
+    def gather_shards(self, n_total: int, *rows):
+        """The exchange by itself, for any other entry a host shards (mixed horizons, follow, rollout): `rows` are FULL-size
+        1-D CUDA tensors (or the rows of 2-D ones) of n_total elements of 4 or 8 bytes each, of which this rank has written
+        its block [first, first + count) -- afterwards every rank holds all of every row (tpc_mpc_gather_shards)."""
+        import torch
+        flat = []
+        for t in rows:
+            if not (t.is_cuda and t.is_contiguous() and t.shape[-1] == n_total and t.element_size() in (4, 8)):
+                raise ValueError("rows must be contiguous CUDA tensors whose last dimension is n_total, 4- or 8-byte elements")
+            flat.extend(t.reshape(-1, n_total).unbind(0))
+        if not flat:
+            return
+        es = flat[0].element_size()
+        if any(r.element_size() != es for r in flat):
+            raise ValueError("one call exchanges rows of one element size")
+        table = (C.c_void_p * len(flat))(*[r.data_ptr() for r in flat])
+        stream = torch.cuda.current_stream(flat[0].device).cuda_stream
+        self._check(self._lib.tpc_mpc_gather_shards(self._h, int(n_total), table, len(flat), es, C.c_void_p(stream)))
+
     def solve_batch_general_sharded(self, A, B, Cc, Q, R, lower, upper, x0, targets, inputs: Optional[int] = None,
                                     want_iters: bool = False, **over):
         """The general form sharded (tpc_mpc_solve_batch_general_sharded): FULL-size component-major CUDA tensors

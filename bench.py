@@ -75,6 +75,8 @@ def parse():
     ap.add_argument("--no-config2", action="store_true", help="skip the BASELINE config 2 leg (4 096 x N=10, WAVE)")
     ap.add_argument("--no-bit-exact", action="store_true", help="skip the bit-exact LANE family leg")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE config 5 leg (65 536 mixed horizons)")
+    ap.add_argument("--no-config4", action="store_true",
+                    help="skip the leg that solves BASELINE config 4's whole batch (2 097 152 x N=20, fp32) on this one GPU")
     ap.add_argument("--no-mid", action="store_true", help="skip the mid-size batch leg (16 384 x N=20 through AUTO)")
     ap.add_argument("--allow-fallback-gather", action="store_true",
                     help="N > 1 only: let the run continue with a torch.distributed gather when the library's RCCL path "
@@ -543,6 +545,32 @@ def main():
             c5["solves_per_s_f64"] = len(hz) / (c5["f64"] * 1e-3)
             c5["solves_per_s_f64_fast_capped"] = len(hz) / (c5["f64_fast_capped"] * 1e-3)
             out["config5"] = c5
+        if world == 1 and not a.no_config4 and a.dtype == "f64" and n == 262144 and H == 20:
+            # BASELINE config 4's workload beside the headline: its WHOLE batch -- 2 097 152 trajectories, N=20, fp32 as
+            # written -- on this ONE GPU.  Not a scaling number (that is `--gpus 8`, eight of these blocks side by side plus
+            # the all-gather of 2 x 8 MiB per rank): what the eight ranks' arithmetic costs when one card does all of it.
+            n4 = 8 * n
+            c4 = [torch.from_numpy(x).to(dev, dtype=torch.float32) for x in compact_inputs(20, n4)]
+            with MpcSolver(horizon=20, device=local_rank, dtype="f32", algo=a.algo) as s4:
+                s4.set_profiling(True)
+                s4.reserve(n4)
+                f4, r4 = torch.empty_like(c4[0]), torch.empty_like(c4[0])
+                for _ in range(2):
+                    s4.solve_batch_compact(*c4, out=(f4, r4), want_flags=False)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    s4.solve_batch_compact(*c4, out=(f4, r4), want_flags=False)
+                torch.cuda.synchronize()
+                d4 = (time.perf_counter() - t1) / 5
+                q1, q2, q_algo = s4.last_kernel_times()
+            out["config4_one_gpu"] = {"workload": "batch 2097152 (config 4's whole batch), N=20, fp32, ONE GPU", "value": n4 / d4,
+                                      "unit": "solves/s", "ms_per_step": d4 * 1e3,
+                                      "algo": {1: "wave", 2: "lane", 3: "lane_fma", 4: "group"}.get(q_algo, str(q_algo)),
+                                      "kernel_ms": {"first": q1, "second": q2},
+                                      "first_block_identical_to_fp32_leg": (bool(torch.equal(f4[:n], f32) and torch.equal(r4[:n], r32))
+                                                                            if "fp32" in out else None)}
+            del c4, f4, r4
         print(json.dumps(out), flush=True)
     for sv in solvers:
         sv.close()

@@ -339,6 +339,56 @@ def test_full_size_properties(torch_cuda, algo):
     assert 950 < it.mean() < 1100
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_config4_total_batch_on_one_gpu(torch_cuda, dtype):
+    """BASELINE config 4's WHOLE batch -- 2 097 152 trajectories, N=20, fp32 as written and fp64 -- on one GPU, and its
+    eight rank blocks the way tpc_mpc_solve_batch_compact_sharded solves them (rank r: instances [r n, (r+1) n) into its
+    slot of full-size outputs; the RCCL exchange, which this box cannot run at world 8, moves finished slots and
+    changes no value).  Size-independent properties: within one kernel family every block's slot equals the whole
+    solve's slice bit for bit (a result does not depend on which batch, queue position or rank an instance is solved
+    in) -- fp64 under AUTO, which takes LANE_FMA at both sizes, fp32 with LANE_FMA named (AUTO takes GROUP for a
+    262 144-instance fp32 block and LANE_FMA for the whole: the same arithmetic in another association, held to the
+    fp32 tolerance statement below); fp64: the first 1024 instances are the real-dlib fixture within 1e-9; outputs
+    obey the bounds; iteration counts are dlib's statistics."""
+    from trajectory_controller_amd.synth import compact_inputs
+    torch = torch_cuda
+    H, world, n = 20, 8, 262144
+    total = world * n
+    tdt = torch.float32 if dtype == "f32" else torch.float64
+    tv, ty, tp = _dev(torch, *compact_inputs(H, total), dtype=tdt)
+
+    def whole_and_blocks(algo):
+        with _solver(H, algo, dtype=dtype) as s:
+            f, r, it = s.solve_batch_compact(tv, ty, tp, want_iters=True)
+            assert s.last_flags & 1 == 0
+            f_all, r_all = torch.full_like(f, float("nan")), torch.full_like(r, float("nan"))
+            for rank in range(world):
+                lo = rank * n
+                # (the per-rank inputs of bench.py --gpus 8: compact_inputs(H, n, first=rank * n) is this slice)
+                s.solve_batch_compact(tv[lo:lo + n], ty[lo:lo + n], tp[lo:lo + n], out=(f_all[lo:lo + n], r_all[lo:lo + n]))
+            torch.cuda.synchronize()
+        return f, r, it, f_all, r_all
+
+    f, r, it, f_all, r_all = whole_and_blocks("auto" if dtype == "f64" else "lane_fma")
+    assert torch.equal(f, f_all) and torch.equal(r, r_all)
+    amax = 22 * np.pi / 180
+    assert float(f.abs().max()) <= amax * (1 + 1e-6) and float(r.abs().max()) <= amax * (1 + 1e-6)
+    it = it.cpu().numpy()
+    assert it.min() >= 0 and it.max() <= 10000 and 950 < it.mean() < 1100
+    if dtype == "f64":
+        g = load_golden("compact_H20.npz")
+        assert np.abs(f[:1024].cpu().numpy() - g["front"]).max() <= 1e-9
+        assert np.abs(r[:1024].cpu().numpy() - g["rear"]).max() <= 1e-9
+    else:
+        # AUTO as a rank would run it: fp32 has no reference to be held to, so this is the tolerance statement of
+        # test_wave_fp32_vs_float_typed_oracle between two fp32 families
+        fa, ra, _, fa_all, ra_all = whole_and_blocks("auto")
+        err = torch.maximum((fa_all - f).abs(), (ra_all - r).abs()).double().cpu().numpy()
+        print(f"fp32 AUTO blocks vs LANE_FMA: median {np.median(err):.2e} p99 {np.quantile(err, 0.99):.2e} max {err.max():.2e}")
+        assert np.median(err) <= 2e-5 and np.quantile(err, 0.99) <= 5e-3
+        assert float(fa_all.abs().max()) <= amax * (1 + 1e-6) and float(ra_all.abs().max()) <= amax * (1 + 1e-6)
+
+
 def test_config2_all_families_vs_oracle(torch_cuda, oracle):
     """BASELINE config 2 at its exact size -- batch 4096, N=10, fp64 -- every kernel family against the ORACLE:
     identical iteration counts; LANE bit for bit, WAVE (what AUTO runs here) and LANE_FMA within 1e-9."""

@@ -72,6 +72,9 @@ TPC_DEV unsigned long long ballot_b(bool pred) { return __builtin_amdgcn_ballot_
 #ifndef TPC_GROUP_OCC
 #define TPC_GROUP_OCC 0
 #endif
+#ifndef TPC_GROUP_OCC_F32
+#define TPC_GROUP_OCC_F32 2
+#endif
 template <typename T, int H, int G> struct GroupPlan {
     static_assert(G == 2 || G == 4 || G == 8 || G == 16, "a group is 2, 4, 8 or 16 lanes of one DPP row");
     static constexpr int L = (H + G - 1) / G;  // horizon steps per lane
@@ -84,11 +87,15 @@ template <typename T, int H, int G> struct GroupPlan {
     // scan steps after the initial shift by one lane: the exclusive prefix of lane p spans up to G - 1 lanes, and each
     // step doubles what a lane's partial result spans (1 after the shift)
     static constexpr int steps = G == 2 ? 0 : (G == 4 ? 2 : (G == 8 ? 3 : 4));
-    // ONE wavefront per SIMD, like LANE_FMA: the family's place is the batch that cannot fill the chip's lanes, where
+    // fp64: ONE wavefront per SIMD, like LANE_FMA: the family's place is the batch that cannot fill the chip's lanes, where
     // what counts is how fast a lone wavefront iterates -- measured (N = 20, G = 4, 16 384 / 32 768 / 65 536 instances,
     // persistent grids of one / two / three wavefronts per SIMD): 1.65 / 1.73 / 2.42 ms against 1.64 / 1.82 / 2.50 and
-    // 1.63 / 1.87 / 2.87 -- so the kernel is built with the whole register file and no scratch
-    static constexpr int occ = TPC_GROUP_OCC > 0 ? TPC_GROUP_OCC : 1;
+    // 1.63 / 1.87 / 2.87 -- so the kernel is built with the whole register file and no scratch.
+    // fp32: built for TWO (256 registers each; a second wavefront per SIMD brings an fp32 instruction from ~2.0 to ~1.2-1.5 ns
+    // where it brings an fp64 one from 2.36 to 2.1), and the launcher pairs them only from the batch size at which the
+    // grid's throughput, not the longest instance, sets the time (auto_table.h, pair_from): profiles/r04_group_f32_occ.txt --
+    // 262 144 x N = 20: G = 2 6.24 -> 4.56 ms, N = 40: G = 4 53.0 -> 34.3; three and four per SIMD spill at N >= 30.
+    static constexpr int occ = TPC_GROUP_OCC > 0 ? TPC_GROUP_OCC : (sizeof(T) == 4 ? TPC_GROUP_OCC_F32 : 1);
 };
 #ifdef TPC_GROUP_REFILL_BATCH
 template <int G> struct GroupRefillBatch { static constexpr int value = TPC_GROUP_REFILL_BATCH; };
@@ -97,7 +104,10 @@ template <int G> struct GroupRefillBatch { static constexpr int value = TPC_GROU
 template <int G> struct GroupRefillBatch { static constexpr int value = G >= 8 ? 1 : 2; };
 #endif
 
-template <typename T, int H, int G, bool EQB>
+// MOVED (fp32 only; fp64 always reads its stop test off the projected step): true = min(|g df|, |x - x_new|) where the
+// coordinate-descent kernel's second screen (ub::moved_stop_ok, stats[2] bit 1) allows it, false = dlib's mask as
+// arithmetic for the batches it refuses -- the two builds of ub_pg_kernel's MODE 2 / MODE 1, launched back to back.
+template <typename T, int H, int G, bool EQB, bool MOVED = true>
 __global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel(
     CompactArgs g, Knobs kn, const T* __restrict__ recs, const uint32_t* __restrict__ order,
     uint32_t* __restrict__ ticket, unsigned long long* __restrict__ stats, const uint32_t* __restrict__ queue_len) {
@@ -106,7 +116,12 @@ __global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel
     constexpr bool D64 = sizeof(T) == 8;
     const int64_t n_queue = (int64_t)__builtin_nontemporal_load(queue_len);
     // the screened stop test only: a batch the coordinate-descent kernel's screen refused is LANE_FMA's exact build's
-    if ((__builtin_nontemporal_load(&stats[2]) & 1ull) != 0ull) return;   // (bit 1 is LANE_FMA's fp32 choice of stop test: not ours)
+    static_assert(MOVED || sizeof(T) == 4, "the mask-as-arithmetic build is fp32's");
+    {
+        const unsigned long long sel = __builtin_nontemporal_load(&stats[2]);
+        if ((sel & 1ull) != 0ull) return;
+        if constexpr (!D64) { if (((sel & 2ull) != 0ull) == MOVED) return; }   // (bit 1: a step may vanish in fp32 rounding -- the mask build's batch)
+    }
     if (n_queue <= 0) return;
 
     const int lane = threadIdx.x;
@@ -314,7 +329,7 @@ __global__ __launch_bounds__(64, (GroupPlan<T, H, G>::occ)) void group_pg_kernel
                     if (l >= DL0) dd = dd * live[l - DL0];
                     const T vn = m.template project<true>(ub::fma_(-il[j], dd, xx), j);          // mpc.h:342
                     T& acc = j == 0 ? acc0 : acc1;
-                    if constexpr (D64) {
+                    if constexpr (D64 || MOVED) {
                         acc = tmax(acc, tmin(tabs(dd), tabs(xx - vn)));
                     } else {
                         const T g_lo = m.gap_lo(j, xx, huge), g_hi = m.gap_hi(j, xx, huge);

@@ -41,20 +41,28 @@ constexpr bool group_built(int H, int G) {
     return H == 10 ? (G == 2 || G == 4) : (H == 20 || H == 30 || H == 40) && (G == 2 || G == 4 || G == 8);
 }
 
-template <typename T, int G, bool EQB>
+template <typename T, int G, bool EQB, bool MOVED = true>
 hipError_t pg(const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
     if constexpr (!group_built(kH, G)) {
         return hipErrorInvalidValue;
     } else {
-        constexpr int NG = GroupPlan<T, kH, G>::NG;
+        constexpr int NG = GroupPlan<T, kH, G>::NG, OCC = GroupPlan<T, kH, G>::occ;
         const int64_t need = (a.n + NG - 1) / NG;
-        // persistent grid: one wavefront per SIMD (the kernel is built for that, GroupPlan::occ)
-        int cap = device_cus() * 4 * GroupPlan<T, kH, G>::occ;
-        if (ws.max_waves > 0 && ws.max_waves < cap) cap = ws.max_waves;   // (experiments: tpc_mpc_x_set_group_share)
-        hipLaunchKernelGGL((group_pg_kernel<T, kH, G, EQB>), dim3((unsigned)(need < cap ? need : cap)), dim3(kWave), 0, s, a, k,
+        // persistent grid: one wavefront per SIMD; as many as the kernel is built for (fp32: two) from the batch size at
+        // which AUTO's table says the pair is ahead (Workspace::group_pair).  An explicit share of the chip
+        // (tpc_mpc_x_set_group_share) is taken as given, up to what fits.
+        int cap = device_cus() * 4 * (ws.group_pair ? OCC : 1);
+        if (ws.max_waves > 0) cap = ws.max_waves < device_cus() * 4 * OCC ? ws.max_waves : device_cus() * 4 * OCC;
+        hipLaunchKernelGGL((group_pg_kernel<T, kH, G, EQB, MOVED>), dim3((unsigned)(need < cap ? need : cap)), dim3(kWave), 0, s, a, k,
                            (const T*)ws.state, (const uint32_t*)ws.order, ws.ticket, ws.stats, order_queue_len(ws.sort_temp));
         return hipGetLastError();
     }
+}
+// fp32: both stop-test builds, back to back -- the coordinate-descent kernel's screens picked one (the other returns at its first load)
+template <int G>
+hipError_t pg_f32(const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
+    const hipError_t e = pg<float, G, true, true>(a, k, ws, s);
+    return e != hipSuccess ? e : pg<float, G, true, false>(a, k, ws, s);
 }
 
 template <typename T, bool EQB>
@@ -77,7 +85,7 @@ hipError_t TPC_CAT(group_compact_h, TPC_GROUP_H)(int dtype, int equal_bounds, in
     hipError_t e = TPC_CAT(ub_phase1_h, TPC_GROUP_H)(dtype, equal_bounds, a, k, ws, s);
     if (e != hipSuccess) return e;
     if (dtype == 0) e = equal_bounds ? pg_any<double, true>(G, a, k, ws, s) : pg_any<double, false>(G, a, k, ws, s);
-    else e = pg_any<float, true>(G, a, k, ws, s);
+    else e = G == 2 ? pg_f32<2>(a, k, ws, s) : (G == 4 ? pg_f32<4>(a, k, ws, s) : (G == 8 ? pg_f32<8>(a, k, ws, s) : hipErrorInvalidValue));
     if (e != hipSuccess) return e;
     // a batch the screen of the select-free stop test refused: LANE_FMA's exact build, on the same records
     e = TPC_CAT(ub_exact_h, TPC_GROUP_H)(dtype, equal_bounds, a, k, ws, s);

@@ -68,7 +68,8 @@ struct Workspace {
     hipEvent_t* ev;
     int wave_group = 0;   // TPC_MPC_OPT_WAVE_GROUP: 0 auto, 1 / 2 / 4 instances per wavefront
     int group_lanes = 0;  // GROUP: lanes per instance (2 / 4 / 8) for this horizon
-    int max_waves = 0;    // GROUP: size of the persistent grid (0: one wavefront per SIMD of the device)
+    int max_waves = 0;    // GROUP: size of the persistent grid (0: one wavefront per SIMD of the device, or per group_pair)
+    bool group_pair = false;   // GROUP: as many wavefronts per SIMD as the kernel is built for (fp32: two) -- the batch is past auto_table.h's pair_from
     int64_t lanex_below = -1;   // LANE, compact form, fp64: batches below this take the G-lanes-per-instance kernel (mpc_lanex.h); -1: the measured default, 0: never
     int cu_count = 0;     // of the device (scales measured crossovers); 0: unknown, take 256
 };

@@ -105,6 +105,17 @@ int group_lanes(const tpc_mpc_context* h, int H, int dtype = 0, int64_t n = 0, i
     return H == 40 ? 8 : (H == 10 ? 2 : 4);
 }
 
+// GROUP, kernels built for more than one wavefront per SIMD (fp32, compact form): does a batch of n take the full grid?
+// From auto_table.h's pair_from: below it the longest instance sets the time and a lone wavefront iterates faster.
+bool group_pair(const tpc_mpc_context* h, int H, int dtype, int64_t n, int form) {
+    for (const AutoRow& r : kAutoTable) {
+        if (r.form != form || r.dtype != dtype || r.horizon != H) continue;
+        const int64_t at = r.pair_from * h->cu_count / 256 < r.pair_from ? r.pair_from * h->cu_count / 256 : r.pair_from;
+        return n >= at;
+    }
+    return false;
+}
+
 // LANE needs enough instances to give every SIMD a full wavefront; below that WAVE's
 // one-wavefront-per-instance launch finishes sooner.  Measured crossovers on MI355X
 // (scripts/crossover.py, fp64, compact form, round 2 kernels; the chip has 65 536 LANE slots):
@@ -312,6 +323,7 @@ int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n,
     ws->wave_group = h->opt_wave_group;
     ws->group_lanes = group_lanes(h, H, dtype, n, form);
     ws->max_waves = h->max_waves;
+    ws->group_pair = group_pair(h, H, dtype, n, form);
     ws->lanex_below = h->opt_lanex_below;
     ws->cu_count = h->cu_count;
     h->ev_valid = h->profiling;

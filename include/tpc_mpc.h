@@ -95,7 +95,9 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
  *          lane of the chip an instance.  LANE_FMA's arithmetic with the horizon cut into G chunks: each lane runs
  *          its chunk's part of the two recurrences of mpc.h:275-281 in registers, and the chunks are joined by an
  *          exclusive scan over the lanes of the group (the recurrences are affine with a constant matrix, so joining
- *          costs log2 G steps of DPP moves and fused multiply-adds).  Persistent wavefronts, one per SIMD, groups
+ *          costs log2 G steps of DPP moves and fused multiply-adds).  Persistent wavefronts, one per SIMD (fp32: two from
+ *          the batch size at which that is faster -- a second resident wavefront nearly doubles a SIMD's fp32 issue rate
+ *          and adds a tenth to its fp64 one), groups
  *          refilled from LANE_FMA's longest-first queue; the coordinate-descent phase and the records are LANE_FMA's
  *          own.  Compact form, N = 10, 20, 30, 40 (chunks padded where G does not divide N), the requests LANE_FMA
  *          takes; anything else runs LANE_FMA / LANE.  Same statement as LANE_FMA: max |du| vs dlib ~2e-13 at N = 20,
@@ -110,7 +112,8 @@ typedef enum tpc_mpc_memory { TPC_MPC_HOST = 0, TPC_MPC_DEVICE = 1 } tpc_mpc_mem
  *          possible.  Family: WAVE below a crossover measured per dtype and horizon, then GROUP with 8, 4, 2 lanes
  *          per instance, then LANE_FMA (csrc/auto_table.h, generated by scripts/measure_crossover.py on a 256-CU
  *          part and scaled by the CU count: at N = 20 in fp64 WAVE below 7 094 instances, GROUP up to 160 530,
- *          LANE_FMA beyond); LANE where none of them takes the request.  Guarantee (fp64, the specialised horizons,
+ *          LANE_FMA beyond -- in fp32 GROUP up to 321 060; at N = 30 and 40 GROUP is never overtaken, in either dtype and
+ *          either form); LANE where none of them takes the request.  Guarantee (fp64, the specialised horizons,
  *          cold starts -- every compact entry point and the general form without controls_inout / v_inout): an
  *          instance that ends on max_iter has not converged, and over thousands of iterations of an ill-conditioned
  *          problem the tolerance families' rounding differences grow (2.3e-5 seen under adversarial parameters), so

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Every rocprofv3 summary DESIGN.md / profiles/README.md quote (run from the repo root, through gpurun):
-#   bash scripts/profile_all.sh r04 [a|b|c|all]   -> gpurun_out/r04_<tag>_{kernel_stats,pmc}.csv  (copy into profiles/)
+#   bash scripts/profile_all.sh r04 [a|b|c|d|e|all]   -> gpurun_out/r04_<tag>_{kernel_stats,pmc}.csv  (copy into profiles/)
 # Each tag = scripts/profile.sh: one --kernel-trace --stats run, then separate --pmc runs.  Three parts, because one
 # gpurun call is limited to 20 minutes:  a = the bench.py workloads, b = long horizons / general form / follow,
 # c = the GROUP family (round 4) and config 5, d = GROUP at 262 144 x N = 30 / 40 and for the general form, the bit-exact family G lanes per instance.
@@ -40,6 +40,10 @@ $P ${R}_groupg_h40     python3 scripts/general_rate.py 2 40 group 16384 >> $LOG 
 $P ${R}_groupg_h20     python3 scripts/general_rate.py 2 20 group 16384 >> $LOG 2>&1
 $P ${R}_lanex_h40      python3 scripts/lane_h.py f64 40 16384 lane >> $LOG 2>&1
 $P ${R}_lanex_h20      python3 scripts/lane_h.py f64 20 16384 lane >> $LOG 2>&1
+fi
+if [ $PART = e ] || [ $PART = all ]; then   # fp32 GROUP, two wavefronts per SIMD (what AUTO runs for a 262 144-instance fp32 batch at N = 20 / 40)
+$P ${R}_group_f32_h20_256k python3 scripts/lane_h.py f32 20 262144 group >> $LOG 2>&1
+$P ${R}_group_f32_h40_256k python3 scripts/lane_h.py f32 40 262144 group >> $LOG 2>&1
 fi
 ls gpurun_out/${R}_*_kernel_stats.csv
 python3 -c "import hashlib;print(hashlib.sha256(open('trajectory_controller_amd/lib/libtpc_mpc.so','rb').read()).hexdigest())"

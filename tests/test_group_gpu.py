@@ -184,6 +184,38 @@ def test_group_fp32_vs_float_typed_oracle(torch_cuda, oracle32, H, G, n):
     assert same >= 0.4 and same_l >= 0.4 and np.median(err) <= 1e-4
 
 
+@pytest.mark.parametrize("H,G,n", [(10, 2, 4096), (10, 4, 2000), (20, 2, 3000), (20, 4, 3001), (20, 8, 1500)])
+def test_group_fp32_stop_test_builds_agree(torch_cuda, H, G, n):
+    """fp32 GROUP has two builds of its kernel (group_pg_kernel's MOVED): the stop test read off the projected step where
+    every instance of the batch passes ub::moved_stop_ok, dlib's mask as arithmetic otherwise -- LANE_FMA's MODE 2 / MODE 1.
+    Where the screen holds the two take the same decisions on the same values: a batch inside the screen, and the same
+    batch with ONE instance beyond it appended (which sends the whole batch to the mask build), give every shared
+    instance the same bits and iteration counts.  Also at both grid sizes (one / two wavefronts per SIMD): a result does
+    not depend on how many wavefronts share a SIMD."""
+    from trajectory_controller_amd import capi
+    from trajectory_controller_amd.synth import compact_inputs
+    torch = torch_cuda
+    v, dy, dphi = (a.astype(np.float32) for a in compact_inputs(H, n, first=410000 + H))
+    v = (v * np.float32(0.75)).astype(np.float32)            # <= 3 m/s: inside the screen at N = 10 and 20
+    v2, dy2, dphi2 = (np.concatenate([a, a[:1]]) for a in (v, dy, dphi))
+    v2[-1] = np.float32(50.0)                                 # lambda ~ v^2: far beyond it (the edge fixture's fastest speed)
+    with _solver(H, G, dtype="f32") as s:
+        f, r, it = _run(torch, s, v, dy, dphi)
+        fm, rm, itm = _run(torch, s, v2, dy2, dphi2)
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        out = []
+        for per_simd in (1, 2):
+            s._check(s._lib.tpc_mpc_x_set_group_share(s._h, per_simd * 4 * cus, 0))
+            out.append(_run(torch, s, v, dy, dphi))
+    # (the batch inside the screen really ran the other build: LANE_FMA's own two builds are told apart the same way in
+    # tests/test_ub_gpu.py::test_ub_f32_stop_test_builds -- here the statement is that nothing tells them apart)
+    assert np.array_equal(it, itm[:n]) and np.array_equal(f, fm[:n]) and np.array_equal(r, rm[:n])
+    for fo, ro, ito in out:
+        assert np.array_equal(it, ito) and np.array_equal(f, fo) and np.array_equal(r, ro)
+    A = np.float32(22.0 * np.pi / 180.0)
+    assert np.isfinite(fm).all() and np.abs(fm).max() <= A and np.abs(rm).max() <= A
+
+
 def test_group_falls_back_where_it_has_no_kernel(torch_cuda, oracle):
     """An explicit GROUP request at a horizon without group kernels (N = 4, 5), or with bounds the unit box cannot take
     (a pinned input), runs the one-lane families -- and says so through last_kernel_times."""

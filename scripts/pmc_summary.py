@@ -17,6 +17,10 @@ def short(name):
         args = head[len(base):]
         last = args.rstrip(">").rstrip().split(",")[-1].strip()   # bool FAST, or ub_pg_kernel's int MODE (0 exact, 1 mask, 2 moved)
         base += "<fast>" if last in ("true", "2") else ("<mask>" if last == "1" else "<exact>")
+    if base.endswith("group_pg_kernel") and head[len(base):].lstrip("<").startswith("float"):
+        # fp32 GROUP: two builds of the stop test (MOVED = the last argument), launched back to back; one returns at once
+        last = head[len(base):].rstrip(">").rstrip().split(",")[-1].strip()
+        base += "<f32,moved>" if last == "true" else "<f32,mask>"
     return base
 
 # kernel trace

@@ -15,9 +15,9 @@ CONFIGS = {   # tag -> (kernel in the csv, bench key, k, note)
     "headline": ("tpc::ub_pg_kernel<fast>", "ub_pg_kernel_f64_H20_n262144", 1, "strided record reads: k=1 (as calibrated on the LANE kernel's identical access pattern)"),
     "bitexact": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_f64_H20_n262144", 1, "strided record reads: k=1 (calibrated)"),
     # (fp32 at 262 144 x N=20 under AUTO is GROUP since the end of round 4: two lanes per instance, two wavefronts per SIMD)
-    "fp32": ("tpc::group_pg_kernel<f32,moved>", "group_pg_kernel_f32_H20_n262144", 1, "chunked record reads: k=1 (uncalibrated)"),
-    "group_f32_h20_256k": ("tpc::group_pg_kernel<f32,moved>", "group_pg_kernel_f32_H20_n262144_lane_h", 1, "the same kernel through scripts/lane_h.py: k=1 (uncalibrated)"),
-    "group_f32_h40_256k": ("tpc::group_pg_kernel<f32,mask>", "group_pg_kernel_f32_H40_n262144", 1, "chunked record reads: k=1 (uncalibrated)"),
+    "fp32": ("tpc::group_pg_kernel<f32 moved>", "group_pg_kernel_f32_H20_n262144", 1, "chunked record reads: k=1 (uncalibrated)"),
+    "group_f32_h20_256k": ("tpc::group_pg_kernel<f32 moved>", "group_pg_kernel_f32_H20_n262144_lane_h", 1, "the same kernel through scripts/lane_h.py: k=1 (uncalibrated)"),
+    "group_f32_h40_256k": ("tpc::group_pg_kernel<f32 mask>", "group_pg_kernel_f32_H40_n262144", 1, "chunked record reads: k=1 (uncalibrated)"),
     "config2": ("tpc::wave_pair_queue_kernel", "wave_kernel_f64_H10_n4096", 1, "broadcast loads of 3 scalars per wavefront + the queue order: uncalibrated, k=1"),
     "h30": ("tpc::ub_pg_kernel<fast>", "ub_pg_kernel_f64_H30_n262144", 1, "strided record reads: k=1"),
     "h40": ("tpc::ub_pg_kernel<fast>", "ub_pg_kernel_f64_H40_n262144", 1, "strided record reads: k=1"),

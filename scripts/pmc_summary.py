@@ -20,7 +20,7 @@ def short(name):
     if base.endswith("group_pg_kernel") and head[len(base):].lstrip("<").startswith("float"):
         # fp32 GROUP: two builds of the stop test (MOVED = the last argument), launched back to back; one returns at once
         last = head[len(base):].rstrip(">").rstrip().split(",")[-1].strip()
-        base += "<f32,moved>" if last == "true" else "<f32,mask>"
+        base += "<f32 moved>" if last == "true" else "<f32 mask>"
     return base
 
 # kernel trace

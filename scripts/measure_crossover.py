@@ -105,6 +105,8 @@ def derive(table, fams):
         idx = next((j for j in range(len(ladder)) if all(w in later for w in winners[j:])), len(ladder))
         if idx == 0:
             b = prev
+        elif idx == len(ladder) and len(ladder) < 2:
+            b = NEVER   # (a single size says nothing about cost per further instance: leave the leader in place)
         elif idx == len(ladder):
             n1, n0 = ladder[-1], ladder[-2]
             w = winners[-1]

@@ -163,6 +163,54 @@ def test_auto_takes_group_at_mid_size_batches(torch_cuda, oracle, H, n):
     assert np.array_equal(it[:m], oit) and max(np.abs(f[:m] - of).max(), np.abs(r[:m] - orr).max()) <= GROUP_ATOL
 
 
+@pytest.mark.parametrize("dtype,H,n,expect", [
+    ("f64", 40, 600000, GROUP),        # never overtaken at N = 30 / 40 (the table used to end at 524 288)
+    ("f64", 30, 600000, GROUP),
+    ("f64", 20, 200000, LANE_FMA),     # N = 20: the one-lane family from 160 530 on
+    ("f32", 20, 262144, GROUP),        # fp32, two wavefronts per SIMD: up to 321 060
+    ("f32", 20, 400000, LANE_FMA),
+    ("f32", 40, 600000, GROUP),
+])
+def test_auto_at_the_top_of_the_table(torch_cuda, dtype, H, n, expect):
+    """What AUTO runs past the sizes its crossovers were measured at (csrc/auto_table.h): a family that was still ahead
+    at the top of the ladder stays in place where its cost per further instance is the lower one.  The iteration cap is
+    cut to 60 so that the large batches take milliseconds (the choice of family does not depend on it), with the
+    opt-out of AUTO's second pass for capped instances set; the outputs are then the named family's, bit for bit."""
+    from trajectory_controller_amd import capi
+    from trajectory_controller_amd.synth import compact_inputs
+    torch = torch_cuda
+    tdt = torch.float32 if dtype == "f32" else torch.float64
+    tv, ty, tp = (torch.from_numpy(a).to("cuda:0", dtype=tdt) for a in compact_inputs(H, n, first=5_000_000))
+    with _solver(H, algo="auto", dtype=dtype, max_iter=60, options=capi.PARAM_FAST_CAPPED) as s:
+        s.set_profiling(True)
+        f, r = s.solve_batch_compact(tv, ty, tp)
+        torch.cuda.synchronize()
+        assert s.last_kernel_times()[2] == expect
+    with _solver(H, algo={GROUP: "group", LANE_FMA: "lane_fma"}[expect], dtype=dtype, max_iter=60, options=capi.PARAM_FAST_CAPPED) as s:
+        f2, r2 = s.solve_batch_compact(tv, ty, tp)
+        torch.cuda.synchronize()
+    assert torch.equal(f, f2) and torch.equal(r, r2)
+
+
+@pytest.mark.parametrize("H", [30, 40])
+def test_auto_general_form_large_batch_stays_with_group(torch_cuda, H):
+    """General form, N = 30 / 40: GROUP (G = 4) is never overtaken by the one-lane LANE kernels (393 216 x N = 40: 119 ms
+    against 316) -- a batch beyond the old end of the table (262 144) must not drop to them."""
+    from trajectory_controller_amd import capi
+    from trajectory_controller_amd.synth import general_inputs
+    torch = torch_cuda
+    n = 300000
+    gi = general_inputs(H, n, I=2)
+    names = ["A", "B", "C", "Q", "R", "lo", "hi", "x0", "targets"]
+    tv = [torch.from_numpy(np.ascontiguousarray(gi[k].reshape(n, -1).T)).to("cuda:0") for k in names]
+    with _solver(H, algo="auto", max_iter=60, options=capi.PARAM_FAST_CAPPED) as s:
+        s.set_profiling(True)
+        u = s.solve_batch_general(*tv, inputs=2)
+        torch.cuda.synchronize()
+        assert s.last_kernel_times()[2] == GROUP
+    assert bool(torch.isfinite(u).all())
+
+
 @pytest.mark.parametrize("H,G,n", [(10, 2, 4096), (20, 4, 3000), (40, 8, 700)])
 def test_group_fp32_vs_float_typed_oracle(torch_cuda, oracle32, H, G, n):
     """fp32 (unpinned: dlib is fp64-only): against the float-typed restatement as a tolerance statement, and against

@@ -36,3 +36,31 @@ def test_no_scratch_inside_wave_loops():
     # the listed rest is exactly the N = 40 fp64 kernels known to spill (a new name here wants a look)
     assert all("Li40E" in name and ("lane_" in name or "ub_cd_kernel" in name or "ub_pg_kernel" in name) or "lane_cd_kernel" in name
                for name, _ in bad), [name for name, _ in bad]
+
+
+def test_auto_table_matches_its_records():
+    """csrc/auto_table.h is GENERATED from the crossover records committed under profiles/ (scripts/measure_crossover.py
+    --from-record): re-derive the rows here, without a GPU, and hold the header to them -- a hand edit of the table, or a
+    record replaced without regenerating it, fails."""
+    import subprocess
+    hdr = open(os.path.join(ROOT, "trajectory_controller_amd", "csrc", "auto_table.h")).read()
+    rows = {}
+    for line in hdr.splitlines():
+        line = line.strip()
+        if line.startswith("{") and line.endswith("},"):
+            nums = [int(x) for x in line.strip("{},").split(",")]
+            rows[(nums[0], nums[1], nums[2])] = tuple(nums[3:])
+    assert len(rows) == 12 and all(len(r) == 5 for r in rows.values())
+    never = 1 << 40
+    derived = {}
+    for form, records in ((0, "profiles/r04_crossover.txt,profiles/r04_crossover_top.txt,profiles/r04_crossover_f32.txt,profiles/r04_crossover_f32_top.txt"),
+                          (1, "profiles/r04_crossover_general.txt,profiles/r04_crossover_general_top.txt")):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "measure_crossover.py"), "--from-record", records],
+                             cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        for m in re.finditer(r"=> (f64|f32) H=(\d+): WAVE (never overtaken|below \d+), GROUP 8 (never overtaken|below \d+), 4 (never overtaken|below \d+), "
+                             r"2 (never overtaken|below \d+), LANE_FMA from there(?:; GROUP grid two wavefronts per SIMD from (\d+))?", out.stdout):
+            val = lambda w: never if w.startswith("never") else int(w.split()[1])
+            derived[(form, 0 if m.group(1) == "f64" else 1, int(m.group(2)))] = (
+                val(m.group(3)), val(m.group(4)), val(m.group(5)), val(m.group(6)), int(m.group(7)) if m.group(7) else never)
+    assert derived == rows, {k: (rows.get(k), derived.get(k)) for k in set(rows) | set(derived) if rows.get(k) != derived.get(k)}

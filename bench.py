@@ -75,6 +75,7 @@ def parse():
     ap.add_argument("--no-config2", action="store_true", help="skip the BASELINE config 2 leg (4 096 x N=10, WAVE)")
     ap.add_argument("--no-bit-exact", action="store_true", help="skip the bit-exact LANE family leg")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE config 5 leg (65 536 mixed horizons)")
+    ap.add_argument("--no-config1", action="store_true", help="skip the BASELINE config 1 leg (one trajectory, N=10: solve_one latency)")
     ap.add_argument("--no-config4", action="store_true",
                     help="skip the leg that solves BASELINE config 4's whole batch (2 097 152 x N=20, fp32) on this one GPU")
     ap.add_argument("--no-mid", action="store_true", help="skip the mid-size batch leg (16 384 x N=20 through AUTO)")
@@ -545,6 +546,43 @@ def main():
             c5["solves_per_s_f64"] = len(hz) / (c5["f64"] * 1e-3)
             c5["solves_per_s_f64_fast_capped"] = len(hz) / (c5["f64_fast_capped"] * 1e-3)
             out["config5"] = c5
+        if world == 1 and not a.no_config1 and not a.no_cpu and a.dtype == "f64" and n == 262144 and H == 20:
+            # BASELINE config 1 beside the headline: ONE trajectory, N=10 -- the call the reference's cycle() makes
+            # (mpcControllerTobi -> tpc_mpc_solve_one), with a new speed in every call: on the calling thread (the host
+            # path, TPC_MPC_OPT_HOST_SOLVE_ONE), through the resident wavefront, and real dlib on one host core beside
+            # them (the checker library, after everything timed above).  Medians over 1 000 calls, Python's ctypes call
+            # included in all three (~1-2 us; examples/solve_one_latency.c measures the first two without it).
+            from oracle import bindings as ob
+            from trajectory_controller_amd import capi as _capi
+
+            def med_us(call, reps=1000):
+                ts = []
+                for i in range(reps + 50):
+                    t1 = time.perf_counter()
+                    call(1.0 + 2e-3 * i)
+                    ts.append(time.perf_counter() - t1)
+                return float(np.median(np.array(ts[50:])) * 1e6)
+            c1 = {"workload": "one trajectory, N=10, fp64: tpc_mpc_solve_one (what mpcControllerTobi calls)", "unit": "us per solve (median)",
+                  "note": "speeds 1.1 .. 3.1 m/s, target (0.1, 0.05): a single short-horizon solve is latency, not throughput -- a host core "
+                          "is as fast as the round trip to the GPU here (SURVEY.md section 7 said so); the batch entries are the product"}
+            with MpcSolver(horizon=10, device=local_rank) as so:
+                c1["resident_wavefront"] = med_us(lambda vv: so.mpc_controller_tobi(vv, 0.1, 0.05))
+                gres = so.mpc_controller_tobi(2.0, 0.1, 0.05)
+                so.set_option(_capi.OPT_HOST_SOLVE_ONE, 10)
+                c1["calling_thread"] = med_us(lambda vv: so.mpc_controller_tobi(vv, 0.1, 0.05))
+                hres = so.mpc_controller_tobi(2.0, 0.1, 0.05)
+            if os.path.exists(ob.REF_SO):
+                # (dlib: the same 1 000 speeds as one single-threaded batch call -- model build, mpc constructor, set_target
+                # and operator() per instance as in cycle() -- so that no per-call binding overhead lands on the reference)
+                ref1 = ob.DlibRef(ob.REF_SO)
+                vs = 1.0 + 2e-3 * np.arange(50, 1050)
+                ref1.solve_compact(10, vs[:64], np.full(64, 0.1), np.full(64, 0.05), nthreads=1)
+                t1 = time.perf_counter()
+                ref1.solve_compact(10, vs, np.full(vs.size, 0.1), np.full(vs.size, 0.05), nthreads=1)
+                c1["dlib_one_core"] = (time.perf_counter() - t1) / vs.size * 1e6
+                df, dr = ref1.solve_compact(10, np.array([2.0]), np.array([0.1]), np.array([0.05]), nthreads=1)
+                c1["max_abs_du_vs_dlib"] = float(max(abs(gres[0] - df[0]), abs(gres[1] - dr[0]), abs(hres[0] - df[0]), abs(hres[1] - dr[0])))
+            out["config1"] = c1
         if world == 1 and not a.no_config4 and a.dtype == "f64" and n == 262144 and H == 20:
             # BASELINE config 4's workload beside the headline: its WHOLE batch -- 2 097 152 trajectories, N=20, fp32 as
             # written -- on this ONE GPU.  Not a scaling number (that is `--gpus 8`, eight of these blocks side by side plus

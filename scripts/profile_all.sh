@@ -12,10 +12,10 @@ P="bash scripts/profile.sh"
 LOG=gpurun_out/prof_${R}_${PART}.log
 : > $LOG
 if [ $PART = a ] || [ $PART = all ]; then
-$P ${R}_headline  python3 bench.py --steps 10 --warmup 2 --no-cpu --no-fp32 --no-pipelined --no-bit-exact --no-config2 --no-config5 --no-config4 --no-mid >> $LOG 2>&1
-$P ${R}_bitexact  python3 bench.py --steps 10 --warmup 2 --algo lane --no-cpu --no-fp32 --no-pipelined --no-config2 --no-config5 --no-config4 --no-mid >> $LOG 2>&1
+$P ${R}_headline  python3 bench.py --steps 10 --warmup 2 --no-cpu --no-fp32 --no-pipelined --no-bit-exact --no-config1 --no-config2 --no-config5 --no-config4 --no-mid >> $LOG 2>&1
+$P ${R}_bitexact  python3 bench.py --steps 10 --warmup 2 --algo lane --no-cpu --no-fp32 --no-pipelined --no-config1 --no-config2 --no-config5 --no-config4 --no-mid >> $LOG 2>&1
 $P ${R}_config2   python3 bench.py --steps 20 --warmup 2 --batch 4096 --horizon 10 --algo wave --no-cpu --no-fp32 --no-pipelined >> $LOG 2>&1
-$P ${R}_fp32      python3 bench.py --steps 10 --warmup 2 --dtype f32 --no-cpu --no-pipelined --no-config2 --no-config5 --no-config4 --no-mid >> $LOG 2>&1
+$P ${R}_fp32      python3 bench.py --steps 10 --warmup 2 --dtype f32 --no-cpu --no-pipelined --no-config1 --no-config2 --no-config5 --no-config4 --no-mid >> $LOG 2>&1
 fi
 if [ $PART = b ] || [ $PART = all ]; then
 $P ${R}_h30        python3 scripts/lane_h.py f64 30 262144 lane_fma >> $LOG 2>&1

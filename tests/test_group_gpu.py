@@ -232,8 +232,9 @@ def test_group_fp32_vs_float_typed_oracle(torch_cuda, oracle32, H, G, n):
     assert same >= 0.4 and same_l >= 0.4 and np.median(err) <= 1e-4
 
 
-@pytest.mark.parametrize("H,G,n", [(10, 2, 4096), (10, 4, 2000), (20, 2, 3000), (20, 4, 3001), (20, 8, 1500)])
-def test_group_fp32_stop_test_builds_agree(torch_cuda, H, G, n):
+@pytest.mark.parametrize("H,G,n,vscale", [(10, 2, 4096, 0.75), (10, 4, 2000, 0.75), (20, 2, 3000, 0.75), (20, 4, 3001, 0.75),
+                                          (20, 8, 1500, 0.75), (30, 2, 1203, 0.3), (30, 4, 900, 0.3), (40, 4, 701, 0.25), (40, 8, 700, 0.25)])
+def test_group_fp32_stop_test_builds_agree(torch_cuda, H, G, n, vscale):
     """fp32 GROUP has two builds of its kernel (group_pg_kernel's MOVED): the stop test read off the projected step where
     every instance of the batch passes ub::moved_stop_ok, dlib's mask as arithmetic otherwise -- LANE_FMA's MODE 2 / MODE 1.
     Where the screen holds the two take the same decisions on the same values: a batch inside the screen, and the same
@@ -244,7 +245,8 @@ def test_group_fp32_stop_test_builds_agree(torch_cuda, H, G, n):
     from trajectory_controller_amd.synth import compact_inputs
     torch = torch_cuda
     v, dy, dphi = (a.astype(np.float32) for a in compact_inputs(H, n, first=410000 + H))
-    v = (v * np.float32(0.75)).astype(np.float32)            # <= 3 m/s: inside the screen at N = 10 and 20
+    # speeds inside the screen (lambda grows with v^2 and the horizon): <= 3 m/s at N = 10 / 20, <= 1.2 / 1 m/s at N = 30 / 40
+    v = (v * np.float32(vscale)).astype(np.float32)
     v2, dy2, dphi2 = (np.concatenate([a, a[:1]]) for a in (v, dy, dphi))
     v2[-1] = np.float32(50.0)                                 # lambda ~ v^2: far beyond it (the edge fixture's fastest speed)
     with _solver(H, G, dtype="f32") as s:

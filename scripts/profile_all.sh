@@ -44,6 +44,7 @@ fi
 if [ $PART = e ] || [ $PART = all ]; then   # fp32 GROUP, two wavefronts per SIMD (what AUTO runs for a 262 144-instance fp32 batch at N = 20 / 40)
 $P ${R}_group_f32_h20_256k python3 scripts/lane_h.py f32 20 262144 group >> $LOG 2>&1
 $P ${R}_group_f32_h40_256k python3 scripts/lane_h.py f32 40 262144 group >> $LOG 2>&1
+$P ${R}_f32_2m             python3 scripts/lane_h.py f32 20 2097152 lane_fma >> $LOG 2>&1   # config 4's whole batch on one GPU: LANE_FMA fp32 at its steady state
 fi
 ls gpurun_out/${R}_*_kernel_stats.csv
 python3 -c "import hashlib;print(hashlib.sha256(open('trajectory_controller_amd/lib/libtpc_mpc.so','rb').read()).hexdigest())"

@@ -11,6 +11,8 @@
 
 namespace tpc {
 
+hipError_t ub_pg_asm_launch(const CompactArgs& a, const Knobs& k, const Workspace& ws, int64_t need, hipStream_t s);
+
 namespace {
 
 constexpr int kH = TPC_UB_H;
@@ -59,6 +61,12 @@ template <typename T, bool EQB, int MODE>
 hipError_t pg_launch(const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
     constexpr int bt = kWave * UbPlan<T, kH>::occ;
     const int64_t need = (a.n + bt - 1) / bt;
+#if TPC_UB_H == 20 && !defined(TPC_UB_NO_ASM)   // (TPC_UB_NO_ASM: the compiler's loop, for A/B runs -- scripts/build_ub_variant.sh)
+    if constexpr (sizeof(T) == 8 && EQB && MODE == 2) {   // mpc_ub_asm.h: the same kernel, 538 instructions per iteration instead of 708
+        static_assert(bt == kWave, "one wavefront per workgroup");
+        return ub_pg_asm_launch(a, k, ws, need, s);   // (its own translation unit: mpc_ub_asm_inst.hip)
+    }
+#endif
     const int cap = ub_grid<TagPg<T, EQB, MODE>>(ub_pg_kernel<T, kH, EQB, MODE>, bt);
     hipLaunchKernelGGL((ub_pg_kernel<T, kH, EQB, MODE>), dim3((unsigned)(need < cap ? need : cap)), dim3(bt), 0, s, a, k,
                        (const T*)ws.state, (const uint32_t*)ws.order, ws.ticket, ws.stats, order_queue_len(ws.sort_temp));

@@ -1,118 +1,267 @@
 #!/usr/bin/env python3
-"""Generates trajectory_controller_amd/csrc/mpc_ub_pg_asm.h: the inner loop of the fp64 LANE_FMA projected-gradient
-kernel (ub_pg_kernel<double, H, EQB = true, MODE = 2>, mpc_ub.h) as ONE inline-asm statement with the registers
-assigned by hand.
+"""Generates trajectory_controller_amd/csrc/mpc_ub_pg_asm.h: the persistent projected-gradient kernel of the fp64
+LANE_FMA family at N = 20 (both inputs sharing their bounds, screened stop test: ub_pg_kernel<double, 20, true, 2> of
+mpc_ub.h) as ONE inline-asm statement -- iteration loop, stop events, refill passes and result stores -- with every
+vector register assigned by hand.
 
-Why: a lone wavefront per SIMD pays ~4 cycles for EVERY instruction it issues (scripts/probes/issue_forms.py:
-fp64 arithmetic, register moves, AGPR transfers, scalar instructions and s_nop all cost 1.72 ns and add up; an LDS
-write costs 9 such slots, an LDS read 4), and the compiler's version of this loop spends 193 of its 708
-instructions on register shuffles and control flow (78 v_accvgpr, 40 v_mov_b64, 75 scalar / mask instructions).
+Why by hand: a lone wavefront per SIMD pays ~4 cycles for EVERY instruction it issues, whatever it is (fp64
+arithmetic, register moves, AGPR transfers, scalar instructions: scripts/probes/issue_forms.py,
+profiles/r05_issue_forms*.txt), 5 when an 8-byte instruction starts on an odd dword, and the compiler's version of
+this loop spends 193 of its 708 instructions on register shuffles and control flow and sits on arbitrary addresses.
 
-The arithmetic is that of csrc/mpc_ub_model.h operation for operation (the CPU model the GPU tests hold the kernel
-to bit for bit); only where values live is decided here:
+The arithmetic is that of csrc/mpc_ub_model.h operation for operation (the CPU model the GPU tests hold the kernel to
+bit for bit); where values live is decided in scripts/ubasm.py (the iteration) and here (everything around it):
 
-  * x (2H values) in place; the forward pass (Z, Y per step) and dlib's momentum v share TWO register pairs per step
-    that swap roles every iteration: the pair that held (Z[i], Y[i]) is dead once the backward sweep has consumed it
-    and receives the new v[i]; the pair that held the old v[i] is dead once the momentum difference is formed and
-    receives (Z[i], Y[i]) in the next forward pass.  The loop is unrolled twice (halves A and B) so that no value is
-    ever copied; a loop exit after half A moves v back to its home pairs (once per exit, not per iteration).
-  * what does not fit the 256 VGPRs -- v of the last NA steps -- lives in AGPRs (2 + 2 transfers per value and
-    iteration: cheaper than LDS for a lone wavefront).
-  * the stop test (mpc.h:310-311) is evaluated BEFORE step 0's momentum update, and that update runs under an EXEC
-    mask that leaves out the lanes that stop: their x[0], x[1] are dlib's answer (the controls before the update,
-    mpc.h:311 `break`), so no copy of x[0], x[1] is kept.
-  * the iteration count is wave-uniform (SGPR), the cap (mpc.h:271) a count-down to the smallest remaining budget
-    of the wavefront's lanes.
+  * the stop test (mpc.h:310-311) is evaluated BEFORE step 0's momentum update, which runs under an EXEC mask that
+    leaves out the lanes that stop: their x[0], x[1] are dlib's answer (the controls before the update), stored at once
+    by the stop block; the loop goes on until a refill pass is due (BATCH lanes wait) or no lane has work;
+  * the iteration count is wave-uniform (SGPR count-down to the earliest cap of the wavefront's lanes, mpc.h:271); a
+    lane's own count is that plus a per-lane base fixed at refill;
+  * a refill pass takes its model scalars and step constants from the instance's record, where the coordinate-descent
+    kernel left them (same operations, same bits as recomputing them: mpc_ub.h), so it contains no division.
 
-    python scripts/gen_ub_pg_asm.py > trajectory_controller_amd/csrc/mpc_ub_pg_asm.h
+    python scripts/gen_ub_pg_asm.py [NA] > trajectory_controller_amd/csrc/mpc_ub_pg_asm.h
 """
-import sys
-
 import os
+import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import ubasm
 
 H = 20
-NA = int(sys.argv[1]) if len(sys.argv) > 1 else 4            # steps H-NA .. H-1 keep v in AGPRs
-BATCH = 3         # lanes that must wait before a refill pass is due (UbRefillBatch<20>)
-P = ubasm.Plan(H=H, NA=NA, batch=BATCH)
-NREG, BASE = P.NREG, P.BASE
-X, V, Wz, Wy, t0, t1 = P.X, P.V, P.Wz, P.Wy, P.t0, P.t1
+NA = int(sys.argv[1]) if len(sys.argv) > 1 else 4   # steps H-NA .. H-1 keep v in AGPRs
+BATCH = 3                                            # lanes that must wait before a refill pass is due (UbRefillBatch<20>)
+RL_BYTES = 400                                       # LaneRec<double, 20>::kLen * 8
+P = ubasm.Plan(H=H, NA=NA, batch=BATCH, all_hard=True)
+NREG = P.NREG
+X, V, Wz, Wy, t0, t1, n0, n1, acc, C = P.X, P.V, P.Wz, P.Wy, P.t0, P.t1, P.n0, P.n1, P.acc, P.C
+assert P.top <= 252
+VK, VBASE, VCAP, VTMP = "v252", "v253", "v254", "v255"   # instance index, iteration-count base, cap (wave iteration), scratch
+# AGPRs: v of the AGPR steps, z0
+AG = {}
+_n = 0
+for q in range(2 * NREG, 2 * H):
+    AG[f"av{q}lo"], AG[f"av{q}hi"] = f"a{_n}", f"a{_n + 1}"; _n += 2
+AG["z0lo"], AG["z0hi"] = f"a{_n}", f"a{_n + 1}"; _n += 2
+N_AGPR = _n
+P.A = AG
+P.S = {n: f"%[{n}]" for n in ("sgq0", "sgq1", "sgrs0", "sgrs1", "slo1", "sgeps", "shave", "sleft")}
+P.S["sexec"] = "-1"   # every lane of the wavefront is live in this kernel
+W0 = int(Wz[0].lo[1:])
 
 
-def forward(half): return P.forward(half)
+def scratch(j):
+    """a pair of the W region (free outside the iteration loop)"""
+    return ubasm.hard(W0 + 2 * j)
 
 
-def backward(half, exit_label, loop_label, stop_label):
-    tail = [f"s_cbranch_vccnz {stop_label}",                 # (does not touch the count-down's SCC)
-            f"s_cbranch_scc1 {exit_label}"]
-    if half == "B":
-        tail += [f"s_branch {loop_label}"]
-    return P.backward(half, tail)
+def publish(which, it_expr):
+    """stores the controls of the lanes in EXEC: front[k] = control(0, x[0]), rear[k] = control(1, x[1]) (Unit::control:
+    the bounds and the untouched start point come out exactly), iters[k] = it_expr + the lane's base; `which`: 'x' = from
+    x[0], x[1]; 'zero' = 0, 0 (non-finite inputs).  Uses t0, t1, acc, VTMP, vcc, stmp."""
+    o = [f"v_lshlrev_b32 {VTMP}, 3, {VK}"]
+    if which == "zero":
+        o += [f"v_mov_b64 {t0}, 0", f"v_mov_b64 {t1}, 0"]
+    else:
+        o += ["s_mov_b64 %[stmp], exec"]
+        for j, (xx, tt) in enumerate(((X[0], t0), (X[1], t1))):
+            o += [f"v_mov_b64 {tt}, %[slo{j}]",
+                  f"v_fma_f64 {tt}, %[ss{j}], {xx}, {tt}",                 # fma(s, x, lo)
+                  f"v_cmp_eq_f64_e64 vcc, {xx}, %[sxz{j}]", "s_and_b64 exec, %[stmp], vcc", f"v_mov_b64 {tt}, 0",
+                  f"v_cmp_eq_f64_e64 vcc, {xx}, 1.0", "s_and_b64 exec, %[stmp], vcc", f"v_mov_b64 {tt}, %[shi{j}]",
+                  "s_mov_b64 exec, %[stmp]"]
+    o += [f"global_store_dwordx2 {VTMP}, {t0}, %[pfront]", f"global_store_dwordx2 {VTMP}, {t1}, %[prear]",
+          "s_cmp_eq_u64 %[piters], 0", "s_cbranch_scc1 1f",
+          f"v_lshlrev_b32 {VTMP}, 2, {VK}", f"v_add_u32 {acc.lo}, {it_expr}, {VBASE}",
+          f"global_store_dword {VTMP}, {acc.lo}, %[piters]", "1:"]
+    return o
+
+
+def stop_block(cont_label, exit_label):
+    """lanes whose stop test fired (vcc): store their answer -- x[0], x[1] before this iteration's update; iteration
+    count = base + wave iterations - 1 --, take them out of `have`; go on unless a refill pass is due, no lane has work
+    left, or the cap fell in the same iteration"""
+    o = ["s_cselect_b32 %[scapf], 1, 0",                      # cap pending (SCC of the count-down)
+         "s_mov_b64 %[sstop], vcc",
+         "s_mov_b64 exec, vcc",
+         "s_sub_u32 %[sa], %[scap], %[sleft]", "s_sub_u32 %[sa], %[sa], 2"]   # wave iterations run (cap - 1 - left), less one
+    o += publish("x", "%[sa]")
+    o += ["s_mov_b64 exec, -1",
+          "s_andn2_b64 %[shave], %[shave], %[sstop]",
+          "s_or_b64 %[stmp], %[shave], %[sexh]", "s_not_b64 %[stmp], %[stmp]",     # lanes waiting for a refill
+          "s_bcnt1_i32_b64 %[sb], %[stmp]",
+          "s_cmp_lg_u32 %[scapf], 0", f"s_cbranch_scc1 {exit_label}",
+          f"s_cmp_ge_u32 %[sb], {BATCH}", f"s_cbranch_scc1 {exit_label}",
+          "s_cmp_eq_u64 %[shave], 0", f"s_cbranch_scc1 {exit_label}",
+          f"s_branch {cont_label}"]
+    return o
+
+
+def gen_body():
+    sc = [scratch(j) for j in range(12)]   # refill scratch pairs
+    o = []
+    # ---------------- prologue: state of every lane to zero (idle lanes iterate on it harmlessly)
+    o += ["s_mov_b64 %[shave], 0", "s_mov_b64 %[sexh], 0", "s_mov_b32 %[sit], 0", "s_mov_b32 %[srefills], 0",
+          "s_mov_b32 %[sflags], 0", "s_mov_b32 %[scap], -1"]
+    for r in X + V + list(C.values()):
+        o += [f"v_mov_b64 {r}, 0"]
+    for a in AG.values():
+        o += [f"v_accvgpr_write_b32 {a}, 0"]
+    o += [f"v_mov_b32 {VK}, 0", f"v_mov_b32 {VBASE}, 0", f"v_mov_b32 {VCAP}, -1",
+          f"v_mov_b64 {C['cgl0']}, %[sgrl0]", f"v_mov_b64 {C['cgl1']}, %[sgrl1]"]
+    # ---------------- main: refill when due, else iterate
+    o += ["MAIN%=:",
+          "s_or_b64 %[stmp], %[shave], %[sexh]", "s_not_b64 %[swant], %[stmp]",
+          "s_cmp_eq_u64 %[swant], 0", "s_cbranch_scc1 NOWANT%=",
+          "s_bcnt1_i32_b64 %[scnt], %[swant]",
+          f"s_cmp_ge_u32 %[scnt], {BATCH}", "s_cbranch_scc1 REFILL%=",
+          "s_cmp_eq_u64 %[shave], 0", "s_cbranch_scc1 REFILL%=",
+          "s_branch ITER%=",
+          "NOWANT%=:",
+          "s_cmp_eq_u64 %[shave], 0", "s_cbranch_scc1 DONE%=",
+          "s_branch ITER%="]
+    # ---------------- refill pass (lane_pg_fused_kernel's protocol: one atomic for the wavefront's tickets)
+    o += ["REFILL%=:",
+          "s_add_u32 %[srefills], %[srefills], 1",
+          "s_ff1_i32_b64 %[sa], %[swant]", "s_lshl_b64 exec, 1, %[sa]",
+          f"v_mov_b32 {sc[0].lo}, %[scnt]", f"v_mov_b32 {sc[0].hi}, 0",
+          f"global_atomic_add {sc[1].lo}, {sc[0].hi}, {sc[0].lo}, %[pticket] sc0",
+          "s_waitcnt vmcnt(0)", "s_nop 1",
+          f"v_readfirstlane_b32 %[sfirst], {sc[1].lo}",
+          "s_mov_b64 exec, %[swant]",
+          f"v_mbcnt_lo_u32_b32 {sc[0].lo}, exec_lo, 0", f"v_mbcnt_hi_u32_b32 {sc[0].lo}, exec_hi, {sc[0].lo}",   # rank among the waiting lanes
+          f"v_add_u32 {sc[0].lo}, %[sfirst], {sc[0].lo}",          # ticket
+          f"v_cmp_le_u32_e64 vcc, %[snq], {sc[0].lo}",              # past the queue's end: exhausted
+          "s_or_b64 %[sexh], %[sexh], vcc",
+          "s_andn2_b64 %[snew], exec, vcc",
+          "s_mov_b64 exec, %[snew]",
+          "s_cbranch_execz RDONE%=",
+          f"v_lshlrev_b32 {sc[0].lo}, 2, {sc[0].lo}",
+          f"global_load_dword {VK}, {sc[0].lo}, %[porder]",
+          "s_waitcnt vmcnt(0)",
+          f"v_mov_b32 {sc[0].hi}, {RL_BYTES}",
+          f"v_mad_u64_u32 {sc[1]}, vcc, {VK}, {sc[0].hi}, %[precs]"]      # &recs[k * RL]
+    for i in range(H):
+        o += [f"global_load_dwordx4 v[{4 * i}:{4 * i + 3}], {sc[1]}, off offset:{16 * i}"]   # x[2i], x[2i+1]
+    # lambda | meta ; il0 il1 ; beta a ; c ty ; tphi
+    r4 = lambda j: f"v[{W0 + 4 + 4 * j}:{W0 + 7 + 4 * j}]"
+    o += [f"global_load_dwordx4 {r4(0)}, {sc[1]}, off offset:{16 * H}",
+          f"global_load_dwordx4 {r4(1)}, {sc[1]}, off offset:{16 * H + 16}",
+          f"global_load_dwordx4 {r4(2)}, {sc[1]}, off offset:{16 * H + 32}",
+          f"global_load_dwordx4 {r4(3)}, {sc[1]}, off offset:{16 * H + 48}",
+          f"global_load_dwordx2 {sc[10]}, {sc[1]}, off offset:{16 * H + 64}",
+          "s_waitcnt vmcnt(0)"]
+    lam, meta, il0, il1_, beta, ra, rc, ty, tphi = sc[2], sc[3], sc[4], sc[5], sc[6], sc[7], sc[8], sc[9], sc[10]
+    o += [f"v_mov_b64 {C['cil']}, {il0}", f"v_mov_b64 {C['cb']}, {beta}",           # pg_constants (mpc.h:342-343), from the record
+          f"v_mov_b64 {C['ca']}, {ra}", f"v_mov_b64 {C['cc']}, {rc}",               # Unit::set_instance_ac
+          f"v_mul_f64 {C['cas']}, {ra}, %[ss1]", f"v_mul_f64 {C['ccs']}, {rc}, %[ss0]",
+          f"v_add_f64 {sc[11]}, 0, {ty.neg()}",                                      # z0 = 0 - ty
+          f"v_accvgpr_write_b32 {AG['z0lo']}, {sc[11].lo}", f"v_accvgpr_write_b32 {AG['z0hi']}, {sc[11].hi}",
+          f"v_add_f64 {sc[11]}, %[slo1], {tphi}", f"v_mul_f64 {C['cq']}, %[sgq1], {sc[11]}",   # q1th = gq1 (lo1 + tphi)
+          f"v_subrev_u32 {VBASE}, %[sit], {meta.lo}",                                # lane's count = base + wave iterations
+          f"v_sub_u32 {VCAP}, %[smaxit], {VBASE}"]                                   # wave iteration at which the lane reaches max_iter
+    # v := x where the coordinate-descent phase ended on its last iteration (mpc.h:330-334), else the start point u = 0
+    o += [f"v_mov_b64 {t0}, %[sxz0]", f"v_mov_b64 {t1}, %[sxz1]"]
+    for q in range(2 * NREG):
+        o += [f"v_mov_b64 {V[q]}, {t0 if q % 2 == 0 else t1}"]
+    for q in range(2 * NREG, 2 * H):
+        tt = t0 if q % 2 == 0 else t1
+        o += [f"v_accvgpr_write_b32 {AG[f'av{q}lo']}, {tt.lo}", f"v_accvgpr_write_b32 {AG[f'av{q}hi']}, {tt.hi}"]
+    o += [f"v_and_b32 {sc[11].lo}, 2, {meta.hi}", f"v_cmp_ne_u32_e64 vcc, 0, {sc[11].lo}",
+          "s_and_b64 exec, %[snew], vcc", "s_cbranch_execz NOVINIT%="]
+    for q in range(2 * NREG):
+        o += [f"v_mov_b64 {V[q]}, {X[q]}"]
+    for q in range(2 * NREG, 2 * H):
+        o += [f"v_accvgpr_write_b32 {AG[f'av{q}lo']}, {X[q].lo}", f"v_accvgpr_write_b32 {AG[f'av{q}hi']}, {X[q].hi}"]
+    o += ["NOVINIT%=:", "s_mov_b64 exec, %[snew]"]
+    # records that are already complete (the coordinate-descent kernel publishes those itself and keeps them out of the
+    # queue; kept for a queue that holds one): stopped, or at the cap
+    o += [f"v_and_b32 {sc[11].lo}, 1, {meta.hi}", f"v_cmp_ne_u32_e64 vcc, 0, {sc[11].lo}",     # kMetaStopped
+          f"v_cmp_le_u32_e64 %[stmp], %[smaxit], {meta.lo}",                                   # iter >= max_iter
+          "s_or_b64 %[sdonenow], vcc, %[stmp]", "s_and_b64 %[sdonenow], %[sdonenow], %[snew]",
+          "s_cmp_eq_u64 %[sdonenow], 0", "s_cbranch_scc1 RHAVE%=",
+          # (rare path)
+          f"v_and_b32 {sc[11].lo}, 4, {meta.hi}", f"v_cmp_ne_u32_e64 %[sstop], 0, {sc[11].lo}",    # kMetaNonFinite
+          "s_and_b64 %[sstop], %[sstop], %[sdonenow]",
+          "s_cmp_lg_u64 %[sstop], 0", "s_cselect_b32 %[sa], 1, 0", "s_or_b32 %[sflags], %[sflags], %[sa]",
+          "s_andn2_b64 %[stmp], %[stmp], vcc", "s_and_b64 %[stmp], %[stmp], %[sdonenow]",            # at the cap without having stopped
+          "s_cmp_lg_u64 %[stmp], 0", "s_cselect_b32 %[sa], 2, 0", "s_or_b32 %[sflags], %[sflags], %[sa]",
+          "s_mov_b64 exec, %[sstop]", "s_cbranch_execz RNF%="]
+    o += publish("zero", "%[sit]")
+    o += ["RNF%=:", "s_andn2_b64 exec, %[sdonenow], %[sstop]", "s_cbranch_execz RHAVE%="]
+    o += publish("x", "%[sit]")
+    o += ["RHAVE%=:",
+          "s_andn2_b64 %[snew], %[snew], %[sdonenow]",
+          "s_or_b64 %[shave], %[shave], %[snew]",
+          # the wavefront's earliest cap: the new lanes' against what it was (a lane that left may leave it early: CAPCHK recomputes)
+          "s_mov_b64 %[stmp], %[snew]",
+          "RCAP%=:", "s_cmp_eq_u64 %[stmp], 0", "s_cbranch_scc1 RDONE%=",
+          "s_ff1_i32_b64 %[sa], %[stmp]", "s_bitset0_b64 %[stmp], %[sa]",
+          f"v_readlane_b32 %[sb], {VCAP}, %[sa]", "s_min_u32 %[scap], %[scap], %[sb]",
+          "s_branch RCAP%=",
+          "RDONE%=:", "s_mov_b64 exec, -1", "s_branch MAIN%="]
+    # ---------------- iterate
+    tailA = ["s_cbranch_vccnz SA%=", "s_cbranch_scc1 XODD%="]
+    tailB = ["s_cbranch_vccnz SB%=", "s_cbranch_scc1 XEVEN%=", "s_branch LA%="]
+    o += ["ITER%=:",
+          "s_sub_u32 %[sleft], %[scap], %[sit]", "s_sub_u32 %[sleft], %[sleft], 1",   # iterations to the earliest cap, less one
+          ".p2align 3", "LA%=:"]
+    o += P.forward("A") + P.backward("A", tailA)
+    o += ["LB%=:"] + P.forward("B") + P.backward("B", tailB)
+    o += ["SA%=:"] + stop_block("LB%=", "XODD%=")
+    o += ["SB%=:"] + stop_block("LA%=", "XEVEN%=")
+    o += ["XODD%=:"] + [f"v_mov_b64 {V[q]}, {(Wz if q % 2 == 0 else Wy)[q // 2]}" for q in range(2 * NREG)]
+    o += ["XEVEN%=:",
+          "s_sub_u32 %[sit], %[scap], %[sleft]", "s_sub_u32 %[sit], %[sit], 1",       # wave iterations so far
+          "s_cmp_ge_u32 %[sit], %[scap]", "s_cbranch_scc0 MAIN%="]
+    # ---------------- a lane may have reached max_iter (mpc.h:271): publish those, recompute the earliest cap exactly
+    o += ["CAPCHK%=:",
+          f"v_cmp_le_u32_e64 vcc, {VCAP}, %[sit]", "s_and_b64 %[sstop], vcc, %[shave]",
+          "s_cmp_eq_u64 %[sstop], 0", "s_cbranch_scc1 CAPMIN%=",
+          "s_or_b32 %[sflags], %[sflags], 2",
+          "s_mov_b64 exec, %[sstop]"]
+    o += publish("x", "%[sit]")
+    o += ["s_mov_b64 exec, -1", "s_andn2_b64 %[shave], %[shave], %[sstop]",
+          "CAPMIN%=:", "s_mov_b32 %[scap], -1", "s_mov_b64 %[stmp], %[shave]",
+          "CAPL%=:", "s_cmp_eq_u64 %[stmp], 0", "s_cbranch_scc1 MAIN%=",
+          "s_ff1_i32_b64 %[sa], %[stmp]", "s_bitset0_b64 %[stmp], %[sa]",
+          f"v_readlane_b32 %[sb], {VCAP}, %[sa]", "s_min_u32 %[scap], %[scap], %[sb]",
+          "s_branch CAPL%=",
+          "DONE%=:", "s_waitcnt vmcnt(0)"]
+    return o
 
 
 def gen():
-    assert Wz[0].lo
-    def stop_block(cont_label, exit_label):
-        """lanes whose stop test fired (vcc): their answer -- x[0], x[1] before this iteration's update -- and the count-down
-        go to AGPRs, they leave `have`; the loop goes on unless a refill pass is due (BATCH lanes wait), no lane has work
-        left, or the cap fell in the same iteration"""
-        return ["s_cselect_b32 %[stmp], 1, 0",                    # cap pending (SCC of the count-down)
-                "s_mov_b64 exec, vcc",
-                f"v_mov_b64 {t0}, {X[0]}", f"v_mov_b64 {t1}, {X[1]}",
-                f"v_accvgpr_write_b32 %[pub0lo], {t0.lo}", f"v_accvgpr_write_b32 %[pub0hi], {t0.hi}",
-                f"v_accvgpr_write_b32 %[pub1lo], {t1.lo}", f"v_accvgpr_write_b32 %[pub1hi], {t1.hi}",
-                f"v_mov_b32 {t0.lo}, %[sleft]", f"v_accvgpr_write_b32 %[publeft], {t0.lo}",
-                "s_mov_b64 exec, %[sexec]",
-                "s_andn2_b64 %[shave], %[shave], vcc",
-                "s_or_b64 %[sdone], %[sdone], vcc",
-                "s_or_b64 vcc, %[sdone], %[swait]",
-                "s_bcnt1_i32_b64 %[stmp2], vcc",
-                "s_cmp_lg_u32 %[stmp], 0", f"s_cbranch_scc1 {exit_label}",
-                f"s_cmp_ge_u32 %[stmp2], {BATCH}", f"s_cbranch_scc1 {exit_label}",
-                "s_cmp_eq_u64 %[shave], 0", f"s_cbranch_scc1 {exit_label}",
-                f"s_branch {cont_label}"]
-    body = ["s_mov_b64 %[sexec], exec", "s_mov_b64 %[sdone], 0", ".p2align 3", "LA%=:"]   # (8-byte instructions on 8-byte addresses: ubasm.py)
-    body += forward("A") + backward("A", "XODD%=", None, "SA%=")
-    body += ["LB%=:"] + forward("B") + backward("B", "XEVEN%=", "LA%=", "SB%=")
-    body += ["SA%=:"] + stop_block("LB%=", "XODD%=")
-    body += ["SB%=:"] + stop_block("LA%=", "XEVEN%=")
-    body += ["XODD%=:"] + [f"v_mov_b64 {V[q]}, {(Wz if q % 2 == 0 else Wy)[q // 2]}" for q in range(2 * NREG)]
-    body += ["XEVEN%=:"]
-    n_iter = (len(forward("A")) + len(backward("A", "x", "y", "z")))
+    body = gen_body()
+    n_iter = len(P.forward("A")) + len(P.backward("A", ["x", "y"]))
     out = []
-    out.append("// GENERATED by scripts/gen_ub_pg_asm.py -- do not edit.  The inner loop of ub_pg_kernel<double, %d, true, 2>\n"
-               "// (mpc_ub.h) with hand-assigned registers; arithmetic: mpc_ub_model.h, operation for operation.\n"
-               "// %d instructions per iteration (the compiler's loop: 708); v of steps %d..%d in AGPRs.\n"
+    out.append("// GENERATED by scripts/gen_ub_pg_asm.py -- do not edit (make -C csrc regen).  The persistent projected-gradient kernel\n"
+               "// of ub_pg_kernel<double, %d, true, 2> (mpc_ub.h) as one asm statement with hand-assigned registers; arithmetic:\n"
+               "// mpc_ub_model.h, operation for operation.  %d instructions per iteration (the compiler's loop: 708); v of steps\n"
+               "// %d..%d in AGPRs.  Register plan and reasons: scripts/gen_ub_pg_asm.py, scripts/ubasm.py.\n"
                "#pragma once\n\nnamespace tpc {\n\n" % (H, n_iter, NREG, H - 1))
-    out.append(f"constexpr int kUbAsmH = {H}, kUbAsmRegSteps = {NREG}, kUbAsmAgprSteps = {NA}, kUbAsmIterInstrs = {n_iter};\n\n")
-    out.append("// x: controls in unit-box coordinates; v: momentum of steps 0..kUbAsmRegSteps-1; av: momentum of the rest (AGPR words);\n"
-               "// z0, a, c, as1, cs, q1th: Unit's per-instance values; il, beta: pg_constants; grl0 / grl1: uniform, in VGPRs (a VOP3\n"
-               "// instruction reads one SGPR pair); gq0 .. geps: uniform.  have: lanes that carry an instance (in / out); wait: lanes\n"
-               "// already waiting for a refill.  left: in = (smallest number of iterations any lane may still run) - 1, out = that minus\n"
-               "// the iterations run (mod 2^32).  Returns the lanes that stopped (mpc.h:310-311) during the call: their answer -- x[0],\n"
-               "// x[1] BEFORE the stopping iteration's update -- is in pub[0], pub[1], the value of `left` after that iteration in\n"
-               "// pub_left.  The loop ends when kUbAsmBatch lanes wait, no lane has work, or the count-down runs out (mpc.h:271).\n")
-    out.append(f"constexpr int kUbAsmBatch = {BATCH};\n")
-    out.append("TPC_DEV uint64_t ub_pg_loop_f64(double (&x)[%d], double (&v)[%d], AgprWord (&av)[%d], const AgprWord& z0,\n"
-               "                               double a, double c, double as1, double cs, double q1th, double il, double beta,\n"
-               "                               double grl0, double grl1, double gq0, double gq1, double grs0, double grs1, double lo1,\n"
-               "                               double geps, uint64_t& have, uint64_t wait, uint32_t& left, AgprWord (&pub)[2],\n"
-               "                               int& pub_left) {\n" % (2 * H, 2 * NREG, 2 * NA))
-    out.append("    uint64_t done, sexec;\n    uint32_t stmp, stmp2;\n    asm volatile(\n")
+    out.append(f"constexpr int kUbAsmH = {H}, kUbAsmIterInstrs = {n_iter}, kUbAsmBatch = {BATCH};\n\n")
+    out.append("struct UbAsmIn {\n"
+               "    const double* recs; const uint32_t* order; uint32_t* ticket; double* front; double* rear; int32_t* iters;\n"
+               "    uint32_t n_queue, max_iter;\n"
+               "    double gq0, gq1, grs0, grs1, grl0, grl1, lo0, lo1, hi0, hi1, s0, s1, xz0, xz1, geps;   // wave-uniform: MUST reach the asm in SGPRs (kernel arguments)\n"
+               "};\n"
+               "// Runs the whole queue (every lane of the wavefront must be live).  Out: wave iterations, refill passes, TPC_MPC_FLAG bits.\n"
+               "TPC_DEV void ub_pg_asm_run(const UbAsmIn& in, uint32_t& wave_iters, uint32_t& refills, uint32_t& flags) {\n"
+               "    uint64_t shave, sexh, swant, snew, stmp, sstop, sdonenow;\n"
+               "    uint32_t scap, sleft, scnt, sfirst, sa, sb, scapf;\n"
+               "    asm volatile(\n")
     for l in body:
         out.append(f'        "{l}\\n"\n')
-    outs = [f'[x{q}] "+v"(x[{q}])' for q in range(2 * H)] + [f'[v{q}] "+v"(v[{q}])' for q in range(2 * NREG)]
-    for q in range(2 * NREG, 2 * H):
-        k = q - 2 * NREG
-        outs += [f'[av{q}lo] "+a"(av[{k}].lo)', f'[av{q}hi] "+a"(av[{k}].hi)']
-    outs += ['[pub0lo] "+a"(pub[0].lo)', '[pub0hi] "+a"(pub[0].hi)', '[pub1lo] "+a"(pub[1].lo)', '[pub1hi] "+a"(pub[1].hi)',
-             '[publeft] "+a"(pub_left)', '[sleft] "+s"(left)', '[shave] "+s"(have)', '[sdone] "=&s"(done)', '[sexec] "=&s"(sexec)',
-             '[stmp] "=&s"(stmp)', '[stmp2] "=&s"(stmp2)']
-    ins = ['[z0lo] "a"(z0.lo)', '[z0hi] "a"(z0.hi)', '[ca] "v"(a)', '[cc] "v"(c)', '[cas] "v"(as1)', '[ccs] "v"(cs)', '[cq] "v"(q1th)',
-           '[cil] "v"(il)', '[cb] "v"(beta)', '[cgl0] "v"(grl0)', '[cgl1] "v"(grl1)', '[sgq0] "s"(gq0)', '[sgq1] "s"(gq1)',
-           '[sgrs0] "s"(grs0)', '[sgrs1] "s"(grs1)', '[slo1] "s"(lo1)', '[sgeps] "s"(geps)', '[swait] "s"(wait)']
-    clob = [f'"v{r}"' for r in range(BASE, 256)] + ['"vcc"', '"scc"']
+    outs = ['[sit] "=&s"(wave_iters)', '[srefills] "=&s"(refills)', '[sflags] "=&s"(flags)',
+            '[shave] "=&s"(shave)', '[sexh] "=&s"(sexh)', '[swant] "=&s"(swant)', '[snew] "=&s"(snew)', '[stmp] "=&s"(stmp)',
+            '[sstop] "=&s"(sstop)', '[sdonenow] "=&s"(sdonenow)', '[scap] "=&s"(scap)', '[sleft] "=&s"(sleft)', '[scnt] "=&s"(scnt)',
+            '[sfirst] "=&s"(sfirst)', '[sa] "=&s"(sa)', '[sb] "=&s"(sb)', '[scapf] "=&s"(scapf)']
+    ins = ['[precs] "s"(in.recs)', '[porder] "s"(in.order)', '[pticket] "s"(in.ticket)', '[pfront] "s"(in.front)', '[prear] "s"(in.rear)',
+           '[piters] "s"(in.iters)', '[snq] "s"(in.n_queue)', '[smaxit] "s"(in.max_iter)',
+           '[sgq0] "s"(in.gq0)', '[sgq1] "s"(in.gq1)', '[sgrs0] "s"(in.grs0)', '[sgrs1] "s"(in.grs1)', '[sgrl0] "s"(in.grl0)', '[sgrl1] "s"(in.grl1)',
+           '[slo0] "s"(in.lo0)', '[slo1] "s"(in.lo1)', '[shi0] "s"(in.hi0)', '[shi1] "s"(in.hi1)', '[ss0] "s"(in.s0)', '[ss1] "s"(in.s1)',
+           '[sxz0] "s"(in.xz0)', '[sxz1] "s"(in.xz1)', '[sgeps] "s"(in.geps)']
+    clob = [f'"v{r}"' for r in range(256)] + [f'"a{r}"' for r in range(N_AGPR)] + ['"vcc"', '"scc"', '"memory"']
     def wrap(items, ind):
         lines, cur = [], ""
         for it in items:
@@ -124,7 +273,7 @@ def gen():
     out.append("        : " + wrap(outs, 10) + "\n")
     out.append("        : " + wrap(ins, 10) + "\n")
     out.append("        : " + wrap(clob, 10) + ");\n")
-    out.append("    return done;\n}\n\n}  // namespace tpc\n")
+    out.append("}\n\n}  // namespace tpc\n")
     return "".join(out)
 
 

@@ -19,8 +19,7 @@ hipError_t ub_pg_asm_launch(const CompactArgs& a, const Knobs& k, const Workspac
         if (per_cu > 4) per_cu = 4;
         cap = cus * per_cu;
     }
-    hipLaunchKernelGGL(ub_pg_asm_kernel, dim3((unsigned)(need < cap ? need : cap)), dim3(kWave), 0, s, a, k,
-                       (const double*)ws.state, (const uint32_t*)ws.order, ws.ticket, ws.stats, order_queue_len(ws.sort_temp));
+    hipLaunchKernelGGL(ub_pg_asm_kernel, dim3((unsigned)(need < cap ? need : cap)), dim3(kWave), 0, s, ub_asm_args(a, k, ws));
     return hipGetLastError();
 }
 

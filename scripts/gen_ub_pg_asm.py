@@ -29,6 +29,8 @@ import ubasm
 
 H = 20
 NA = int(sys.argv[1]) if len(sys.argv) > 1 else 4   # steps H-NA .. H-1 keep v in AGPRs
+DIAG = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # diagnostic builds only (scripts/build_asm_variant.sh): the wave-iteration statistic
+                                                      # becomes the shader cycles spent in: 1 ticket wait, 2 queue-entry wait, 3 record wait, 4 a whole refill pass, 5 the iteration loop
 BATCH = 3                                            # lanes that must wait before a refill pass is due (UbRefillBatch<20>)
 RL_BYTES = 400                                       # LaneRec<double, 20>::kLen * 8
 P = ubasm.Plan(H=H, NA=NA, batch=BATCH, all_hard=True)
@@ -45,7 +47,9 @@ AG["z0lo"], AG["z0hi"] = f"a{_n}", f"a{_n + 1}"; _n += 2
 N_AGPR = _n
 P.A = AG
 P.S = {n: f"%[{n}]" for n in ("sgq0", "sgq1", "sgrs0", "sgrs1", "slo1", "sgeps", "shave", "sleft")}
-P.S["sexec"] = "-1"   # every lane of the wavefront is live in this kernel
+EXECMASK = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # 1: the loop runs under EXEC = the lanes that carry an instance (measured SLOWER: 5.14-5.24 ms against 4.82-4.87,
+                                                          # profiles/r05_ab_execmask.txt); 0: every lane iterates, idle ones on stale state
+P.S["sexec"] = "%[shave]" if EXECMASK else "-1"
 W0 = int(Wz[0].lo[1:])
 
 
@@ -85,8 +89,8 @@ def stop_block(cont_label, exit_label):
          "s_mov_b64 exec, vcc",
          "s_sub_u32 %[sa], %[scap], %[sleft]", "s_sub_u32 %[sa], %[sa], 2"]   # wave iterations run (cap - 1 - left), less one
     o += publish("x", "%[sa]")
-    o += ["s_mov_b64 exec, -1",
-          "s_andn2_b64 %[shave], %[shave], %[sstop]",
+    o += ["s_andn2_b64 %[shave], %[shave], %[sstop]",
+          f"s_mov_b64 exec, {P.S['sexec']}",
           "s_or_b64 %[stmp], %[shave], %[sexh]", "s_not_b64 %[stmp], %[stmp]",     # lanes waiting for a refill
           "s_bcnt1_i32_b64 %[sb], %[stmp]",
           "s_cmp_lg_u32 %[scapf], 0", f"s_cbranch_scc1 {exit_label}",
@@ -96,9 +100,20 @@ def stop_block(cont_label, exit_label):
     return o
 
 
+def stamp_begin(k):
+    return ["s_memtime s[96:97]", "s_waitcnt lgkmcnt(0)"] if DIAG == k else []
+
+
+def stamp_end(k):
+    return (["s_memtime s[98:99]", "s_waitcnt lgkmcnt(0)", "s_sub_u32 s98, s98, s96", "s_add_u32 %[sdiag], %[sdiag], s98"]
+            if DIAG == k else [])
+
+
 def gen_body():
     sc = [scratch(j) for j in range(12)]   # refill scratch pairs
-    o = []
+    o = ["s_mov_b32 %[sdiag], 0"] if DIAG else []
+    if DIAG == 6: o += ["s_memtime s[96:97]", "s_waitcnt lgkmcnt(0)"]
+    if DIAG == 7: o += ["s_memrealtime s[96:97]", "s_waitcnt lgkmcnt(0)"]
     # ---------------- prologue: state of every lane to zero (idle lanes iterate on it harmlessly)
     o += ["s_mov_b64 %[shave], 0", "s_mov_b64 %[sexh], 0", "s_mov_b32 %[sit], 0", "s_mov_b32 %[srefills], 0",
           "s_mov_b32 %[sflags], 0", "s_mov_b32 %[scap], -1"]
@@ -120,12 +135,12 @@ def gen_body():
           "s_cmp_eq_u64 %[shave], 0", "s_cbranch_scc1 DONE%=",
           "s_branch ITER%="]
     # ---------------- refill pass (lane_pg_fused_kernel's protocol: one atomic for the wavefront's tickets)
-    o += ["REFILL%=:",
+    o += ["REFILL%=:"] + stamp_begin(4) + [
           "s_add_u32 %[srefills], %[srefills], 1",
           "s_ff1_i32_b64 %[sa], %[swant]", "s_lshl_b64 exec, 1, %[sa]",
-          f"v_mov_b32 {sc[0].lo}, %[scnt]", f"v_mov_b32 {sc[0].hi}, 0",
+          f"v_mov_b32 {sc[0].lo}, %[scnt]", f"v_mov_b32 {sc[0].hi}, 0"] + stamp_begin(1) + [
           f"global_atomic_add {sc[1].lo}, {sc[0].hi}, {sc[0].lo}, %[pticket] sc0",
-          "s_waitcnt vmcnt(0)", "s_nop 1",
+          "s_waitcnt vmcnt(0)"] + stamp_end(1) + ["s_nop 1",
           f"v_readfirstlane_b32 %[sfirst], {sc[1].lo}",
           "s_mov_b64 exec, %[swant]",
           f"v_mbcnt_lo_u32_b32 {sc[0].lo}, exec_lo, 0", f"v_mbcnt_hi_u32_b32 {sc[0].lo}, exec_hi, {sc[0].lo}",   # rank among the waiting lanes
@@ -135,11 +150,12 @@ def gen_body():
           "s_andn2_b64 %[snew], exec, vcc",
           "s_mov_b64 exec, %[snew]",
           "s_cbranch_execz RDONE%=",
-          f"v_lshlrev_b32 {sc[0].lo}, 2, {sc[0].lo}",
+          f"v_lshlrev_b32 {sc[0].lo}, 2, {sc[0].lo}"] + stamp_begin(2) + [
           f"global_load_dword {VK}, {sc[0].lo}, %[porder]",
-          "s_waitcnt vmcnt(0)",
+          "s_waitcnt vmcnt(0)"] + stamp_end(2) + [
           f"v_mov_b32 {sc[0].hi}, {RL_BYTES}",
           f"v_mad_u64_u32 {sc[1]}, vcc, {VK}, {sc[0].hi}, %[precs]"]      # &recs[k * RL]
+    o += stamp_begin(3)
     for i in range(H):
         o += [f"global_load_dwordx4 v[{4 * i}:{4 * i + 3}], {sc[1]}, off offset:{16 * i}"]   # x[2i], x[2i+1]
     # lambda | meta ; il0 il1 ; beta a ; c ty ; tphi
@@ -149,7 +165,7 @@ def gen_body():
           f"global_load_dwordx4 {r4(2)}, {sc[1]}, off offset:{16 * H + 32}",
           f"global_load_dwordx4 {r4(3)}, {sc[1]}, off offset:{16 * H + 48}",
           f"global_load_dwordx2 {sc[10]}, {sc[1]}, off offset:{16 * H + 64}",
-          "s_waitcnt vmcnt(0)"]
+          "s_waitcnt vmcnt(0)"] + stamp_end(3)
     lam, meta, il0, il1_, beta, ra, rc, ty, tphi = sc[2], sc[3], sc[4], sc[5], sc[6], sc[7], sc[8], sc[9], sc[10]
     o += [f"v_mov_b64 {C['cil']}, {il0}", f"v_mov_b64 {C['cb']}, {beta}",           # pg_constants (mpc.h:342-343), from the record
           f"v_mov_b64 {C['ca']}, {ra}", f"v_mov_b64 {C['cc']}, {rc}",               # Unit::set_instance_ac
@@ -198,19 +214,20 @@ def gen_body():
           "s_ff1_i32_b64 %[sa], %[stmp]", "s_bitset0_b64 %[stmp], %[sa]",
           f"v_readlane_b32 %[sb], {VCAP}, %[sa]", "s_min_u32 %[scap], %[scap], %[sb]",
           "s_branch RCAP%=",
-          "RDONE%=:", "s_mov_b64 exec, -1", "s_branch MAIN%="]
+          "RDONE%=:", "s_mov_b64 exec, -1"] + stamp_end(4) + ["s_branch MAIN%="]
     # ---------------- iterate
     tailA = ["s_cbranch_vccnz SA%=", "s_cbranch_scc1 XODD%="]
     tailB = ["s_cbranch_vccnz SB%=", "s_cbranch_scc1 XEVEN%=", "s_branch LA%="]
     o += ["ITER%=:",
-          "s_sub_u32 %[sleft], %[scap], %[sit]", "s_sub_u32 %[sleft], %[sleft], 1",   # iterations to the earliest cap, less one
+          "s_sub_u32 %[sleft], %[scap], %[sit]", "s_sub_u32 %[sleft], %[sleft], 1"] + stamp_begin(5) + [   # iterations to the earliest cap, less one
+          f"s_mov_b64 exec, {P.S['sexec']}",
           ".p2align 3", "LA%=:"]
     o += P.forward("A") + P.backward("A", tailA)
     o += ["LB%=:"] + P.forward("B") + P.backward("B", tailB)
     o += ["SA%=:"] + stop_block("LB%=", "XODD%=")
     o += ["SB%=:"] + stop_block("LA%=", "XEVEN%=")
     o += ["XODD%=:"] + [f"v_mov_b64 {V[q]}, {(Wz if q % 2 == 0 else Wy)[q // 2]}" for q in range(2 * NREG)]
-    o += ["XEVEN%=:",
+    o += ["XEVEN%=:", "s_mov_b64 exec, -1"] + stamp_end(5) + [
           "s_sub_u32 %[sit], %[scap], %[sleft]", "s_sub_u32 %[sit], %[sit], 1",       # wave iterations so far
           "s_cmp_ge_u32 %[sit], %[scap]", "s_cbranch_scc0 MAIN%="]
     # ---------------- a lane may have reached max_iter (mpc.h:271): publish those, recompute the earliest cap exactly
@@ -227,6 +244,8 @@ def gen_body():
           f"v_readlane_b32 %[sb], {VCAP}, %[sa]", "s_min_u32 %[scap], %[scap], %[sb]",
           "s_branch CAPL%=",
           "DONE%=:", "s_waitcnt vmcnt(0)"]
+    if DIAG == 6: o += ["s_memtime s[98:99]", "s_waitcnt lgkmcnt(0)", "s_sub_u32 %[sdiag], s98, s96"]
+    if DIAG == 7: o += ["s_memrealtime s[98:99]", "s_waitcnt lgkmcnt(0)", "s_sub_u32 %[sdiag], s98, s96"]
     return o
 
 
@@ -247,6 +266,7 @@ def gen():
                "};\n"
                "// Runs the whole queue (every lane of the wavefront must be live).  Out: wave iterations, refill passes, TPC_MPC_FLAG bits.\n"
                "TPC_DEV void ub_pg_asm_run(const UbAsmIn& in, uint32_t& wave_iters, uint32_t& refills, uint32_t& flags) {\n"
+               + ("    uint32_t sdiag;\n" if DIAG else "") +
                "    uint64_t shave, sexh, swant, snew, stmp, sstop, sdonenow;\n"
                "    uint32_t scap, sleft, scnt, sfirst, sa, sb, scapf;\n"
                "    asm volatile(\n")
@@ -262,6 +282,9 @@ def gen():
            '[slo0] "s"(in.lo0)', '[slo1] "s"(in.lo1)', '[shi0] "s"(in.hi0)', '[shi1] "s"(in.hi1)', '[ss0] "s"(in.s0)', '[ss1] "s"(in.s1)',
            '[sxz0] "s"(in.xz0)', '[sxz1] "s"(in.xz1)', '[sgeps] "s"(in.geps)']
     clob = [f'"v{r}"' for r in range(256)] + [f'"a{r}"' for r in range(N_AGPR)] + ['"vcc"', '"scc"', '"memory"']
+    if DIAG:
+        outs.append('[sdiag] "=&s"(sdiag)')
+        clob += ['"s96"', '"s97"', '"s98"', '"s99"']
     def wrap(items, ind):
         lines, cur = [], ""
         for it in items:
@@ -273,6 +296,8 @@ def gen():
     out.append("        : " + wrap(outs, 10) + "\n")
     out.append("        : " + wrap(ins, 10) + "\n")
     out.append("        : " + wrap(clob, 10) + ");\n")
+    if DIAG:
+        out.append("    wave_iters = sdiag;   // DIAGNOSTIC BUILD %d: shader cycles of one section, not wave iterations\n" % DIAG)
     out.append("}\n\n}  // namespace tpc\n")
     return "".join(out)
 

@@ -79,6 +79,11 @@ def parse():
     ap.add_argument("--no-config4", action="store_true",
                     help="skip the leg that solves BASELINE config 4's whole batch (2 097 152 x N=20, fp32) on this one GPU")
     ap.add_argument("--no-mid", action="store_true", help="skip the mid-size batch leg (16 384 x N=20 through AUTO)")
+    ap.add_argument("--split", default="block", choices=["block", "interleaved"],
+                    help="N > 1: how the batch is split over the ranks (tpc_mpc_solve_batch_compact_sharded_split)")
+    ap.add_argument("--sorted-by-speed", action="store_true",
+                    help="the synthetic stream arrives sorted by speed (what the interleaved split is for: the iteration count is a "
+                         "function of the speed, a block split then gives one rank all the long instances)")
     ap.add_argument("--allow-fallback-gather", action="store_true",
                     help="N > 1 only: let the run continue with a torch.distributed gather when the library's RCCL path "
                          "cannot be set up (the line then carries \"gather\": \"fallback\"); by default such a run exits non-zero")
@@ -175,15 +180,25 @@ def main():
             dist.init_process_group(backend)
 
     H, n = a.horizon, a.batch
-    # weak scaling: rank r owns instances [r*n, (r+1)*n) of the horizon-H stream
-    v, dy, dphi = compact_inputs(H, n, first=rank * n)
+    # weak scaling: rank r owns its shard of the world * n instances of the horizon-H stream: [r*n, (r+1)*n) under the
+    # block split, r, r + world, ... under the interleaved one
+    n_total = world * n
+    from trajectory_controller_amd.shard import shard_slice
+    my = shard_slice(n_total, rank, world, a.split)
+    if a.split == "block" and not a.sorted_by_speed:
+        v, dy, dphi = compact_inputs(H, n, first=rank * n)
+    else:
+        v, dy, dphi = compact_inputs(H, n_total)
+        if a.sorted_by_speed:
+            o = np.argsort(v, kind="stable")
+            v, dy, dphi = v[o], dy[o], dphi[o]
+        v, dy, dphi = (np.ascontiguousarray(x[my]) for x in (v, dy, dphi))
     tdt = torch.float64 if a.dtype == "f64" else torch.float32
     tv, ty, tp = (torch.from_numpy(x).to(dev, dtype=tdt) for x in (v, dy, dphi))
     slots = max(1, a.inflight)
     fronts = [torch.empty_like(tv) for _ in range(slots)]
     rears = [torch.empty_like(tv) for _ in range(slots)]
     iters_t = None
-    n_total = world * n
     if world > 1:
         # full-size outputs: every rank ends each step holding the controls of all world*n instances
         front_all = [torch.empty(n_total, dtype=tdt, device=dev) for _ in range(slots)]
@@ -217,7 +232,7 @@ def main():
                                            dtype=torch.uint8).to(dev)
                     dist.broadcast(idt, src=0)
                     sv.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
-                gather_path = "library: tpc_mpc_solve_batch_compact_sharded (ncclAllGather over RCCL)"
+                gather_path = f"library: tpc_mpc_solve_batch_compact_sharded_split, {a.split} split (ncclAllGather over RCCL)"
             except Exception as exc:   # noqa: BLE001
                 probe_err = str(exc)
         if probe_err:
@@ -243,8 +258,10 @@ def main():
         i = k % slots
         with torch.cuda.stream(streams[i]):
             if world > 1 and use_lib_gather:
-                solvers[i].solve_batch_compact_sharded(n_total, tv, ty, tp, out=(front_all[i], rear_all[i]))
+                solvers[i].solve_batch_compact_sharded(n_total, tv, ty, tp, out=(front_all[i], rear_all[i]), split=a.split)
             elif world > 1:
+                if a.split != "block":
+                    raise SystemExit("[bench] the torch.distributed fallback gather knows the block split only")
                 lo = rank * n
                 solvers[i].solve_batch_compact(tv, ty, tp, out=(front_all[i][lo:lo + n], rear_all[i][lo:lo + n]),
                                                want_flags=False)
@@ -286,13 +303,32 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    local_elapsed = elapsed
+    # the same K-step region twice more (same bracket): box-to-box and run-to-run noise is +-4 %, so a 3 % kernel change is
+    # only visible in the median; `value` stays the FIRST region, the one the contract describes
+    region_s = [elapsed]
+    for _ in range(2):
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(a.steps):
+            step(k)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        region_s.append(time.perf_counter() - t1)
+    if world > 1:
+        tr = torch.tensor(region_s, dtype=torch.float64, device=dev)
+        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        region_s = [float(x) for x in tr.tolist()]
     # HIP events the library recorded on the launch streams inside the timed region
     k1, k2, algo_ran = kernel_times(min(slots, a.steps))
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        front, rear = front_all[0][rank * n:(rank + 1) * n], rear_all[0][rank * n:(rank + 1) * n]
+        front, rear = front_all[0][my], rear_all[0][my]
         # the gather really delivered the other ranks' blocks: every rank checks the checksum of the
         # whole output against the all-reduced sum of the per-rank block checksums (exact: integers)
         chk = lambda t: t.view(torch.int64 if t.dtype == torch.float64 else torch.int32).bitwise_and(0xFFFFF).sum()
@@ -300,11 +336,30 @@ def main():
         dist.all_reduce(local, op=dist.ReduceOp.SUM)
         whole = torch.stack([chk(front_all[0]), chk(rear_all[0])])
         gather_ok = bool(torch.equal(local, whole))
-        print(f"[bench] rank {rank}/{world}: instances [{rank * n}, {(rank + 1) * n}) of {n_total}; "
+        print(f"[bench] rank {rank}/{world}: instances {my.start}:{my.stop}:{my.step or 1} of {n_total}; "
               f"gather {'verified' if gather_ok else 'FAILED'} ({gather_path})", file=sys.stderr, flush=True)
     else:
         front, rear = fronts[0], rears[0]
         gather_ok = None
+        chk = lambda t: t.view(torch.int64 if t.dtype == torch.float64 else torch.int32).bitwise_and(0xFFFFF).sum()
+
+    # One record per rank, in the line: device, shard, iteration total (= the rank's share of the work; the projected-
+    # gradient kernel's time follows it), kernel times, wall time, checksum of its block of the outputs -- so that the first
+    # run on a multi-GPU node can be diagnosed from its one line.  Outside the timed region.
+    _, _, it_r = solver.solve_batch_compact(tv, ty, tp, want_iters=True)
+    torch.cuda.synchronize()
+    rec = {"rank": rank, "device": local_rank, "device_name": torch.cuda.get_device_name(dev),
+           "shard": {"first": my.start, "stride": my.step or 1, "count": n},
+           "iterations_total": int(it_r.sum().item()), "cd_kernel_ms": k1, "pg_kernel_ms": k2,
+           "ms_per_step_local": local_elapsed / a.steps * 1e3,
+           "block_checksum": [int(chk(front).item()), int(chk(rear).item())], "gather_verified": gather_ok}
+    recs = [rec]
+    if world > 1:
+        recs = [None] * world
+        dist.all_gather_object(recs, rec)
+    it_tot = [r["iterations_total"] for r in recs]
+    imbalance = {"iterations_max_over_mean": max(it_tot) / (sum(it_tot) / len(it_tot)), "split": a.split,
+                 "sorted_by_speed": bool(a.sorted_by_speed)}
 
     if rank == 0:
         # iteration statistics of this rank's shard (for the algorithmic-flop figure)
@@ -358,6 +413,8 @@ def main():
             "metric": "MPC QP solves/sec (horizon N=20, 2 inputs) at 1/2/4/8 MI355X; max|du| vs dlib",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value_median_of": {"repeats": len(region_s), "value": total / sorted(region_s)[len(region_s) // 2],
+                                "values": [total / t for t in region_s]},
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic", "gather": gather_word,
             "config": {"workload": f"batch {n} trajectories per GPU, N={H}, 2 inputs, compact "
                                    f"(mpcControllerTobi) form, cold start, eps 0.01, max_iter 10000",
@@ -365,6 +422,7 @@ def main():
                        "parallelism": f"batch-sharded x{world}", "batches_in_flight": slots,
                        "gather": gather_path, "gather_verified": gather_ok},
             "build": MpcSolver.build_info(),
+            "ranks": recs, "imbalance": imbalance,
             "kernel_ms": {"first": k1, "second": k2, "dominant": dom_name},
             "kernel_ms_serial": {"first": s1, "second": s2},
             "mean_iterations": mean_iters, "lane_stats": lane_stats,
@@ -460,13 +518,34 @@ def main():
             c1, c2, c_algo = s32.last_kernel_times()
             _, _, it32 = s32.solve_batch_compact(v32, y32, p32, want_iters=True)
             err = torch.maximum((f32.double() - front).abs(), (r32.double() - rear).abs())
+            mi32 = float(it32.double().mean().item())
+            a32 = {1: "wave", 2: "lane", 3: "lane_fma", 4: "group"}.get(c_algo, str(c_algo))
+            dom32 = {1: "wave_kernel", 2: "lane_pg_fused_kernel", 3: "ub_pg_kernel", 4: "group_pg_kernel"}.get(c_algo, "?")
+            t32, t32_note = None, "no profiles/traffic.json entry for this kernel"
+            try:
+                tdata = json.load(open(tj))
+                e32 = tdata.get(f"{dom32}_f32_H{H}_n{n}")
+                if e32 is not None and tdata.get("_library_sha256") == library_sha256():
+                    t32, t32_note = e32, "PMC passes of this binary (profiles/traffic.json)"
+                elif e32 is not None:
+                    t32_note = f"profiles/traffic.json was measured on a different build ({e32} B per launch there)"
+            except Exception as exc:   # noqa: BLE001
+                t32_note = f"profiles/traffic.json unreadable: {exc}"
+            gbs32 = 5 * 4 * n / (max(c1, c2) * 1e-3) / 1e9             # 3 in + 2 out floats per solve
+            tf32 = (46 * H - 16) * mi32 * n / (d32 / a.steps) / 1e12
             out["fp32"] = {"value": n * a.steps / d32, "unit": "solves/s (1 GPU)",
-                           "ms_per_step": d32 / a.steps * 1e3,
-                           "algo": {1: "wave", 2: "lane", 3: "lane_fma", 4: "group"}.get(c_algo, str(c_algo)),
-                           "kernel_ms": {"first": c1, "second": c2},
-                           "mean_iterations": float(it32.double().mean().item()),
+                           "ms_per_step": d32 / a.steps * 1e3, "algo": a32,
+                           "kernel_ms": {"first": c1, "second": c2, "dominant": dom32},
+                           "mean_iterations": mi32,
+                           "roofline": {"bound": "hbm", "achieved": gbs32, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": gbs32 / HBM_PEAK_GBS, "traffic": t32, "traffic_note": t32_note,
+                                        "note": "20 B/solve algorithmic (config 3 as written: fp32)"},
+                           "alu": {"bound": "fp32 vector issue", "achieved": tf32, "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                                   "frac": tf32 / FP32_VECTOR_PEAK_TF, "flops_per_solve": (46 * H - 16) * mi32,
+                                   "note": "the 157.3 TFLOP/s fp32 vector peak assumes packed FMAs; a scalar-fp32 stream tops out at half"},
                            "within": {str(t): float((err <= t).double().mean().item())
-                                      for t in (1e-2, 1e-3, 1e-4, 1e-5, 1e-6)},
+                                      for t in (1e-2, 1e-3, 1e-4, 1e-5, 1e-6, 1e-7, 1e-8, 1e-9)},
+                           "note": "fp32 has no reference (dlib is fp64-only): errors are against this run's fp64 outputs",
                            "max_abs_du_vs_fp64": float(err.max().item())}
             s32.close()
         if world == 1 and not a.no_config2 and a.dtype == "f64" and n == 262144 and H == 20:
@@ -532,6 +611,17 @@ def main():
                           "f64_fast_capped: TPC_MPC_PARAM_FAST_CAPPED, the tolerance families' answer kept (<= 1.5e-12 from "
                           "dlib on this workload)"}
             from trajectory_controller_amd import capi
+            # the reference's answers for the first 1 024 instances of each horizon's stream: the committed real-dlib fixtures
+            # (outputs) and, for the iteration counts the fixtures only bound from below, the checker run on the host
+            fix = {}
+            if not a.no_cpu:
+                from oracle import bindings as ob5
+                for Hh, pp in zip(Hs, parts):
+                    g = np.load(os.path.join(ROOT, "tests", "golden", f"compact_H{Hh}.npz"))
+                    m = len(g["front"])
+                    of5, or5, oi5 = ob5.Oracle().solve_compact(Hh, pp[0][:m], pp[1][:m], pp[2][:m], nthreads=os.cpu_count() or 1)
+                    assert np.array_equal(of5, g["front"]) and np.array_equal(or5, g["rear"])   # (the checker IS dlib, bit for bit)
+                    fix[Hh] = (g["front"], g["rear"], oi5)
             for dt_name, dt_t, opt in (("f64", torch.float64, 0), ("f64_fast_capped", torch.float64, capi.PARAM_FAST_CAPPED),
                                        ("f32", torch.float32, 0)):
                 xv, xy, xp = (torch.from_numpy(z[perm]).to(dev, dtype=dt_t) for z in (mv, my, mp))
@@ -543,6 +633,29 @@ def main():
                         sm.solve_batch_compact_mixed(hz[perm], xv, xy, xp)
                     torch.cuda.synchronize()
                     c5[dt_name] = (time.perf_counter() - t1) / 5 * 1e3
+                    # parity of this very batch: the first 1 024 instances of every horizon's stream are the real-dlib
+                    # fixtures (tests/golden/compact_H*.npz) -- relative error histogram and iteration-count agreement per
+                    # horizon
+                    if fix:
+                        f5, r5, i5 = sm.solve_batch_compact_mixed(hz[perm], xv, xy, xp, want_iters=True)
+                        torch.cuda.synchronize()
+                        inv = np.empty_like(perm)
+                        inv[perm] = np.arange(len(perm))
+                        f5, r5, i5 = (z.cpu().numpy()[inv] for z in (f5, r5, i5))
+                        par = {}
+                        for bi, Hh in enumerate(Hs):
+                            gf5, gr5, gi5 = fix[Hh]
+                            m = len(gf5)
+                            sl5 = slice(bi * per, bi * per + m)
+                            bound = 22 * np.pi / 180
+                            rel = np.maximum(np.abs(f5[sl5].astype(np.float64) - gf5) / np.where(gf5 != 0, np.abs(gf5), bound),
+                                             np.abs(r5[sl5].astype(np.float64) - gr5) / np.where(gr5 != 0, np.abs(gr5), bound))
+                            par[f"N={Hh}"] = {"instances": int(m),
+                                              "rel_err_within": {str(t): float((rel <= t).mean()) for t in
+                                                                 (1e-2, 1e-3, 1e-4, 1e-5, 1e-6, 1e-7, 1e-8, 1e-9)},
+                                              "max_rel_err": float(rel.max()),
+                                              "iteration_counts_equal": float((i5[sl5] == gi5).mean())}
+                        c5.setdefault("vs_dlib_fixtures", {})[dt_name] = par
             c5["solves_per_s_f64"] = len(hz) / (c5["f64"] * 1e-3)
             c5["solves_per_s_f64_fast_capped"] = len(hz) / (c5["f64_fast_capped"] * 1e-3)
             out["config5"] = c5

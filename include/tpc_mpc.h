@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TPC_MPC_ABI_VERSION 4
+#define TPC_MPC_ABI_VERSION 5   /* 5 = 4 + new symbols only (the split-named sharded entries); 4 broke 3: tpc_mpc_params.reserved became .options and must be zero-initialised */
 
 typedef struct tpc_mpc_context* tpc_mpc_handle;
 
@@ -362,6 +362,14 @@ int tpc_mpc_group_begin(void);
 int tpc_mpc_group_end(void);
 /* The contiguous block of a batch of n_total that `rank` of `world` owns (blocks differ by <= 1). */
 int tpc_mpc_shard_range(int64_t n_total, int rank, int world, int64_t* first, int64_t* count);
+/* How a batch is split over the ranks (ABI 5).  BLOCK: rank r owns one contiguous block (tpc_mpc_shard_range).
+ * INTERLEAVED: rank r owns the instances i = r (mod world).  The iteration count of an instance is a function of its
+ * speed (dlib's lambda, mpc.h:116-123), so a batch that arrives SORTED by speed gives one rank of a block split all the
+ * 10 000-iteration instances; the interleaved split deals them round.  For iid inputs the two cost the same.
+ * tpc_mpc_shard_map: element j of rank's shard is instance first + j * stride, j < count. */
+#define TPC_MPC_SPLIT_BLOCK 0
+#define TPC_MPC_SPLIT_INTERLEAVED 1
+int tpc_mpc_shard_map(int64_t n_total, int rank, int world, int split, int64_t* first, int64_t* count, int64_t* stride);
 
 /* tpc_mpc_solve_batch_compact for this rank's block of a batch of n_total, then the all-gather:
  * v/delta_y/delta_phi_shard hold the block's `count` instances, steering_front_all / _rear_all are
@@ -374,6 +382,18 @@ int tpc_mpc_solve_batch_compact_sharded(tpc_mpc_handle h, const tpc_mpc_params* 
                                         const void* delta_phi_shard, void* steering_front_all,
                                         void* steering_rear_all, int32_t* iters_shard,
                                         uint32_t* flags_out, void* stream);
+
+/* The same with the split named (ABI 5).  TPC_MPC_SPLIT_BLOCK: exactly the call above.  TPC_MPC_SPLIT_INTERLEAVED: the shard
+ * arrays hold the rank's `count` instances compacted (element j = instance rank + j * world: the host scatters with a
+ * stride); the shard is solved into the rank's slot of a [world][ceil(n_total / world)] staging array owned by the
+ * handle, the slots are all-gathered there (equal sizes by construction: one ncclAllGather per output, no ragged form)
+ * and one kernel per output writes them back in INSTANCE order, so the full-size outputs look the same under either
+ * split -- bit for bit within one kernel family.  iters_shard [count] stays in shard order. */
+int tpc_mpc_solve_batch_compact_sharded_split(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n_total, int split,
+                                              const void* v_shard, const void* delta_y_shard,
+                                              const void* delta_phi_shard, void* steering_front_all,
+                                              void* steering_rear_all, int32_t* iters_shard,
+                                              uint32_t* flags_out, void* stream);
 
 /* No reference counterpart (the reference drives one dlib::mpc object on one device: src/trajectory_point_follower.cpp:366).
  * The general form sharded the same way: io_all describes the FULL batch (n = n_total, ld >= n_total, DEVICE memory;
@@ -392,6 +412,11 @@ int tpc_mpc_solve_batch_general_sharded(tpc_mpc_handle h, const tpc_mpc_params* 
  * (ncclAllGather when n_total divides evenly, otherwise one in-place ncclBroadcast per owner; one RCCL group).  A handle
  * without a communicator: a no-op. */
 int tpc_mpc_gather_shards(tpc_mpc_handle h, int64_t n_total, void* const* rows, int n_rows, int elem_bytes, void* stream);
+/* The same with the split named (ABI 5).  TPC_MPC_SPLIT_INTERLEAVED: on entry the FIRST `count` elements of each row are
+ * this rank's shard (element j = instance rank + j * world -- what an entry called on the compacted shard leaves when its
+ * output pointer is the row's base); on return the row holds all n_total elements in instance order. */
+int tpc_mpc_gather_shards_split(tpc_mpc_handle h, int64_t n_total, int split, void* const* rows, int n_rows, int elem_bytes,
+                                void* stream);
 
 /* ---- memory ------------------------------------------------------------------------------------ */
 

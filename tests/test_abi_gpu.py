@@ -176,7 +176,7 @@ def test_build_info_names_the_schedulers(torch_cuda):
     from trajectory_controller_amd import MpcSolver
     info = MpcSolver.build_info()
     print(info)
-    assert "abi 4" in info and all(f"h{h}[sched=default]" in info for h in (4, 5, 10, 20, 30, 40))
+    assert "abi 5" in info and all(f"h{h}[sched=default]" in info for h in (4, 5, 10, 20, 30, 40))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -275,6 +275,40 @@ def test_sharded_entry_through_rccl_world_of_one(torch_cuda, ragged):
     assert torch.equal(f, want[0]) and torch.equal(r, want[1])
 
 
+def test_interleaved_split_through_rccl_world_of_one(torch_cuda):
+    """tpc_mpc_solve_batch_compact_sharded_split / tpc_mpc_gather_shards_split with TPC_MPC_SPLIT_INTERLEAVED through a real
+    one-rank RCCL communicator: the shard is solved into the handle's staging array, all-gathered there and written back
+    in instance order by unpermute_kernel (a world of one: the identity, but every launch of the path runs); without a
+    communicator the shard is solved straight into the outputs.  Results = the plain solve; an unknown split is refused."""
+    from trajectory_controller_amd import MpcSolver, capi
+    from trajectory_controller_amd.synth import compact_inputs
+    torch = torch_cuda
+    H, n = 10, 4097
+    v, dy, dphi = (torch.from_numpy(a).cuda() for a in compact_inputs(H, n, first=23))
+    with _solver(H, "lane") as s:
+        want = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+        f0, r0 = s.solve_batch_compact_sharded(n, v, dy, dphi, split="interleaved")     # no communicator
+        assert s.shard_map(n, "interleaved") == (0, n, 1)
+        s.comm_test_mode(True, False)
+        s.comm_init(MpcSolver.comm_unique_id(), 0, 1)
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            f, r, it = s.solve_batch_compact_sharded(n, v, dy, dphi, split="interleaved", want_iters=True)
+            rows = torch.stack([want[0], want[1]]).clone()
+            s.gather_shards(n, rows, split="interleaved")
+            it2 = want[2].clone()
+            s.gather_shards(n, it2, split="interleaved")                                # 4-byte elements
+        stream.synchronize()
+        p = s._params()
+        import ctypes as C
+        with pytest.raises(capi.TpcMpcError):
+            s._check(s._lib.tpc_mpc_solve_batch_compact_sharded_split(s._h, C.byref(p), n, 2, v.data_ptr(), dy.data_ptr(),
+                                                                      dphi.data_ptr(), f.data_ptr(), r.data_ptr(), None, None, None))
+    for a, b in ((f0, want[0]), (r0, want[1]), (f, want[0]), (r, want[1]), (it, want[2]), (rows[0], want[0]), (rows[1], want[1]),
+                 (it2, want[2])):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("ragged", [False, True])
 def test_general_sharded_entry(torch_cuda, oracle, ragged):
     """tpc_mpc_solve_batch_general_sharded: a world of one without a communicator, then through a real one-rank RCCL
@@ -364,6 +398,25 @@ assert np.array_equal(bits(rear.numpy()[:1024]), bits(g["rear"])), "rear"
 with MpcSolver(horizon=H, device=0, algo="lane") as s:
     ff, rr = s.solve_batch_compact(v, dy, dphi)
 assert np.array_equal(bits(front.numpy()), bits(ff.cpu().numpy())) and np.array_equal(bits(rear.numpy()), bits(rr.cpu().numpy()))
+# a batch that arrives sorted by speed: the block split gives one rank the long instances, the interleaved one deals them
+# round (SURVEY.md section 8e); same bits in instance order under either, within one family
+o = torch.argsort(v)
+vs, ys, ps = v[o].contiguous(), dy[o].contiguous(), dphi[o].contiguous()
+with MpcSolver(horizon=H, device=0, algo="lane_fma") as s:
+    whole = s.solve_batch_compact(vs, ys, ps)
+    for split in ("block", "interleaved"):
+        tot = []
+        def solve2(a, b, c):
+            f, r, it = s.solve_batch_compact(a, b, c, want_iters=True)
+            tot.append(int(it.sum()))
+            return f.cpu(), r.cpu()
+        f2, r2 = solve_sharded(solve2, vs, ys, ps, split=split)
+        assert np.array_equal(bits(f2.numpy()), bits(whole[0].cpu().numpy())) and np.array_equal(bits(r2.numpy()), bits(whole[1].cpu().numpy())), split
+        t = torch.tensor([tot[0]], dtype=torch.int64)
+        both = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(both, t)
+        ratio = max(int(b) for b in both) / min(int(b) for b in both)
+        assert (ratio > 2.0) if split == "block" else (ratio < 1.05), (split, ratio)
 print("rank", rank, "of", world, "ok", shard_range(n, rank, world))
 open(os.path.join(os.path.dirname(os.path.abspath(__file__)), f"rank{{rank}}.ok"), "w").write("ok")   # (the two ranks' prints can interleave)
 dist.destroy_process_group()

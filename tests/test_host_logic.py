@@ -27,7 +27,7 @@ def test_library_exports_whole_abi():
     out = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH], text=True)
     exported = set(re.findall(r" T (tpc_mpc_[a-z_0-9]+)", out))
     assert set(decl) <= exported
-    assert lib.tpc_mpc_abi_version() == capi.ABI_VERSION == 4
+    assert lib.tpc_mpc_abi_version() == capi.ABI_VERSION == 5
 
 
 def test_header_is_plain_c(tmp_path):
@@ -118,6 +118,85 @@ def test_shard_ranges_cover():
             assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
 
 
+def test_shard_maps_cover():
+    """tpc_mpc_shard_map (C ABI) and shard.shard_slice agree, and each split's shards partition the batch."""
+    import ctypes as C
+    from trajectory_controller_amd import capi
+    from trajectory_controller_amd.shard import shard_slice
+    lib = capi.load_library()
+    for n in (0, 1, 7, 64, 1001, 4096):
+        for world in (1, 2, 3, 5, 8):
+            for name, split in capi.SPLITS.items():
+                seen = np.zeros(n, dtype=np.int32)
+                for rank in range(world):
+                    first, count, stride = C.c_int64(), C.c_int64(), C.c_int64()
+                    assert lib.tpc_mpc_shard_map(n, rank, world, split, C.byref(first), C.byref(count), C.byref(stride)) == capi.OK
+                    idx = first.value + stride.value * np.arange(count.value)
+                    assert np.array_equal(idx, np.arange(n)[shard_slice(n, rank, world, name)])
+                    seen[idx] += 1
+                assert np.all(seen == 1)
+    assert lib.tpc_mpc_shard_map(10, 2, 2, 0, C.byref(first), C.byref(count), C.byref(stride)) == 1   # TPC_MPC_ERR_BAD_ARG
+    assert lib.tpc_mpc_shard_map(10, 0, 2, 7, C.byref(first), C.byref(count), C.byref(stride)) == 1   # TPC_MPC_ERR_BAD_ARG
+
+
+def test_exchange_plan_on_a_host_communicator():
+    """The slot arithmetic of the sharded entries for 2..8 owners, without a GPU: tpc_mpc_x_exchange_plan hands out the very
+    list of collectives tpc_mpc_solve_batch_compact_sharded_split / tpc_mpc_gather_shards_split issue for one output row
+    (the same function feeds their RCCL calls); here a host-memory communicator executes it for every rank at once --
+    equal blocks (in-place all-gather), ragged blocks (one in-place broadcast per owner, also forced on sizes that divide),
+    and the interleaved split's staged all-gather followed by the un-permutation."""
+    import ctypes as C
+    from trajectory_controller_amd import capi
+    lib = capi.load_library()
+    for world in range(2, 9):
+        for n in (1, world - 1, world, 7 * world, 7 * world + 3, 1001, 4096):
+            for split in (capi.SPLIT_BLOCK, capi.SPLIT_INTERLEAVED):
+                for ragged in (0, 1):
+                    plans, bufs = [], []
+                    for rank in range(world):
+                        ops = (C.c_int64 * (5 * 64))()
+                        blen = C.c_int64()
+                        k = lib.tpc_mpc_x_exchange_plan(n, world, rank, split, ragged, ops, 64, C.byref(blen))
+                        assert 0 < k <= 64
+                        plans.append(np.array(ops[:5 * k], dtype=np.int64).reshape(k, 5))
+                        first, count, stride = C.c_int64(), C.c_int64(), C.c_int64()
+                        lib.tpc_mpc_shard_map(n, rank, world, split, C.byref(first), C.byref(count), C.byref(stride))
+                        mine = first.value + stride.value * np.arange(count.value)     # the instances this rank solved
+                        buf = np.full(blen.value, -1, dtype=np.int64)
+                        if split == capi.SPLIT_BLOCK:
+                            buf[mine] = mine                                            # its slot of the full-size row
+                        else:
+                            cap = blen.value // world
+                            buf[rank * cap: rank * cap + count.value] = mine            # its slot of the staging array
+                        bufs.append(buf)
+                    assert all(len(pl) == len(plans[0]) for pl in plans)               # a collective needs every rank
+                    for i in range(len(plans[0])):
+                        kind = plans[0][i, 0]
+                        assert all(pl[i, 0] == kind for pl in plans)
+                        if kind == 0:       # all-gather: rank q's `count` elements land at recv_off + q * count everywhere
+                            cnt = plans[0][i, 4]
+                            assert all(pl[i, 4] == cnt and pl[i, 3] == plans[0][i, 3] for pl in plans)
+                            parts = [bufs[q][plans[q][i, 2]: plans[q][i, 2] + cnt].copy() for q in range(world)]
+                            for q in range(world):
+                                for src in range(world):
+                                    ro = plans[q][i, 3] + src * cnt
+                                    bufs[q][ro: ro + cnt] = parts[src]
+                        else:               # broadcast from root, in place
+                            root, so, ro, cnt = plans[0][i, 1:5]
+                            assert all(tuple(pl[i, 1:5]) == (root, so, ro, cnt) for pl in plans)
+                            data = bufs[root][so: so + cnt].copy()
+                            for q in range(world):
+                                bufs[q][ro: ro + cnt] = data
+                    for q in range(world):
+                        if split == capi.SPLIT_BLOCK:
+                            out = bufs[q]
+                        else:               # unpermute_kernel: out[i] = stage[(i mod world) * cap + i // world]
+                            cap = len(bufs[q]) // world
+                            i_ = np.arange(n)
+                            out = bufs[q][(i_ % world) * cap + i_ // world]
+                        assert np.array_equal(out, np.arange(n)), (world, n, split, ragged, q)
+
+
 _GLOO_WORKER = r'''
 import os, sys
 sys.path.insert(0, {root!r})
@@ -154,6 +233,61 @@ def test_sharded_solve_world2_gloo(tmp_path):
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+_GLOO_SKEW_WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from oracle.bindings import Oracle            # the checker stands in for the GPU solve here (tests only)
+from trajectory_controller_amd.shard import solve_sharded
+from trajectory_controller_amd.synth import compact_inputs
+dist.init_process_group("gloo")
+H, n = 10, 2001
+v, dy, dphi = compact_inputs(H, n)
+o = np.argsort(v)                              # a host that hands over its batch SORTED BY SPEED
+v, dy, dphi = (torch.from_numpy(np.ascontiguousarray(a[o])) for a in (v, dy, dphi))
+orc = Oracle()
+ef, er, _ = orc.solve_compact(H, v.numpy(), dy.numpy(), dphi.numpy())
+work = {{}}
+for split in ("block", "interleaved"):
+    def solve(a, b, c):
+        f, r, it = orc.solve_compact(H, a.numpy(), b.numpy(), c.numpy())
+        work[split] = int(it.sum())            # the rank's iteration total = its solve time on a GPU
+        return torch.from_numpy(f), torch.from_numpy(r)
+    front, rear = solve_sharded(solve, v, dy, dphi, split=split)
+    assert np.array_equal(front.numpy(), ef) and np.array_equal(rear.numpy(), er), split   # instance order, same bits
+    t = torch.tensor([work[split]], dtype=torch.int64)
+    both = [torch.zeros_like(t) for _ in range(2)]
+    dist.all_gather(both, t)
+    a, b = int(both[0]), int(both[1])
+    ratio = max(a, b) / min(a, b)
+    if dist.get_rank() == 0:
+        print(split, "iteration totals per rank", a, b, "max/min %.3f" % ratio)
+    if split == "block":
+        assert ratio > 2.0, ratio              # one rank gets the slow half
+    else:
+        assert ratio < 1.05, ratio
+print("rank", dist.get_rank(), "ok")
+dist.destroy_process_group()
+'''
+
+
+def test_interleaved_split_balances_a_speed_sorted_batch_world2_gloo(tmp_path):
+    """SURVEY.md section 8e: the iteration count is a function of the speed, so a block split of a speed-sorted batch is
+    > 2x out of balance; the interleaved split is within 5 %, and both return the same bits in instance order."""
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_SKEW_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", GLOO_SOCKET_IFNAME="lo")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 2 and "interleaved iteration totals" in out.stdout
 
 
 def test_examples_compile_as_c99(tmp_path):

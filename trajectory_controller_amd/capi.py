@@ -24,7 +24,7 @@ PARAM_FAST_CAPPED = 0x1   # tpc_mpc_params.options
 
 STATUS_NAMES = {0: "OK", 1: "BAD_ARG", 2: "BAD_WEIGHTS", 3: "BAD_BOUNDS", 4: "BAD_HORIZON",
                 5: "BAD_EPS", 6: "NO_DEVICE", 7: "HIP", 8: "ALLOC", 9: "COMM"}
-ABI_VERSION = 4
+ABI_VERSION = 5
 COMM_ID_BYTES = 128
 
 # every symbol include/tpc_mpc.h declares
@@ -37,7 +37,10 @@ EXPORTS = ("tpc_mpc_default_params", "tpc_mpc_create", "tpc_mpc_destroy", "tpc_m
            "tpc_mpc_follow_batch_horizon", "tpc_mpc_comm_unique_id", "tpc_mpc_comm_init_rank",
            "tpc_mpc_comm_destroy", "tpc_mpc_group_begin", "tpc_mpc_group_end", "tpc_mpc_shard_range",
            "tpc_mpc_solve_batch_compact_sharded", "tpc_mpc_comm_test_mode",
-           "tpc_mpc_solve_batch_general_sharded", "tpc_mpc_last_flags", "tpc_mpc_gather_shards")
+           "tpc_mpc_solve_batch_general_sharded", "tpc_mpc_last_flags", "tpc_mpc_gather_shards",
+           "tpc_mpc_shard_map", "tpc_mpc_solve_batch_compact_sharded_split", "tpc_mpc_gather_shards_split")
+SPLIT_BLOCK, SPLIT_INTERLEAVED = 0, 1
+SPLITS = {"block": SPLIT_BLOCK, "interleaved": SPLIT_INTERLEAVED}
 
 
 class Params(C.Structure):
@@ -139,6 +142,12 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.tpc_mpc_shard_range.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.tpc_mpc_solve_batch_compact_sharded.argtypes = [vp, C.POINTER(Params), C.c_int64, vp, vp, vp, vp, vp, vp,
                                                         u32p, vp]
+    i64p = C.POINTER(C.c_int64)
+    lib.tpc_mpc_shard_map.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, i64p, i64p, i64p]
+    lib.tpc_mpc_solve_batch_compact_sharded_split.argtypes = [vp, C.POINTER(Params), C.c_int64, C.c_int, vp, vp, vp, vp, vp, vp,
+                                                              u32p, vp]
+    lib.tpc_mpc_gather_shards_split.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, vp]
+    lib.tpc_mpc_x_exchange_plan.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, i64p, C.c_int, i64p]   # experimental
     for name in EXPORTS:
         getattr(lib, name)   # raises AttributeError if the library lacks a declared entry point
     if path == LIB_PATH:

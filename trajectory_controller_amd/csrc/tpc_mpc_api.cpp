@@ -664,6 +664,7 @@ int tpc_mpc_destroy(tpc_mpc_handle h) {
         if (h->roll) (void)hipFree(h->roll);
         if (h->cap_iters) (void)hipFree(h->cap_iters);
         if (h->mix) (void)hipFree(h->mix);
+        if (h->gather) (void)hipFree(h->gather);
         if (h->hint_own) (void)hipFree(h->hint_own);
         if (h->pin_host) (void)hipHostFree(h->pin_host);
         if (h->done_ev) (void)hipEventDestroy(h->done_ev);

@@ -74,6 +74,8 @@ struct tpc_mpc_context {
     bool have_last = false;
     // sharded solves (tpc_mpc_comm.cpp); null = a world of one
     tpc::Comm* comm = nullptr;
+    void* gather = nullptr;          // [world][cap] staging of the interleaved split's exchange
+    int64_t gather_bytes = 0;
     bool comm_test_force = false, comm_test_ragged = false;   // tpc_mpc_comm_test_mode
     // mixed-horizon batches run their bins concurrently: one child handle (scratch of its own) and one stream
     // per bin, forked from and joined back into the caller's stream (tpc_mpc_mixed.hip)

@@ -30,6 +30,15 @@ int tpc_mpc_x_set_group_share(tpc_mpc_handle h, int waves, int cu_count);
  * (scripts/lanex_crossover.py). */
 int tpc_mpc_x_set_lanex_below(tpc_mpc_handle h, int64_t below);
 
+/* The collectives tpc_mpc_solve_batch_compact_sharded_split / tpc_mpc_gather_shards_split issue for ONE output row, as data:
+ * ops5[5 * i + 0..4] = kind (0 all-gather: every rank sends `count` elements at send_off and receives world * count at
+ * recv_off; 1 in-place broadcast of [send_off, +count) from `root`), root, send_off, recv_off, count -- offsets in elements
+ * of the exchanged buffer, which is the full-size row (block split) or the [world][ceil(n / world)] staging array
+ * (interleaved split; *buffer_elems says how long).  Returns the number of operations (-1: bad arguments).  No device, no
+ * RCCL: it lets the CPU suite execute the slot arithmetic of all `world` owners with a host-memory communicator. */
+int tpc_mpc_x_exchange_plan(int64_t n_total, int world, int rank, int split, int force_ragged, int64_t* ops5, int max_ops,
+                            int64_t* buffer_elems);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,9 +20,23 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     return first, count
 
 
-def solve_sharded(solve_fn: Callable, v, delta_y, delta_phi, group=None):
+def shard_slice(n_total: int, rank: int, world: int, split: str = "block") -> slice:
+    """The instances rank owns, as a slice of the batch: one contiguous block ("block"), or every world-th instance from
+    `rank` on ("interleaved": SURVEY.md section 8e names it first -- the iteration count of an instance is a function of
+    its speed, so a batch that arrives sorted by speed would give one rank of a block split all the long instances)."""
+    if split == "block":
+        first, count = shard_range(n_total, rank, world)
+        return slice(first, first + count)
+    if split != "interleaved":
+        raise ValueError("split is 'block' or 'interleaved'")
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    return slice(rank, n_total, world)
+
+
+def solve_sharded(solve_fn: Callable, v, delta_y, delta_phi, group=None, split: str = "block"):
     """Solve the FULL batch (every rank holds the same full input tensors) by sharding it over the
-    ranks of `group`, then all-gather the outputs so every rank returns the full (front, rear).
+    ranks of `group`, then all-gather the outputs so every rank returns the full (front, rear) in instance order.
 
     solve_fn(v, dy, dphi) -> (front, rear) on tensors of one shard (e.g. MpcSolver.solve_batch_compact).
     """
@@ -32,13 +46,13 @@ def solve_sharded(solve_fn: Callable, v, delta_y, delta_phi, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = v.numel()
-    first, count = shard_range(n, rank, world)
-    sl = slice(first, first + count)
+    sl = shard_slice(n, rank, world, split)
     f, r = solve_fn(v[sl].contiguous(), delta_y[sl].contiguous(), delta_phi[sl].contiguous())
     if world == 1:
         return f, r
-    # ragged shards: pad to the largest block so one all_gather_into_tensor moves everything
-    cap = shard_range(n, 0, world)[1]
+    count = f.numel()
+    # ragged shards: pad to the largest one so one all_gather_into_tensor moves everything
+    cap = (n + world - 1) // world
     mine = torch.zeros((2, cap), dtype=f.dtype, device=f.device)
     mine[0, :count] = f
     mine[1, :count] = r
@@ -47,7 +61,8 @@ def solve_sharded(solve_fn: Callable, v, delta_y, delta_phi, group=None):
     front = torch.empty(n, dtype=f.dtype, device=f.device)
     rear = torch.empty(n, dtype=f.dtype, device=f.device)
     for q in range(world):
-        qf, qc = shard_range(n, q, world)
-        front[qf:qf + qc] = allo[q, 0, :qc]
-        rear[qf:qf + qc] = allo[q, 1, :qc]
+        qs = shard_slice(n, q, world, split)
+        qc = len(range(*qs.indices(n)))
+        front[qs] = allo[q, 0, :qc]
+        rear[qs] = allo[q, 1, :qc]
     return front, rear

@@ -253,14 +253,17 @@ class MpcSolver:
         self.rank, self.world = int(rank), int(world)
 
     def solve_batch_compact_sharded(self, n_total: int, v_shard, dy_shard, dphi_shard, out=None,
-                                    want_iters: bool = False, want_flags: bool = False, **over):
-        """This rank's block of a batch of n_total, then the all-gather of the control outputs over
-        RCCL (tpc_mpc_solve_batch_compact_sharded).  Device tensors; returns full-size (front, rear)."""
+                                    want_iters: bool = False, want_flags: bool = False, split: str = "block", **over):
+        """This rank's shard of a batch of n_total, then the all-gather of the control outputs over RCCL
+        (tpc_mpc_solve_batch_compact_sharded_split).  split "block": the shard is the contiguous block of shard_range;
+        "interleaved": instances rank, rank + world, ... compacted (shard_map).  Device tensors; returns full-size
+        (front, rear) in instance order under either split."""
         import torch
         p = self._params(**over)
         tdt = torch.float64 if p.dtype == capi.F64 else torch.float32
-        first, count = C.c_int64(), C.c_int64()
-        self._lib.tpc_mpc_shard_range(int(n_total), self.rank, self.world, C.byref(first), C.byref(count))
+        first, count, stride = C.c_int64(), C.c_int64(), C.c_int64()
+        self._lib.tpc_mpc_shard_map(int(n_total), self.rank, self.world, capi.SPLITS[split], C.byref(first), C.byref(count),
+                                    C.byref(stride))
         for t in (v_shard, dy_shard, dphi_shard):
             if not (t.is_cuda and t.dtype == tdt and t.is_contiguous() and t.numel() == count.value):
                 raise ValueError(f"shard arrays must be contiguous CUDA tensors of the solver dtype holding this "
@@ -273,8 +276,8 @@ class MpcSolver:
         iters = torch.empty(v_shard.numel(), dtype=torch.int32, device=v_shard.device) if want_iters else None
         flags = C.c_uint32(0)
         stream = torch.cuda.current_stream(v_shard.device).cuda_stream
-        self._check(self._lib.tpc_mpc_solve_batch_compact_sharded(
-            self._h, C.byref(p), int(n_total), v_shard.data_ptr(), dy_shard.data_ptr(), dphi_shard.data_ptr(),
+        self._check(self._lib.tpc_mpc_solve_batch_compact_sharded_split(
+            self._h, C.byref(p), int(n_total), capi.SPLITS[split], v_shard.data_ptr(), dy_shard.data_ptr(), dphi_shard.data_ptr(),
             front.data_ptr(), rear.data_ptr(), iters.data_ptr() if want_iters else None,
             C.byref(flags) if want_flags else None, C.c_void_p(stream)))
         self.last_flags = flags.value
@@ -286,10 +289,18 @@ class MpcSolver:
         self._lib.tpc_mpc_shard_range(int(n_total), self.rank, self.world, C.byref(first), C.byref(count))
         return first.value, count.value
 
-    def gather_shards(self, n_total: int, *rows):
+    def shard_map(self, n_total: int, split: str = "block"):
+        """(first, count, stride): element j of this rank's shard is instance first + j * stride (tpc_mpc_shard_map)."""
+        first, count, stride = C.c_int64(), C.c_int64(), C.c_int64()
+        self._lib.tpc_mpc_shard_map(int(n_total), self.rank, self.world, capi.SPLITS[split], C.byref(first), C.byref(count),
+                                    C.byref(stride))
+        return first.value, count.value, stride.value
+
+    def gather_shards(self, n_total: int, *rows, split: str = "block"):
         """The exchange by itself, for any other entry a host shards (mixed horizons, follow, rollout): `rows` are FULL-size
         1-D CUDA tensors (or the rows of 2-D ones) of n_total elements of 4 or 8 bytes each, of which this rank has written
-        its block [first, first + count) -- afterwards every rank holds all of every row (tpc_mpc_gather_shards)."""
+        its block [first, first + count) -- afterwards every rank holds all of every row (tpc_mpc_gather_shards_split).
+        split "interleaved": the rank's shard sits compacted in the row's first `count` elements instead."""
         import torch
         flat = []
         for t in rows:
@@ -303,7 +314,8 @@ class MpcSolver:
             raise ValueError("one call exchanges rows of one element size")
         table = (C.c_void_p * len(flat))(*[r.data_ptr() for r in flat])
         stream = torch.cuda.current_stream(flat[0].device).cuda_stream
-        self._check(self._lib.tpc_mpc_gather_shards(self._h, int(n_total), table, len(flat), es, C.c_void_p(stream)))
+        self._check(self._lib.tpc_mpc_gather_shards_split(self._h, int(n_total), capi.SPLITS[split], table, len(flat), es,
+                                                          C.c_void_p(stream)))
 
     def solve_batch_general_sharded(self, A, B, Cc, Q, R, lower, upper, x0, targets, inputs: Optional[int] = None,
                                     want_iters: bool = False, **over):

@@ -135,3 +135,44 @@ def test_solve_one_capped(torch_cuda, oracle):
             f, r = s.solve_one([2.0, 50.0][k], [-0.2, 0.3][k], [0.1, 0.2][k])
             assert s.last_solve_one_flags() == (FLAG_MAX_ITER, 200) and oit[k] == 200
             assert bits_equal([f, r], [of[k], orr[k]])
+
+
+def _lambda(H, v, T=0.1, l=0.21, q=(20.0, 7.0), r=(0.0005, 10.0)):
+    """dlib's trace bound (mpc.h:116-123) for the compact model, on the host: what AUTO's presolve predicts from"""
+    out = np.empty(len(v))
+    for i, x in enumerate(v):
+        a, c = T * x, T * x / l
+        A = np.array([[1.0, a], [0.0, 1.0]])
+        B = np.array([[0.0, a], [c, -c]])
+        lam, Tm = (r[0] + r[1]) * H, np.diag(q).astype(float)
+        for _ in range(H):
+            P = B.T @ Tm @ B
+            lam += P[0, 0] + P[1, 1]
+            Tm = A.T @ Tm @ A + np.diag(q)
+        out[i] = lam
+    return out
+
+
+@pytest.mark.parametrize("eps, expect_missed, expect_spare", [(0.01, False, True), (1e-5, True, False), (0.5, False, True)])
+def test_presolve_prediction_wrong_in_both_directions(torch_cuda, oracle, eps, expect_missed, expect_spare):
+    """AUTO's presolve (tpc_mpc_api.cpp: presolve_begin) takes the instances with lambda >= (max_iter / 7)^2 to the
+    bit-exact kernels BEFORE the tolerance family runs, on a side stream.  That is a prediction: with dlib's eps it names
+    every capped instance of the N = 40 stream and some that converge after all (spare); with a tiny eps far more instances
+    cap than it names (missed: the flag-driven second pass must catch them); with a huge eps nothing caps and everything it
+    took is spare.  In every case: each capped instance and each instance the prediction took comes back with dlib's
+    BITS, every other one within 1e-9, every iteration count equal -- the same outcome as before the presolve existed."""
+    from trajectory_controller_amd import FLAG_MAX_ITER
+    from trajectory_controller_amd.synth import compact_inputs
+    H, n, max_iter = 40, 4096, 10000
+    v, dy, dphi = compact_inputs(H, n, first=4242)
+    of, orr, oit = oracle.solve_compact(H, v, dy, dphi, nthreads=8, eps=eps, max_iter=max_iter)
+    capped = oit == max_iter
+    taken = _lambda(H, v) >= (max_iter / 7.0) ** 2
+    assert taken.sum() > 100
+    assert bool((capped & ~taken).any()) == expect_missed and bool((taken & ~capped).any()) == expect_spare
+    f, r, it, flags = _solve(torch_cuda, H, v, dy, dphi, expect=GROUP, eps=eps, max_iter=max_iter)
+    assert np.array_equal(it, oit)
+    exact = capped | (taken & (oit > 50))   # (what stops inside the coordinate-descent phase is not queued by either pass)
+    assert bits_equal(f[exact], of[exact]) and bits_equal(r[exact], orr[exact])
+    assert max(np.abs(f - of).max(), np.abs(r - orr).max()) <= 1e-9
+    assert bool(flags & FLAG_MAX_ITER) == bool(capped.any())

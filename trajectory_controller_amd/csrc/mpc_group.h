@@ -97,12 +97,8 @@ template <typename T, int H, int G> struct GroupPlan {
     // 262 144 x N = 20: G = 2 6.24 -> 4.56 ms, N = 40: G = 4 53.0 -> 34.3; three and four per SIMD spill at N >= 30.
     static constexpr int occ = TPC_GROUP_OCC > 0 ? TPC_GROUP_OCC : (sizeof(T) == 4 ? TPC_GROUP_OCC_F32 : 1);
 };
-#ifdef TPC_GROUP_REFILL_BATCH
-template <int G> struct GroupRefillBatch { static constexpr int value = TPC_GROUP_REFILL_BATCH; };
-#else
 // groups that wait for an instance before a refill pass is worth leaving the loop for
 template <int G> struct GroupRefillBatch { static constexpr int value = G >= 8 ? 1 : 2; };
-#endif
 
 // MOVED (fp32 only; fp64 always reads its stop test off the projected step): true = min(|g df|, |x - x_new|) where the
 // coordinate-descent kernel's second screen (ub::moved_stop_ok, stats[2] bit 1) allows it, false = dlib's mask as

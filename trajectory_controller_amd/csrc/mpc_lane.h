@@ -147,21 +147,29 @@ template <typename T, int H> struct CdOcc {
 // solves them once more here and in lane_pg_fused_kernel, in dlib's own operation order, and publishes dlib's bits
 // (tpc_mpc_api.cpp, wants_cap_resolve).  With the gate closed -- the usual case -- every wavefront leaves at once, the
 // queue stays empty and the projected-gradient kernels return on their first look at it.
-template <typename T, int I, int H, class Model, class Args, bool RESOLVE = false>
+//
+// SUBSET 2 (PRESOLVE) picks by PREDICTION instead: the instances whose lambda (mpc.h:116-123) is at least `lambda_from` --
+// the iteration count grows like 5.5 sqrt(lambda), so lambda >= (max_iter / 7)^2 names the instances that will end on
+// the cap (tpc_mpc_api.cpp, presolve_lambda) -- are queued BEFORE any tolerance family has run, so that their 10 000
+// bit-exact iterations run beside that family's pass instead of behind it.  SUBSET 1 then skips what SUBSET 2 took
+// (the same comparison on the same lambda).
+template <typename T, int I, int H, class Model, class Args, int SUBSET = 0>
 __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args g, Knobs kn, T* __restrict__ recs,
                                                          uint32_t* __restrict__ keys,
                                                          uint32_t* __restrict__ key_rank,
                                                          uint32_t* __restrict__ key_hist,
                                                          unsigned long long* __restrict__ stats,
                                                          int publish_finished, const int32_t* __restrict__ select = nullptr,
-                                                         const uint32_t* __restrict__ gate = nullptr) {
+                                                         const uint32_t* __restrict__ gate = nullptr, T lambda_from = (T)0,
+                                                         const uint32_t* __restrict__ pre_len = nullptr, uint32_t pre_limit = 0u) {
+    constexpr bool RESOLVE = SUBSET != 0;
     constexpr int RL = LaneRec<T, H>::kLen;
     __shared__ T s_qd[2 * H][kWave];   // Q_diag[i](j) of lane l at s_qd[2*i + j][l]
     __shared__ T s_mm[2 * H][kWave];   // MM[i](j)
     const int lane = threadIdx.x;
     const int64_t k = (int64_t)blockIdx.x * kWave + lane;
     if (k >= g.n) return;   // no barriers below: a partial last wave just runs with fewer lanes
-    if constexpr (RESOLVE) {
+    if constexpr (SUBSET == 1) {
         if ((__builtin_nontemporal_load(gate) & 0x2u) == 0u) return;      // nothing ended on the cap: the usual case
         if (select[k] != (int32_t)kn.max_iter) return;
     }
@@ -174,6 +182,10 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void lane_cd_kernel(Args 
     T u[2 * H], w[2 * H];
     LaneIO<T, I, H, Args>::init_controls(g, k, u);
     const T lambda = ctor_lambda_qdiag<T, I, H>(m, [&](int i, int j, T val) { s_qd[2 * i + j][lane] = val; });
+    if constexpr (SUBSET == 1) {   // solved ahead by SUBSET 2 -- unless that queue grew past what its kernel takes (mpc_lanex.h, SOLO)
+        if (lambda_from > (T)0 && lambda >= lambda_from && __builtin_nontemporal_load(pre_len) <= pre_limit) return;
+    }
+    if constexpr (SUBSET == 2) { if (!(lambda >= lambda_from)) return; }
     T mm_max = (T)0;
     bool mm_nan = false;   // fmax drops a NaN operand: a NaN element of the linear term is tracked on its own
     linear_term<T, I, H>(m, w, [&](int q, T val) { s_mm[q][lane] = val; mm_max = tmax(mm_max, tabs(val)); mm_nan = mm_nan || val != val; });
@@ -509,17 +521,9 @@ template <int N, class F> TPC_DEV void static_for(F&& f) { static_for_impl(f, st
 // pass costs about 4 us whatever the horizon, an iteration 0.2 us at H = 4 and 2.4 us at H = 20, so
 // short horizons batch more.  Measured optima (PG kernel, n = 262 144): H = 4: 1.09 ms at 2, 0.27 ms
 // at 24-48; H = 5: 0.34 ms at 24; H = 10: flat from 3 to 8; H = 20: 10.24 ms at 2, 9.82 at 3-4.
-#ifdef TPC_REFILL_BATCH   // A/B override
-template <int H> struct RefillBatch { static constexpr int value = TPC_REFILL_BATCH; };
-#else
 template <int H> struct RefillBatch { static constexpr int value = H <= 5 ? 24 : (H <= 10 ? 6 : 3); };
-#endif
-#ifdef TPC_EXIT_EVERY_STOP   // A/B override (0 / 1)
-template <typename T, int H> struct ExitEveryStop { static constexpr bool value = TPC_EXIT_EVERY_STOP != 0; };
-#else
 // measured per kernel (scripts/ab_many.sh, both forms at every horizon and dtype)
 template <typename T, int H> struct ExitEveryStop { static constexpr bool value = (sizeof(T) == 8 && H == 20) || (sizeof(T) == 4 && H == 30); };
-#endif
 // fp32 at H = 30 / 40 keeps everything in registers as well (240 / 320 of them), at one wave per SIMD: without
 // the LDS round trips of MM and v the kernels run 29.6 -> 26.0 ms (H = 30) and 73.6 -> 67.4 ms (H = 40) per
 // 262 144 instances.
@@ -646,11 +650,7 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
     // exactly when u sits on a bound with df pushing outward (mpc.h:298-299), or when the step
     // vanishes in rounding, which the screen allows only for |df| < eps.  So
     // min(|df|, |u - v_new| * 2^600) is >= eps exactly where dlib's masked |df| is.
-#ifdef TPC_STOP_OLD   // A/B: the two-fma form for fp64 too
-    constexpr bool MOVED = false;
-#else
     constexpr bool MOVED = FAST && sizeof(T) == 8;
-#endif
     constexpr T kHuge = (T)(sizeof(T) == 8 ? 0x1p600 : 0x1p100);
     T nlo_h[2] = {(T)0, (T)0}, hi_h[2] = {(T)0, (T)0};
     // ... and the factor in VGPRs: a VOP3 instruction reads one SGPR operand at most, and with both
@@ -784,10 +784,7 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
         }
         // ---- backward pass fused with the stop test and the speculative update
         u0_prev[0] = u[0]; u0_prev[1] = u[1];
-#ifndef TPC_ACC_N
-#define TPC_ACC_N 4
-#endif
-        constexpr int NA = TPC_ACC_N;   // independent max accumulators (max is exact: any split gives dlib's value)
+        constexpr int NA = 4;   // independent max accumulators (max is exact: any split gives dlib's value)
         T acc[NA];
 #pragma unroll
         for (int z = 0; z < NA; ++z) acc[z] = (T)0;
@@ -803,9 +800,7 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
                     pv[nxt][j] = v_get(2 * (i - 1) + j);
                 });
             }
-#ifndef TPC_NO_SCHED_BARRIER
             __builtin_amdgcn_sched_barrier(0);
-#endif
             if constexpr (CK) {
                 static_assert(!CK || H % 2 == 0, "checkpoints sit on the even steps");
                 if constexpr (i < H - 1) {
@@ -860,9 +855,7 @@ __global__ __launch_bounds__((64 * FusedOcc<T, H>::value), (FusedOcc<T, H>::valu
                 }
                 if constexpr (!MOVED) vn[j] = clamp3_fast<FAST>(uu - inv_lambda * dd, m.lo(j), m.hi(j));   // mpc.h:342
                 u[q] = clamp3_fast<FAST>(vn[j] + beta * (vn[j] - pv[cur][j]), m.lo(j), m.hi(j));   // mpc.h:343
-#ifndef TPC_NO_UPIN
                 asm volatile("" : "+v"(u[q]));   // keep the update in its step (LLVM would sink it)
-#endif
             });
             static_for<I>([&](auto jc) {   // adjacent stores: one ds_write2st64 per step
                 constexpr int j = decltype(jc)::value;

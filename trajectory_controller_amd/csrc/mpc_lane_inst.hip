@@ -154,8 +154,12 @@ hipError_t run(const Args& a, const Knobs& k, const Workspace& ws, hipStream_t s
 // The instances of a batch that ended on the iteration cap, once more in dlib's own arithmetic: lane_cd_kernel
 // (RESOLVE) leaves their records and queues them, the fused projected-gradient kernel finishes them.  `gate` closed
 // (no instance on the cap): one 32-byte memset and two kernels that leave at once.
-template <typename T, int I, class Model, class Args>
-hipError_t resolve(const Args& a, const Knobs& k, const Workspace& ws, const int32_t* select, const uint32_t* gate, hipStream_t s) {
+//
+// SUBSET 2 (presolve): the same two kernels BEFORE the tolerance family's pass, on a stream of their own, for the instances
+// lambda predicts to end on the cap (lane_cd_kernel); SUBSET 1 then leaves those out.
+template <typename T, int I, class Model, class Args, int SUBSET = 1>
+hipError_t resolve(const Args& a, const Knobs& k, const Workspace& ws, const int32_t* select, const uint32_t* gate, hipStream_t s,
+                   double lambda_from = 0.0, const uint32_t* pre_len = nullptr, uint32_t pre_limit = 0u) {
     if (a.n <= 0) return hipSuccess;
     T* recs = (T*)ws.state;
     // ticket, queue length and statistics of this stage sit side by side (resolve_workspace, tpc_mpc_api.cpp): one memset
@@ -163,13 +167,19 @@ hipError_t resolve(const Args& a, const Knobs& k, const Workspace& ws, const int
     hipError_t e = hipMemsetAsync(ws.ticket, 0, 32, s);
     if (e != hipSuccess) return e;
     const int grid = (int)((a.n + kWave - 1) / kWave);
-    hipLaunchKernelGGL((lane_cd_kernel<T, I, kH, Model, Args, true>), dim3(grid), dim3(kWave), 0, s, a, k, recs, ws.order,
-                       (uint32_t*)nullptr, queue_len, ws.stats, 1, select, gate);
+    hipLaunchKernelGGL((lane_cd_kernel<T, I, kH, Model, Args, SUBSET>), dim3(grid), dim3(kWave), 0, s, a, k, recs, ws.order,
+                       (uint32_t*)nullptr, queue_len, ws.stats, 1, select, gate, (T)lambda_from, pre_len, pre_limit);
     if constexpr (std::is_same<Model, CompactModel<T>>::value && sizeof(T) == 8 && LanexPlan<kH>::built) {
         // compact form, N = 10, 20, 40: G lanes per instance, the chains handed from chunk to chunk (mpc_lanex.h) -- the
         // same bits at a third of the iteration's time
         constexpr int ng = LanexPlan<kH>::NG;
         const int64_t need = (a.n + ng - 1) / ng;
+        if constexpr (SUBSET == 2) {   // beside the tolerance family's grid: SIMDs of its own, one round of the chain or nothing
+            const int64_t solo = (int64_t)pre_limit / ng;
+            hipLaunchKernelGGL((lanex_pg_kernel<T, kH, true>), dim3((unsigned)(need < solo ? need : solo)), dim3(kWave), 0, s, a, k,
+                               (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats, (const uint32_t*)queue_len, 1, pre_limit);
+            return hipGetLastError();
+        }
         const int grid_cap = pg_grid<TagLanex>(lanex_pg_kernel<T, kH>, kWave);
         hipLaunchKernelGGL((lanex_pg_kernel<T, kH>), dim3((unsigned)(need < grid_cap ? need : grid_cap)), dim3(kWave), 0, s, a, k,
                            (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats, (const uint32_t*)queue_len, 1);
@@ -217,8 +227,15 @@ hipError_t TPC_CAT(lane_compact_h, TPC_LANE_H)(int dtype, const CompactArgs& a, 
 
 // fp64 only: the re-solve exists to deliver dlib's bits, and dlib is fp64
 hipError_t TPC_CAT(lane_resolve_compact_h, TPC_LANE_H)(const CompactArgs& a, const Knobs& k, const Workspace& ws,
-                                                         const int32_t* select, const uint32_t* gate, hipStream_t s) {
-    return resolve<double, 2, CompactModel<double>, CompactArgs>(a, k, ws, select, gate, s);
+                                                         const int32_t* select, const uint32_t* gate, hipStream_t s,
+                                                         double presolved_from, const uint32_t* pre_len, uint32_t pre_limit) {
+    return resolve<double, 2, CompactModel<double>, CompactArgs>(a, k, ws, select, gate, s, presolved_from, pre_len, pre_limit);
+}
+// the instances with lambda >= lambda_from, ahead of the tolerance family (outputs where `a` says: the caller's side arrays)
+hipError_t TPC_CAT(lane_presolve_compact_h, TPC_LANE_H)(const CompactArgs& a, const Knobs& k, const Workspace& ws,
+                                                          double lambda_from, uint32_t limit, hipStream_t s) {
+    if constexpr (!LanexPlan<kH>::built) return hipErrorInvalidValue;
+    return resolve<double, 2, CompactModel<double>, CompactArgs, 2>(a, k, ws, nullptr, nullptr, s, lambda_from, nullptr, limit);
 }
 hipError_t TPC_CAT(lane_resolve_general_h, TPC_LANE_H)(int I, const GeneralArgs& a, const Knobs& k, const Workspace& ws,
                                                          const int32_t* select, const uint32_t* gate, hipStream_t s) {

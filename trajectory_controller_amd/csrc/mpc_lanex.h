@@ -42,12 +42,23 @@ template <int H> struct LanexPlan {
     static constexpr int NG = built ? kWave / G : 1;  // instances per wavefront
 };
 
-template <typename T, int H>
+// SOLO (AUTO's presolve, tpc_mpc_api.cpp): the kernel runs BESIDE a tolerance family's persistent grid.  Sharing a SIMD with
+// that grid's wavefronts more than doubles this kernel's 10 000-iteration chain (measured: 34 ms against 14), so the SOLO
+// build claims enough of the register file (a clobbered AGPR: 352 registers) that no other fp64 kernel of this library fits
+// beside it, and it only runs when its whole queue fits `solo_limit` instances at once (one round of the chain); a longer
+// queue makes it -- and the merge and the second pass's exclusion, which read the same word -- leave the job to the ordinary
+// second pass.
+template <typename T, int H, bool SOLO = false>
 __global__ __launch_bounds__(64, 1) void lanex_pg_kernel(CompactArgs g, Knobs kn, const T* __restrict__ recs,
                                                          const uint32_t* __restrict__ order, uint32_t* __restrict__ ticket,
                                                          unsigned long long* __restrict__ stats,
-                                                         const uint32_t* __restrict__ queue_len, int refill_groups) {
+                                                         const uint32_t* __restrict__ queue_len, int refill_groups,
+                                                         uint32_t solo_limit = 0u) {
     using P = LanexPlan<H>;
+    if constexpr (SOLO) {
+        asm volatile("" ::: "a159");
+        if (__builtin_nontemporal_load(queue_len) > solo_limit) return;
+    }
     static_assert(P::built && P::GA * P::L == H, "chunks of five steps: N = 10, 20, 30, 40");
     constexpr int L = P::L, G = P::G, GA = P::GA, NG = P::NG, RL = LaneRec<T, H>::kLen;
     const int64_t n_queue = (int64_t)__builtin_nontemporal_load(queue_len);

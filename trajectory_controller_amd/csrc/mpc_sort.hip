@@ -104,4 +104,27 @@ hipError_t order_finish(const uint32_t* keys, const uint32_t* rank, uint32_t* or
     return hipGetLastError();
 }
 
+// AUTO's presolve (tpc_mpc_api.cpp): the bit-exact results of the queued instances, computed into side arrays beside the
+// tolerance family's pass, over that family's answers
+template <typename T>
+__global__ void presolve_merge_kernel(const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queue_len,
+                                      const T* __restrict__ sf, const T* __restrict__ sr, const int32_t* __restrict__ si,
+                                      T* __restrict__ f, T* __restrict__ r, int32_t* __restrict__ it, uint32_t limit) {
+    const uint32_t nq = *queue_len;
+    if (nq > limit) return;   // the presolve kernel left a queue this long alone (mpc_lanex.h, SOLO)
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+        const uint32_t k = queue[q];
+        f[k] = sf[k];
+        r[k] = sr[k];
+        if (it) it[k] = si[k];
+    }
+}
+hipError_t presolve_merge(const uint32_t* queue, const uint32_t* queue_len, int64_t n, const void* sf, const void* sr,
+                          const int32_t* si, void* f, void* r, int32_t* it, uint32_t limit, hipStream_t s) {
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(presolve_merge_kernel<double>, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, s, queue, queue_len,
+                       (const double*)sf, (const double*)sr, si, (double*)f, (double*)r, it, limit);
+    return hipGetLastError();
+}
+
 }  // namespace tpc

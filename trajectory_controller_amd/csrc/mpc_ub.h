@@ -49,16 +49,8 @@ template <typename T, int H> struct UbCdPlan {
     // 4 x CdOcc wavefronts of a CU share 160 KB: fp64 N = 30 would keep two of four SIMDs idle)
     static constexpr bool mirror = 2 * (2 * H * kWave * (int)sizeof(T)) <= 64 * 1024 &&
                                    2 * (2 * H * kWave * (int)sizeof(T)) * 4 * CdOcc<T, H>::value <= 160 * 1024;
-#ifdef TPC_UB_CD_XLDS
-    static constexpr bool x_in_lds = mirror && TPC_UB_CD_XLDS != 0;
-#else
     static constexpr bool x_in_lds = mirror && sizeof(T) == 8 && H >= 20;
-#endif
-#ifdef TPC_UB_CD_FAST
-    static constexpr bool fast = TPC_UB_CD_FAST != 0;
-#else
-    static constexpr bool fast = true;
-#endif
+    static constexpr bool fast = true;   // (the select-free sweep wherever the screen allows it)
 };
 
 TPC_DEV double cd_ldexp(double x, int e) { return __builtin_ldexp(x, e); }
@@ -240,9 +232,8 @@ __global__ __launch_bounds__(64, (CdOcc<T, H>::value)) void ub_cd_kernel(Compact
 // State of one instance: x (2H), the forward pass (Z, Y per step: 2H), dlib's momentum v (2H).
 // Where it lives (UbPlan): x always in VGPRs; the forward pass in VGPRs, or -- where x and it do
 // not both fit the 256 a VALU instruction can name (fp64, N >= 30) -- not kept at all: the backward sweep
-// regenerates each step's (Z, Y) from the next one's (ub::Reverse; a checkpointed plan, even steps in AGPRs or
-// VGPRs, remains as an A/B switch); v in VGPRs for the first KV steps, in LDS beyond ([var][lane] columns,
-// fetched one step ahead).
+// regenerates each step's (Z, Y) from the next one's (ub::Reverse); v in VGPRs for the first KV steps, in LDS beyond
+// ([var][lane] columns, fetched one step ahead).
 #ifndef TPC_UB_OCC
 #define TPC_UB_OCC 0
 #endif
@@ -263,47 +254,14 @@ template <typename T, int H> struct UbPlan {
     // 0.241 / 0.260, N = 10: 0.943 / 0.788, N = 20: 5.58 / 5.26, N = 30: 18.4 / 19.5 -- two only at N = 10 and 20.
     static constexpr int occ_default = D ? 1 : ((H == 10 || H == 20) ? 2 : 1);
     static constexpr int occ = TPC_UB_OCC > 0 ? TPC_UB_OCC : occ_default;
-    // forward pass checkpointed (even steps kept, odd steps recomputed in the backward pass): in AGPRs where
-    // x and w together exceed the VGPRs (fp64, H >= 30); TPC_UB_CKPT=1: in VGPRs (A/B at H = 20)
-    static constexpr bool ckpt_agpr = D && H >= 30 && !reverse;
-#ifdef TPC_UB_CKPT
-    static constexpr bool ckpt = ckpt_agpr || (TPC_UB_CKPT != 0 && D && !regs);
-#else
-    static constexpr bool ckpt = ckpt_agpr;
-#endif
     // steps of v in VGPRs (the rest in LDS)
     // (N = 30 / 40 with the forward pass regenerated, kernel time per 262 144 instances at KV = 0 / 8 / 16:
     // 24.3 / 22.7 / 22.9 ms and 58.9 / 55.5 / 54.0 ms on the box where the checkpointed plan took 23.7 and 55.9)
     static constexpr int kv_default = regs ? H : (H == 20 ? 16 : (H == 30 ? 8 : 16));
     static constexpr int kv = regs ? H : (TPC_UB_KV >= 0 ? TPC_UB_KV : kv_default);
-#ifdef TPC_UB_SCHED_BARRIER
-    static constexpr bool step_barrier = TPC_UB_SCHED_BARRIER != 0;
-#else
     static constexpr bool step_barrier = H - kv >= 8;
-#endif
 };
-#ifdef TPC_UB_EXIT_EVERY_STOP
-template <typename T, int H> struct UbExitEveryStop { static constexpr bool value = TPC_UB_EXIT_EVERY_STOP != 0; };
-#else
-template <typename T, int H> struct UbExitEveryStop { static constexpr bool value = false; };
-#endif
-#ifdef TPC_UB_REFILL_BATCH
-template <int H> struct UbRefillBatch { static constexpr int value = TPC_UB_REFILL_BATCH; };
-#else
 template <int H> struct UbRefillBatch { static constexpr int value = RefillBatch<H>::value; };
-#endif
-
-// an fma the optimiser cannot merge with an identical one elsewhere (checkpoint re-computation)
-TPC_DEV double fma_opaque(double a, double b, double c) {
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-TPC_DEV float fma_opaque(float a, float b, float c) {
-    float r;
-    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
 
 // MODE: which stop test (the coordinate-descent kernel's screens pick one build per batch, stats[2]):
 //   0 exact  dlib's mask by compare and select (mpc.h:298-299); any input
@@ -325,32 +283,19 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
         if (n_queue <= 0) return;   // (nothing queued: no wavefront should go and ask the ticket -- a thousand returning atomics on one address take 35 us)
     }
     constexpr int BT = kWave * P::occ;
-    constexpr bool CK = P::ckpt;
     constexpr int KV = P::kv, VL = H - KV;
-    static_assert(!CK || H % 2 == 0, "checkpoints sit on the even steps");
     __shared__ T s_all[VL > 0 ? 2 * VL : 1][BT];
     T r_v[2 * KV + 1];
-    constexpr bool CKA = P::ckpt_agpr;   // checkpoints in AGPRs (else in VGPRs)
-    AgprWord a_w[CKA ? H : 1];
-    T c_w[(CK && !CKA) ? H : 1];
     const int lane = threadIdx.x;
     auto v_put = [&](int q, T val) { if (q < 2 * KV) r_v[q] = val; else s_all[q - 2 * KV][threadIdx.x] = val; };
     auto v_get = [&](int q) -> T { if (q < 2 * KV) return r_v[q]; else return s_all[q - 2 * KV][threadIdx.x]; };
     constexpr bool RV = P::reverse;
-    T w[(CK || RV) ? 1 : 2 * H];
-    // CK keeps the even steps only: (Z, Y) of step i (even) at a_w[i], a_w[i+1]
+    T w[RV ? 1 : 2 * H];
     auto w_put = [&](int i, T Z, T Y) {
-        if constexpr (RV) {}
-        else if constexpr (CKA) { if ((i & 1) == 0) { agpr_put(a_w[i], Z); agpr_put(a_w[i + 1], Y); } }
-        else if constexpr (CK) { if ((i & 1) == 0) { c_w[i] = Z; c_w[i + 1] = Y; } }
-        else { w[2 * i] = Z; w[2 * i + 1] = Y; }
+        if constexpr (!RV) { w[2 * i] = Z; w[2 * i + 1] = Y; }
     };
-    auto w_getz = [&](int i) -> T {
-        if constexpr (CKA) return agpr_get<T>(a_w[i]); else if constexpr (CK) return c_w[i]; else return w[2 * i];
-    };
-    auto w_gety = [&](int i) -> T {
-        if constexpr (CKA) return agpr_get<T>(a_w[i + 1]); else if constexpr (CK) return c_w[i + 1]; else return w[2 * i + 1];
-    };
+    auto w_getz = [&](int i) -> T { return w[2 * i]; };
+    auto w_gety = [&](int i) -> T { return w[2 * i + 1]; };
 
     constexpr T gs = ub::GradScale<T>::g;
     const T geps = gs * (T)kn.eps;
@@ -394,11 +339,7 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
     // N = 10: 0.910 / 0.915 / 0.901 / 0.888, N = 20: 5.34 / 5.41 / 5.40 / 5.52 -- at N = 20 a pass is dominated by the 42 scattered
     // record loads and the set-up behind them, not by the round trips in front, and the deal's 0.6 % of extra wave
     // iterations (shares are even by rank, not by iteration count) cost more than it saves: dealt up to N = 10 only.
-#ifdef TPC_UB_DEAL
-    constexpr int kDeal = TPC_UB_DEAL;
-#else
     constexpr int kDeal = H <= 10 ? 95 : 0;
-#endif
     const int wl = lane & (kWave - 1);
     const uint32_t n_waves = gridDim.x * (uint32_t)P::occ;
     const uint32_t wave_id = blockIdx.x * (uint32_t)P::occ + ((uint32_t)threadIdx.x >> 6);
@@ -445,11 +386,7 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
                     // N = 10: 0.887 / 0.875, N = 40: 52.6 / 52.4, fp32 N = 20: 5.35 / 5.26 -- and fp64 N = 20: 5.45 / 5.57 (three
                     // interleaved rounds; its pass is bounded by three dependent memory round trips, which the divisions
                     // used to fill), so that one kernel keeps recomputing.
-#ifdef TPC_UB_REFILL_RECORD
-                    constexpr bool kFromRecord = TPC_UB_REFILL_RECORD != 0;
-#else
                     constexpr bool kFromRecord = !(sizeof(T) == 8 && H == 20);
-#endif
                     iter = (uint32_t)meta;
                     if (meta & kMetaNonFinite) flags |= 0x1u;
                     const bool vinit = (meta & kMetaVInit) != 0;   // mpc.h:330-334, else a fresh v = 0
@@ -494,16 +431,12 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
         }
         // ---- backward pass fused with the stop test and the speculative update
         x0_prev[0] = x[0]; x0_prev[1] = x[1];
-#ifndef TPC_UB_ACC_N
-#define TPC_UB_ACC_N 4
-#endif
-        constexpr int NA = TPC_UB_ACC_N;
+        constexpr int NA = 4;   // accumulators of the stop test (2 / 4 / 8 measured: 5.52 / 5.35 / 5.44 ms at N = 20)
         T acc[NA];
 #pragma unroll
         for (int z = 0; z < NA; ++z) acc[z] = (T)0;
         T n0, n1;
         m.bwd_last(n0, n1, Z, Y);
-        T cz = (T)0, cy = (T)0;   // CK: the checkpoint of step i-1 read at an odd step i, used again at step i-1
         static_for<H>([&](auto ic) {
             constexpr int i = H - 1 - decltype(ic)::value;
             constexpr int cur = i & 1, nxt = (i - 1) & 1;
@@ -517,23 +450,7 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
             // LDS read to the top of the iteration -- harmless with four steps in LDS (N = 20: 5 % faster without),
             // ~700 register moves per iteration with thirty or forty
             if constexpr (P::step_barrier) __builtin_amdgcn_sched_barrier(0);
-            if constexpr (CK) {
-                if constexpr (i < H - 1) {
-                    if constexpr (i % 2 == 1) {
-                        // (Z, Y) of step i again from the checkpoint of step i-1 and x[i], which this
-                        // step has not updated yet: the forward pass's own operations, opaque to CSE
-                        cz = w_getz(i - 1); cy = w_gety(i - 1);
-                        const T rz = fma_opaque(m.as1, x[2 * i + 1], fma_opaque(m.a, cy, cz));
-                        T ry = fma_opaque(m.cs0, x[2 * i], fma_opaque(-m.cs1, x[2 * i + 1], cy));
-                        if constexpr (!EQB) ry = ry + m.dlt;
-                        m.bwd(n0, n1, rz, ry);
-                    } else {
-                        m.bwd(n0, n1, cz, cy);
-                    }
-                } else {
-                    cz = w_getz(i - 1); cy = w_gety(i - 1);   // i = H-1 (odd): its own (Z, Y) went into bwd_last
-                }
-            } else if constexpr (RV) {
+            if constexpr (RV) {
                 if constexpr (i < H - 1) m.bwd(n0, n1, Z, Y);   // (Z, Y) hold step i (regenerated below)
             } else {
                 if constexpr (i < H - 1) m.bwd(n0, n1, w_getz(i), w_gety(i));
@@ -542,9 +459,7 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
             // x[i] is dead when the new one is defined and the two can share a register (no copy at the back edge)
             if constexpr (RV && i > 0) {
                 m.rev(Z, Y, x[2 * i], x[2 * i + 1]);
-#ifndef TPC_UB_NO_RV_PIN
                 asm volatile("" : "+v"(Z), "+v"(Y));   // (keeps the regeneration here: LLVM would sink it past the update)
-#endif
             }
             T vn[2], st[2];
             static_for<2>([&](auto jc) {
@@ -567,11 +482,6 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
                     acc[(2 * i + j) % NA] = tmax(acc[(2 * i + j) % NA], tmax(up, dn));
                 }
             });
-#ifdef TPC_UB_MID_BARRIER
-            // everything that reads the old x comes before everything that defines the new one, so the new x
-            // can take the old one's register
-            __builtin_amdgcn_sched_barrier(0);
-#endif
             static_for<2>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 constexpr int q = 2 * i + j;
@@ -579,9 +489,6 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
                 if constexpr (i >= KV) vold = pv[cur][j]; else vold = r_v[q];
                 x[q] = m.template project<FAST>(ub::fma_(beta, vn[j] - vold, vn[j]), j);   // mpc.h:343 (difference form: pg_update)
                 if constexpr (i < KV) r_v[q] = vn[j];
-#ifdef TPC_UB_UPIN   // (A/B: LANE's pin of the update to its step; here it costs register copies)
-                asm volatile("" : "+v"(x[q]));
-#endif
             });
             if constexpr (i >= KV) {
                 static_for<2>([&](auto jc) {   // adjacent stores: one ds_write2st64 per step
@@ -597,9 +504,7 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
         stop = have && (max_df < geps);                                         // mpc.h:310-311
         ++iter;
         cap = have && !stop && iter >= kn.max_iter;                             // mpc.h:271
-        if constexpr (UbExitEveryStop<T, H>::value) {
-            if (__ballot(stop || cap) != 0ull) break;
-        } else if (__ballot(stop || cap) != 0ull) {
+        if (__ballot(stop || cap) != 0ull) {
             if (stop) {
                 publish(x0_prev[0], x0_prev[1], iter - 1);
                 have = false;
@@ -613,17 +518,6 @@ __global__ __launch_bounds__((64 * UbPlan<T, H>::occ), (UbPlan<T, H>::occ)) void
             if (__popcll(waiting) >= UbRefillBatch<H>::value || __ballot(have) == 0ull) break;
         }
         } while (true);
-        if constexpr (UbExitEveryStop<T, H>::value) {
-            if (stop) {
-                publish(x0_prev[0], x0_prev[1], iter - 1);
-                have = false;
-            }
-            if (cap) {
-                flags |= 0x2u;
-                publish(x[0], x[1], iter);
-                have = false;
-            }
-        }
     }
     raise_flags(g.flags, flags);
     if (stats && (lane & (kWave - 1)) == 0) {

@@ -67,7 +67,8 @@ hipError_t pg_launch(const CompactArgs& a, const Knobs& k, const Workspace& ws, 
         return ub_pg_asm_launch(a, k, ws, need, s);   // (its own translation unit: mpc_ub_asm_inst.hip)
     }
 #endif
-    const int cap = ub_grid<TagPg<T, EQB, MODE>>(ub_pg_kernel<T, kH, EQB, MODE>, bt);
+    int cap = ub_grid<TagPg<T, EQB, MODE>>(ub_pg_kernel<T, kH, EQB, MODE>, bt);
+    if (ws.max_waves > 0 && cap > ws.max_waves / UbPlan<T, kH>::occ) cap = ws.max_waves / UbPlan<T, kH>::occ;   // (a presolve holds the other SIMDs: tpc_mpc_api.cpp)
     hipLaunchKernelGGL((ub_pg_kernel<T, kH, EQB, MODE>), dim3((unsigned)(need < cap ? need : cap)), dim3(bt), 0, s, a, k,
                        (const T*)ws.state, (const uint32_t*)ws.order, ws.ticket, ws.stats, order_queue_len(ws.sort_temp));
     return hipGetLastError();

@@ -254,14 +254,8 @@ template <typename T, bool EQB> TPC_HD bool moved_stop_ok(const Unit<T, EQB>& m,
 // fp64 at N = 30 and 40: x alone takes 120 / 160 of the 256 registers a VALU instruction can name, and a kept
 // (even a checkpointed) forward pass sent ~300 values per iteration through the AGPRs; regenerating it costs 4
 // operations per step and no register.  (At N = 20 the kept forward pass fits and is faster: 5.35 against 6.1 ms.)
-#ifndef TPC_UB_REVERSE
-#define TPC_UB_REVERSE 0   // A/B: also at N = 20
-#endif
-#ifndef TPC_UB_REVERSE_BIG
-#define TPC_UB_REVERSE_BIG 1   // A/B: 0 = the checkpointed forward pass at N = 30 / 40
-#endif
 template <typename T, int H> struct Reverse {
-    static constexpr bool value = sizeof(T) == 8 && ((TPC_UB_REVERSE_BIG != 0 && H >= 30) || (TPC_UB_REVERSE != 0 && H == 20));
+    static constexpr bool value = sizeof(T) == 8 && H >= 30;
 };
 
 // dlib's constructor quantities for the compact model (mpc.h:116-123), in dlib's own operation order

@@ -215,11 +215,7 @@ template <typename T, int H> struct UbgPlan {
     static constexpr bool D = sizeof(T) == 8;
     static constexpr bool regs = !D || H <= 10;
     static constexpr int occ = (!D && H == 10) ? 2 : 1;
-#ifdef TPC_UBG_KV
-    static constexpr int kv = regs ? H : TPC_UBG_KV;
-#else
     static constexpr int kv = regs ? H : 6;
-#endif
 };
 
 template <typename T, int I, int H, bool FAST>

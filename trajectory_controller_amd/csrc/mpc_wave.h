@@ -550,13 +550,7 @@ TPC_DEV void wave_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, Hook 
         return a0 + a1;
     };
 
-#ifndef TPC_WAVE_UNROLL_CD
-#define TPC_WAVE_UNROLL_CD 5
-#endif
-#ifndef TPC_WAVE_UNROLL_PG
-#define TPC_WAVE_UNROLL_PG 8
-#endif
-    constexpr int kUnrollCd = TPC_WAVE_UNROLL_CD, kUnrollPg = TPC_WAVE_UNROLL_PG;
+    constexpr int kUnrollCd = 5, kUnrollPg = 8;
     uint32_t iter = 0;
     bool capped = true;
     // Two loops, one per phase; both kinds of step are computed SPECULATIVELY beside the stop test they do
@@ -823,7 +817,7 @@ TPC_DEV void wave_pair_solve(const Args& g, const Knobs& kn, const int64_t (&ks)
         return a0 + a1;
     };
 
-    constexpr int kUnrollCd = TPC_WAVE_UNROLL_CD, kUnrollPg = TPC_WAVE_UNROLL_PG;
+    constexpr int kUnrollCd = 5, kUnrollPg = 8;
     uint32_t iter_l = 0;              // iterations of this lane's instance (alike within a half)
     unsigned long long still = 0ull;  // halves that were still going when the loops ended (= ran into the cap)
     auto run = [&](auto mask_tag) {
@@ -924,10 +918,7 @@ TPC_DEV void wave_pair_solve(const Args& g, const Knobs& kn, const int64_t (&ks)
 
 // kWavesPerBlock instances per workgroup, one per wavefront; they share nothing but the launch.
 // Measured at 4 096 instances, N = 10: 231 / 230 / 225 / 242 us for 1 / 2 / 4 / 8 wavefronts per workgroup.
-#ifndef TPC_WAVES_PER_BLOCK
-#define TPC_WAVES_PER_BLOCK 4
-#endif
-constexpr int kWavesPerBlock = TPC_WAVES_PER_BLOCK;
+constexpr int kWavesPerBlock = 4;
 
 // ---- the compact model's gradient by prefix sums (one horizon step per lane) --------------------------------
 // The dense form above spends 2 (2H)^2 flops per iteration on a Hessian whose structure is a double integrator
@@ -945,11 +936,8 @@ constexpr int kWavesPerBlock = TPC_WAVES_PER_BLOCK;
 // (From N = 40.  At N = 30 the dense one-variable-per-lane kernel is still ahead: 2.25 against 2.55 ms per 4 096
 // instances, 6.9 against 7.5 per 16 384.  At N = 40: 4.7 / 4.7 / 15.0 ms per 2 048 / 4 096 / 16 384 instances against
 // 7.8 / 13.0 / 42 with the Hessian rows -- 0.47 us per iteration instead of 0.75, and eight wavefronts per CU.)
-#ifndef TPC_WAVE_SCAN_MIN_H
-#define TPC_WAVE_SCAN_MIN_H 40
-#endif
 template <typename T, int I, int H, class Model> constexpr bool wave_scan() {
-    return I == 2 && std::is_same<Model, CompactModel<T>>::value && H >= TPC_WAVE_SCAN_MIN_H && H > 16 && H <= 48;
+    return I == 2 && std::is_same<Model, CompactModel<T>>::value && H >= 40 && H <= 48;
 }
 template <typename T> struct ScanConsts {   // per lane, set up once per instance
     T ka1, ka2, ka4, ka8;   // k a (wave-uniform)
@@ -1179,13 +1167,7 @@ TPC_DEV void wave2_solve(const Args& g, const Knobs& kn, int64_t k, T* s_w, T* s
     // kept half of one Hessian entry in scratch, reloaded inside the loops -- and that build returned wrong controls
     // for one instance in nine while the scratch-free builds of the same source agree with dlib to 1e-13.  The
     // cause was not found; tests/test_build_artifacts.py refuses a two-per-lane kernel that uses scratch.)
-#ifndef TPC_WAVE2_UNROLL_CD
-#define TPC_WAVE2_UNROLL_CD 4
-#endif
-#ifndef TPC_WAVE2_UNROLL_PG
-#define TPC_WAVE2_UNROLL_PG 4
-#endif
-    constexpr int kUnrollCd = TPC_WAVE2_UNROLL_CD, kUnrollPg = TPC_WAVE2_UNROLL_PG;
+    constexpr int kUnrollCd = 4, kUnrollPg = 4;
     uint32_t iter = 0;
     bool capped = true;
     auto run = [&](auto mask_tag) {
@@ -1321,16 +1303,14 @@ TPC_DEV void wave_solve_any(const Args& g, const Knobs& kn, int64_t k, T* s_w, T
 // chip at once amounts to, so that is the occupancy asked for (256 registers): only the 60-variable kernels'
 // set-up code spills under it (a few dozen scratch accesses per instance, none inside a loop).  Asking for
 // more made the set-up code of the smaller kernels spill too: 20 MB of scratch traffic per 4 096 instances.
-#ifndef TPC_WAVE_MIN_WAVES
-#define TPC_WAVE_MIN_WAVES 2
-#endif
+constexpr int kWaveMinWaves = 2;
 // (the general model's 60-variable fp64 kernels -- a Hessian row of 120 registers beside the per-instance model --
 // do not fit 256 registers without spilling inside their loops: they get the whole file, one wavefront per SIMD)
 template <typename T, int I, int H, class Model = void> constexpr int wave_min_waves() {
     constexpr bool big_general = sizeof(T) == 8 && I * H > 48 && !std::is_same<Model, CompactModel<T>>::value &&
                                  !std::is_same<Model, void>::value;
-    if (wave_scan<T, I, H, Model>()) return TPC_WAVE_MIN_WAVES;   // ~40 registers: no reason for less
-    return (wave_two_per_lane<I, H>() || big_general) ? 1 : TPC_WAVE_MIN_WAVES;
+    if (wave_scan<T, I, H, Model>()) return kWaveMinWaves;   // ~40 registers: no reason for less
+    return (wave_two_per_lane<I, H>() || big_general) ? 1 : kWaveMinWaves;
 }
 template <typename T, int I, int H, class Model, class Args>
 __global__ __launch_bounds__((waves_per_block<T, I, H, Model>() * kWave)) __attribute__((amdgpu_waves_per_eu(wave_min_waves<T, I, H, Model>())))
@@ -1354,17 +1334,11 @@ void wave_kernel(Args g, Knobs kn) {
 // Measured (kernel time, 4 096 / 16 384 instances): N = 10: 226 -> 215 / 609 -> 602 us, N = 20: 1 266 -> 909 /
 // 3 455 -> 2 575 us, N = 30: 3 849 -> 2 488 / 11 256 -> 7 164 us.  At N = 4 and 5 an instance is too short for the
 // queue to pay (45 -> 92 us): those keep one launch slot per instance.
-#ifndef TPC_QUEUE_WG_PER_CU
-#define TPC_QUEUE_WG_PER_CU 2
-#endif
-constexpr int kQueueWorkgroupsPerCu = TPC_QUEUE_WG_PER_CU;   // (one where a lane holds two variables: 380 registers per lane)
+constexpr int kQueueWorkgroupsPerCu = 2;   // (one where a lane holds two variables: 380 registers per lane)
 template <int I, int H, typename T = void, class Model = void> constexpr int queue_waves_per_cu() {
     return ((wave_two_per_lane<I, H>() && !wave_scan<T, I, H, Model>()) ? 1 : kQueueWorkgroupsPerCu) * kWavesPerBlock;
 }
-#ifndef TPC_QUEUE_MIN_H
-#define TPC_QUEUE_MIN_H 10
-#endif
-constexpr int kQueueMinHorizon = TPC_QUEUE_MIN_H;
+constexpr int kQueueMinHorizon = 10;
 constexpr int kOrderThreads = 1024, kOrderBins = 2048, kOrderPerThread = 32;
 constexpr int64_t kQueueMaxInstances = (int64_t)kOrderThreads * kOrderPerThread;   // larger batches: plain launch
 static_assert(kQueueMaxInstances == kWaveQueueMaxInstances, "tpc_mpc_api.cpp's AUTO rule counts on it");

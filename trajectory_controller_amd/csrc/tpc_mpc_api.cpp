@@ -15,7 +15,8 @@ namespace tpc {
 #define TPC_DECL_H(h)                                                                             \
     hipError_t lane_compact_h##h(int, const CompactArgs&, const Knobs&, const Workspace&, hipStream_t); \
     hipError_t lane_general_h##h(int, int, const GeneralArgs&, const Knobs&, const Workspace&, hipStream_t); \
-    hipError_t lane_resolve_compact_h##h(const CompactArgs&, const Knobs&, const Workspace&, const int32_t*, const uint32_t*, hipStream_t); \
+    hipError_t lane_resolve_compact_h##h(const CompactArgs&, const Knobs&, const Workspace&, const int32_t*, const uint32_t*, hipStream_t, double, const uint32_t*, uint32_t); \
+    hipError_t lane_presolve_compact_h##h(const CompactArgs&, const Knobs&, const Workspace&, double, uint32_t, hipStream_t); \
     hipError_t lane_resolve_general_h##h(int, const GeneralArgs&, const Knobs&, const Workspace&, const int32_t*, const uint32_t*, hipStream_t); \
     hipError_t wave_compact_h##h(int, const CompactArgs&, const Knobs&, const Workspace&, hipStream_t); \
     hipError_t wave_general_h##h(int, int, const GeneralArgs&, const Knobs&, const Workspace&, hipStream_t); \
@@ -297,9 +298,10 @@ int cap_iters_buffer(tpc_mpc_context* h, int64_t n, int32_t** out) {
     *out = (int32_t*)h->cap_iters;
     return TPC_MPC_OK;
 }
-hipError_t resolve_compact(int H, const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
+hipError_t resolve_compact(int H, const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s, double presolved_from = 0.0,
+                           const uint32_t* pre_len = nullptr, uint32_t pre_limit = 0u) {
     switch (H) {
-#define X(h) case h: return lane_resolve_compact_h##h(a, k, ws, a.iters, a.flags, s);
+#define X(h) case h: return lane_resolve_compact_h##h(a, k, ws, a.iters, a.flags, s, presolved_from, pre_len, pre_limit);
         X(4) X(5) X(10) X(20) X(30) X(40)
 #undef X
     }
@@ -323,6 +325,8 @@ int prepare_workspace(tpc_mpc_context* h, int algo, int H, int dtype, int64_t n,
     ws->wave_group = h->opt_wave_group;
     ws->group_lanes = group_lanes(h, H, dtype, n, form);
     ws->max_waves = h->max_waves;
+    if (h->pre_busy && h->pre_group_waves > 0 && (ws->max_waves == 0 || ws->max_waves > h->pre_group_waves))
+        ws->max_waves = h->pre_group_waves;   // a presolve holds the other SIMDs (presolve_begin)
     ws->group_pair = group_pair(h, H, dtype, n, form);
     ws->lanex_below = h->opt_lanex_below;
     ws->cu_count = h->cu_count;
@@ -536,38 +540,160 @@ int check_general_device_io(tpc_mpc_context* h, const tpc_mpc_general_io* io) {
     return TPC_MPC_OK;
 }
 
-int compact_launch(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy,
-                   const void* dphi, void* front, void* rear, int32_t* iters, hipStream_t s) {
+static void compact_args(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy, const void* dphi,
+                         void* front, void* rear, int32_t* iters, CompactArgs* a) {
+    std::memset(a, 0, sizeof(*a));
+    a->n = n;
+    a->v = v; a->dy = dy; a->dphi = dphi;
+    a->front = front; a->rear = rear; a->iters = iters;
+    a->flags = h->collect_flags ? h->ws_words + 1 : nullptr;
+    a->step = p->step_size; a->wheelbase = p->wheelbase;
+    a->q[0] = p->weight_y; a->q[1] = p->weight_phi;
+    a->r[0] = p->weight_steering_front; a->r[1] = p->weight_steering_rear;
+    a->lo[0] = p->lower[0]; a->lo[1] = p->lower[1]; a->hi[0] = p->upper[0]; a->hi[1] = p->upper[1];
+}
+
+// Which instances will end on the iteration cap can be said before any of them is solved: dlib's iteration count grows like
+// 5.5 sqrt(lambda) (lambda = its trace bound of the Hessian, mpc.h:116-123; measured with the checker on the synthetic
+// streams: median 5.45; 6.36 at most among the instances near the cap at N = 40), so lambda >= (max_iter / 7)^2 names them --
+// at N = 40 with dlib's default cap: every one of the 1 614 capped instances of a 16 384-instance batch, 20 % of the batch,
+// half of those really capped.  The margin matters: ONE capped instance the prediction misses costs the second pass its
+// whole 10 000-iteration chain again (with max_iter / 6.25 one of 16 384 slipped through: 31 ms instead of 16).  Still a
+// prediction, not a decision: an instance it takes comes back with dlib's bits whether it capped or not, one it misses is
+// caught by the flag-driven second pass as before.  Horizons below 30 never get near the cap with dlib's defaults and
+// (and N = 30: lambda <= 1.1e6 at 4 m/s) are left alone: a presolve that finds nothing still costs GROUP its share of the chip.
+static double presolve_lambda(const tpc_mpc_params* p) {
+    if (p->horizon < 40 || p->max_iter < 2000) return 0.0;
+    const double t = (double)p->max_iter / 7.0;
+    return t * t;
+}
+
+int presolve_begin(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy, const void* dphi,
+                   hipStream_t s, Presolve* ps) {
+    *ps = Presolve();
+    const int algo = pick_algo(h, p->algo, 2, p->horizon, n, p->dtype, fma_usable(p));
+    if (algo != TPC_MPC_ALGO_GROUP || !wants_cap_resolve(p, algo) || !h->collect_flags) return TPC_MPC_OK;
+    const double lf = presolve_lambda(p);
+    if (!(lf > 0.0) || h->pre_busy) return TPC_MPC_OK;
+    // SIMDs of its own for the bit-exact kernel (mpc_lanex.h, SOLO), the rest for GROUP's persistent grid: 7 of 16 and 9 of
+    // 16 -- the predicted set of the N = 40 stream is 20 % of a batch, eight instances per wavefront, and GROUP's pass is
+    // bounded by its longest instance rather than by its share of the chip at the batch sizes it is AUTO's choice for
+    // (16 384 x N = 40: 4.7 ms on the whole chip, 8.8 on 11 / 16).  A batch whose predicted set cannot run in ONE round of
+    // those wavefronts is left to the second pass -- decided on the device, where the set's size is known; a batch too
+    // large for a fifth of it to fit is not tried.
+    const int simds = (h->cu_count > 0 ? h->cu_count : 256) * 4;
+    const int solo_waves = simds * 7 / 16;
+    if (n > (int64_t)solo_waves * 8 * 5) return TPC_MPC_OK;
+    ps->limit = (uint32_t)solo_waves * 8u;
+    ps->group_waves = simds - solo_waves;
+    // scratch of its own (the tolerance pass runs in the handle's main scratch at the same time): LANE layout | side outputs
+    const int H = p->horizon, dtype = p->dtype;
+    const int64_t rec_b = pad256(lane_rec_len(H, dtype) * (int64_t)esize(dtype) * n), col_b = pad256(n * 4), out_b = pad256(n * 8);
+    const size_t tmp_b = sort_temp_bytes(n);
+    const int64_t lane_b = rec_b + 3 * col_b + pad256((int64_t)tmp_b);
+    int rc = ensure(h, &h->pre, &h->pre_bytes, lane_b + 2 * out_b + col_b);
+    if (rc) return rc;
+    if (!h->pre_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking));
+    if (!h->pre_fork) HIP_TRY(h, hipEventCreateWithFlags(&h->pre_fork, hipEventDisableTiming));
+    if (!h->pre_done) HIP_TRY(h, hipEventCreateWithFlags(&h->pre_done, hipEventDisableTiming));
+    char* b = (char*)h->pre;
+    Workspace ws;
+    std::memset(&ws, 0, sizeof(ws));
+    ws.state = b;
+    ws.keys = (uint32_t*)(b + rec_b);
+    ws.rank = (uint32_t*)(b + rec_b + col_b);
+    ws.order = (uint32_t*)(b + rec_b + 2 * col_b);
+    ws.sort_temp = b + rec_b + 3 * col_b;
+    ws.sort_temp_bytes = tmp_b;
+    ws.capacity_bytes = lane_b;
+    ws.ev = nullptr;
+    ws.lanex_below = h->opt_lanex_below;
+    ws.cu_count = h->cu_count;
+    ws.ticket = h->ws_words + 24;   // ticket | queue length | statistics: 32 contiguous bytes, as the second pass's (resolve_workspace)
+    ws.stats = (unsigned long long*)(h->ws_words + 26);
+    ps->side_front = b + lane_b;
+    ps->side_rear = b + lane_b + out_b;
+    ps->side_iters = (int32_t*)(b + lane_b + 2 * out_b);
+    ps->queue = ws.order;
+    ps->queue_len = ws.ticket + 1;
+    ps->lambda_from = lf;
+    CompactArgs a;
+    compact_args(h, p, n, v, dy, dphi, ps->side_front, ps->side_rear, ps->side_iters, &a);
+    HIP_TRY(h, hipEventRecord(h->pre_fork, s));
+    HIP_TRY(h, hipStreamWaitEvent(h->pre_stream, h->pre_fork, 0));
+    ps->on = true;   // (from here on presolve_finish must join the side stream, whatever happens)
+    h->pre_busy = true;
+    h->pre_group_waves = ps->group_waves;
+    hipError_t e = hipErrorInvalidValue;
+    switch (H) {
+#define X(hh) case hh: e = lane_presolve_compact_h##hh(a, knobs_of(p), ws, lf, ps->limit, h->pre_stream); break;
+        X(4) X(5) X(10) X(20) X(30) X(40)
+#undef X
+    }
+    if (e != hipSuccess) return hip_fail(h, e, "kernel launch (presolve)");
+    return TPC_MPC_OK;
+}
+
+int presolve_finish(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy, const void* dphi,
+                    void* front, void* rear, int32_t* iters, hipStream_t s, Presolve* ps) {
+    if (ps->on) {
+        ps->on = false;
+        h->pre_busy = false;
+        HIP_TRY(h, hipEventRecord(h->pre_done, h->pre_stream));
+        HIP_TRY(h, hipStreamWaitEvent(s, h->pre_done, 0));
+    }
+    const int algo = pick_algo(h, p->algo, 2, p->horizon, n, p->dtype, fma_usable(p));
+    if (algo < 0 || !wants_cap_resolve(p, algo) || !h->collect_flags) return TPC_MPC_OK;
+    int32_t* sel = iters ? iters : ps->select;
+    if (ps->lambda_from > 0.0) {
+        hipError_t e = presolve_merge(ps->queue, ps->queue_len, n, ps->side_front, ps->side_rear, ps->side_iters, front, rear, sel, ps->limit, s);
+        if (e != hipSuccess) return hip_fail(h, e, "kernel launch (presolve merge)");
+    }
+    CompactArgs a;
+    compact_args(h, p, n, v, dy, dphi, front, rear, sel, &a);
+    Workspace ws2;
+    int rc = resolve_workspace(h, p->horizon, p->dtype, n, &ws2);
+    if (rc) return rc;
+    hipError_t e = resolve_compact(p->horizon, a, knobs_of(p), ws2, s, ps->lambda_from, ps->queue_len, ps->limit);
+    if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
+    return TPC_MPC_OK;
+}
+
+// the tolerance (or whatever pick_algo says) pass; with `ps`: AUTO's guarantee is the caller's business (presolve_finish),
+// immediately unless ps->deferred
+int compact_launch_ps(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy,
+                      const void* dphi, void* front, void* rear, int32_t* iters, hipStream_t s, Presolve* ps) {
     const int algo = pick_algo(h, p->algo, 2, p->horizon, n, p->dtype, fma_usable(p));
     if (algo < 0) return fail(h, TPC_MPC_ERR_BAD_HORIZON, "the WAVE kernel exists for the specialised horizons with inputs*horizon <= 64 only; use LANE or AUTO");
     CompactArgs a;
-    std::memset(&a, 0, sizeof(a));
-    a.n = n;
-    a.v = v; a.dy = dy; a.dphi = dphi;
-    a.front = front; a.rear = rear; a.iters = iters;
-    a.flags = h->collect_flags ? h->ws_words + 1 : nullptr;
+    compact_args(h, p, n, v, dy, dphi, front, rear, iters, &a);
     a.work_hint = take_hint(h, n);
-    a.step = p->step_size; a.wheelbase = p->wheelbase;
-    a.q[0] = p->weight_y; a.q[1] = p->weight_phi;
-    a.r[0] = p->weight_steering_front; a.r[1] = p->weight_steering_rear;
-    a.lo[0] = p->lower[0]; a.lo[1] = p->lower[1]; a.hi[0] = p->upper[0]; a.hi[1] = p->upper[1];
     const bool fix = wants_cap_resolve(p, algo) && a.flags;
     int rc = TPC_MPC_OK;
     if (fix && !a.iters) rc = cap_iters_buffer(h, n, &a.iters);
     if (!rc && fix) rc = resolve_reserve(h, p->horizon, p->dtype, n);
     if (rc) return rc;
+    ps->select = a.iters;
     Workspace ws;
     rc = prepare_workspace(h, algo, p->horizon, p->dtype, n, &ws);
     if (rc) return rc;
     hipError_t e = dispatch_compact(algo, p->horizon, p->dtype, a, knobs_of(p), ws, s);
-    if (e == hipSuccess && fix) {
-        Workspace ws2;
-        rc = resolve_workspace(h, p->horizon, p->dtype, n, &ws2);
-        if (rc) return rc;
-        e = resolve_compact(p->horizon, a, knobs_of(p), ws2, s);
-    }
     if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
-    return TPC_MPC_OK;
+    if (ps->deferred) return TPC_MPC_OK;
+    return presolve_finish(h, p, n, v, dy, dphi, front, rear, iters, s, ps);
+}
+
+int compact_launch(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy,
+                   const void* dphi, void* front, void* rear, int32_t* iters, hipStream_t s) {
+    Presolve ps;
+    int rc = presolve_begin(h, p, n, v, dy, dphi, s, &ps);
+    if (!rc) rc = compact_launch_ps(h, p, n, v, dy, dphi, front, rear, iters, s, &ps);
+    if (rc && ps.on) {   // the side stream got work: the caller's stream must not run ahead of it (scratch, outputs)
+        h->pre_busy = false;
+        (void)hipEventRecord(h->pre_done, h->pre_stream);
+        (void)hipStreamWaitEvent(s, h->pre_done, 0);
+    }
+    return rc;
 }
 
 }  // namespace tpc
@@ -665,6 +791,10 @@ int tpc_mpc_destroy(tpc_mpc_handle h) {
         if (h->cap_iters) (void)hipFree(h->cap_iters);
         if (h->mix) (void)hipFree(h->mix);
         if (h->gather) (void)hipFree(h->gather);
+        if (h->pre_stream) { (void)hipStreamSynchronize(h->pre_stream); (void)hipStreamDestroy(h->pre_stream); }
+        if (h->pre_fork) (void)hipEventDestroy(h->pre_fork);
+        if (h->pre_done) (void)hipEventDestroy(h->pre_done);
+        if (h->pre) (void)hipFree(h->pre);
         if (h->hint_own) (void)hipFree(h->hint_own);
         if (h->pin_host) (void)hipHostFree(h->pin_host);
         if (h->done_ev) (void)hipEventDestroy(h->done_ev);

@@ -43,6 +43,14 @@ struct tpc_mpc_context {
     // iteration counts of a tolerance family's pass when the caller asked for none (AUTO re-solves what ended on the cap)
     void* cap_iters = nullptr;
     int64_t cap_iters_bytes = 0;
+    // AUTO's presolve (tpc_mpc_api.cpp, presolve_begin): the instances predicted to end on the iteration cap are solved
+    // bit-exactly on a stream of the handle's own BESIDE the tolerance family's pass: LANE scratch + side outputs, stream, events
+    void* pre = nullptr;
+    int64_t pre_bytes = 0;
+    hipStream_t pre_stream = nullptr;
+    hipEvent_t pre_fork = nullptr, pre_done = nullptr;
+    bool pre_busy = false;           // a presolve is in flight on pre_stream (one at a time per handle)
+    int pre_group_waves = 0;         // ... and this many wavefronts are what it leaves to every other persistent grid of the handle
     // mixed-horizon batches: bin-contiguous copies of the inputs and outputs, permutation, counters
     void* mix = nullptr;
     int64_t mix_bytes = 0;
@@ -177,6 +185,29 @@ int general_launch(tpc_mpc_context* h, const tpc_mpc_params* p, const tpc_mpc_ge
 int check_general_device_io(tpc_mpc_context* h, const tpc_mpc_general_io* io);
 int compact_launch(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy,
                    const void* dphi, void* front, void* rear, int32_t* iters, hipStream_t s);
+// AUTO's presolve around a compact solve whose tolerance pass the caller launches itself (tpc_mpc_mixed.hip starts the
+// longest bin's presolve before the first bin and finishes it behind the last): begin forks the handle's side stream and
+// launches the bit-exact kernels there for the instances lambda predicts to end on the cap; compact_launch(..., ps) then
+// runs the tolerance pass only; finish joins, merges the side results over the pass's and runs the flag-driven second pass
+// for what the prediction missed.  ps->on false: nothing was started (not applicable) and finish does the plain second pass.
+struct Presolve {
+    bool on = false;
+    bool deferred = false;      // compact_launch leaves merge + second pass to presolve_finish
+    double lambda_from = 0.0;
+    uint32_t limit = 0;         // the longest queue the presolve kernel takes (one round of its wavefronts)
+    int group_waves = 0;        // what is left of the chip for the tolerance family's persistent grid meanwhile
+    uint32_t* queue = nullptr;  // instances taken, and how many (device)
+    uint32_t* queue_len = nullptr;
+    void *side_front = nullptr, *side_rear = nullptr;
+    int32_t* side_iters = nullptr;
+    int32_t* select = nullptr;  // the tolerance pass's iteration counts (what the second pass selects on)
+};
+int presolve_begin(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy, const void* dphi,
+                   hipStream_t s, Presolve* ps);
+int compact_launch_ps(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy,
+                      const void* dphi, void* front, void* rear, int32_t* iters, hipStream_t s, Presolve* ps);
+int presolve_finish(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy, const void* dphi,
+                    void* front, void* rear, int32_t* iters, hipStream_t s, Presolve* ps);
 bool group_applicable(const tpc_mpc_context* h, const tpc_mpc_params* p, int H);
 // scratch of the LANE family for (H, dtype, n), without launching (grows the handle's workspace)
 int reserve_lane_workspace(tpc_mpc_context* h, int H, int dtype, int64_t n);

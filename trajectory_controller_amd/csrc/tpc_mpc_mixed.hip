@@ -157,14 +157,34 @@ int run_mixed(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const int3
     }
     if (!h->fork_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
     if (any_group || live == 1) {
+        // AUTO's presolve of the LONGEST horizon's bin -- the one whose cap-bound instances cost a 10 000-iteration chain --
+        // starts here, on the handle's side stream and on SIMDs of its own, before the first bin, and is finished behind the
+        // last; every persistent grid launched meanwhile keeps to the other SIMDs (tpc_mpc_api.cpp: presolve_begin)
+        int last = -1;
+        for (int i = 0; i < bins.nb; ++i)
+            if (hc[i]) last = i;
+        Presolve ps;
+        tpc_mpc_params ql = *p;
+        ql.horizon = bins.horizon[last];
+        const int64_t ol = ho[last];
+        int rc = presolve_begin(h, &ql, hc[last], gv + ol, gdy + ol, gdphi + ol, s, &ps);
+        ps.deferred = true;
+        auto bail = [&](int code) {   // the side stream got work: the caller's stream must not run ahead of it
+            if (ps.on) { (void)hipEventRecord(h->pre_done, h->pre_stream); (void)hipStreamWaitEvent(s, h->pre_done, 0); h->pre_busy = false; }
+            return code;
+        };
+        if (rc) return bail(rc);
         for (int i = 0; i < bins.nb; ++i) {   // ascending horizon
             if (!hc[i]) continue;
             tpc_mpc_params q = *p;
             q.horizon = bins.horizon[i];
             const int64_t o = ho[i];
-            int rc = compact_launch(h, &q, hc[i], gv + o, gdy + o, gdphi + o, gfront + o, grear + o, d_iters ? giters + o : nullptr, s);
-            if (rc) return rc;
+            if (i == last) rc = compact_launch_ps(h, &q, hc[i], gv + o, gdy + o, gdphi + o, gfront + o, grear + o, d_iters ? giters + o : nullptr, s, &ps);
+            else rc = compact_launch(h, &q, hc[i], gv + o, gdy + o, gdphi + o, gfront + o, grear + o, d_iters ? giters + o : nullptr, s);
+            if (rc) return bail(rc);
         }
+        rc = presolve_finish(h, &ql, hc[last], gv + ol, gdy + ol, gdphi + ol, gfront + ol, grear + ol, d_iters ? giters + ol : nullptr, s, &ps);
+        if (rc) return bail(rc);
         if (live > 1) {   // several solves went through this handle: its kernel times / lane statistics describe the last bin only
             h->ev_valid = false;
             h->last_algo = kAlgoMixed;

@@ -95,6 +95,8 @@ size_t sort_temp_bytes(int64_t n);
 hipError_t order_begin(void* temp, hipStream_t s);   // zero the bins the key producer counts into
 hipError_t presolve_merge(const uint32_t* queue, const uint32_t* queue_len, int64_t n, const void* sf, const void* sr,
                           const int32_t* si, void* f, void* r, int32_t* it, uint32_t limit, hipStream_t s);   // AUTO's presolve (tpc_mpc_api.cpp)
+hipError_t presolve_merge_rows(const uint32_t* queue, const uint32_t* queue_len, int64_t n, const void* su, const int32_t* si,
+                               void* u, int32_t* it, int rows, int64_t ld, uint32_t limit, hipStream_t s);
 const uint32_t* order_queue_len(const void* temp);   // device word: queue entries above the lowest 128 bins
 hipError_t order_finish(const uint32_t* keys, const uint32_t* rank, uint32_t* order, int64_t n, void* temp,
                         hipStream_t s);

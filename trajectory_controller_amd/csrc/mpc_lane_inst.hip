@@ -187,6 +187,12 @@ hipError_t resolve(const Args& a, const Knobs& k, const Workspace& ws, const int
     } else if constexpr (std::is_same<Args, GeneralArgs>::value && sizeof(T) == 8 && LanexPlan<kH>::built) {
         constexpr int ng = LanexPlan<kH>::NG;
         const int64_t need = (a.n + ng - 1) / ng;
+        if constexpr (SUBSET == 2) {
+            const int64_t solo = (int64_t)pre_limit / ng;
+            hipLaunchKernelGGL((lanexg_pg_kernel<T, I, kH, false, true>), dim3((unsigned)(need < solo ? need : solo)), dim3(kWave), 0, s,
+                               a, k, (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats, (const uint32_t*)queue_len, 1, pre_limit);
+            return hipGetLastError();
+        }
         const int grid_cap = pg_grid<TagLanexG<I>>(lanexg_pg_kernel<T, I, kH>, kWave);
         hipLaunchKernelGGL((lanexg_pg_kernel<T, I, kH>), dim3((unsigned)(need < grid_cap ? need : grid_cap)), dim3(kWave), 0, s, a, k,
                            (const T*)recs, (const uint32_t*)ws.order, ws.ticket, ws.stats, (const uint32_t*)queue_len, 1);
@@ -238,9 +244,16 @@ hipError_t TPC_CAT(lane_presolve_compact_h, TPC_LANE_H)(const CompactArgs& a, co
     return resolve<double, 2, CompactModel<double>, CompactArgs, 2>(a, k, ws, nullptr, nullptr, s, lambda_from, nullptr, limit);
 }
 hipError_t TPC_CAT(lane_resolve_general_h, TPC_LANE_H)(int I, const GeneralArgs& a, const Knobs& k, const Workspace& ws,
-                                                         const int32_t* select, const uint32_t* gate, hipStream_t s) {
-    if (I == 2) return resolve<double, 2, GeneralModel<double, 2>, GeneralArgs>(a, k, ws, select, gate, s);
-    return resolve<double, 1, GeneralModel<double, 1>, GeneralArgs>(a, k, ws, select, gate, s);
+                                                         const int32_t* select, const uint32_t* gate, hipStream_t s,
+                                                         double presolved_from, const uint32_t* pre_len, uint32_t pre_limit) {
+    if (I == 2) return resolve<double, 2, GeneralModel<double, 2>, GeneralArgs>(a, k, ws, select, gate, s, presolved_from, pre_len, pre_limit);
+    return resolve<double, 1, GeneralModel<double, 1>, GeneralArgs>(a, k, ws, select, gate, s, presolved_from, pre_len, pre_limit);
+}
+hipError_t TPC_CAT(lane_presolve_general_h, TPC_LANE_H)(int I, const GeneralArgs& a, const Knobs& k, const Workspace& ws,
+                                                          double lambda_from, uint32_t limit, hipStream_t s) {
+    if constexpr (!LanexPlan<kH>::built) return hipErrorInvalidValue;
+    if (I == 2) return resolve<double, 2, GeneralModel<double, 2>, GeneralArgs, 2>(a, k, ws, nullptr, nullptr, s, lambda_from, nullptr, limit);
+    return resolve<double, 1, GeneralModel<double, 1>, GeneralArgs, 2>(a, k, ws, nullptr, nullptr, s, lambda_from, nullptr, limit);
 }
 
 // the halves the general-form GROUP kernels borrow (fp64; mpc_groupg_inst.hip): coordinate descent + queue order, and

@@ -274,12 +274,19 @@ __global__ __launch_bounds__(64, 1) void lanex_pg_kernel(CompactArgs g, Knobs kn
 // STATE = true: the caller wants the controller state back (all controls and dlib's v: warm-start chains,
 // tpc_mpc_rollout) and may hand one in (GeneralArgs::controls, ::v) -- lane_pg_kernel's job: every instance goes through
 // this kernel (queue_len = nullptr: the whole batch, g.n entries of `order`), a lane writes its chunk's part of the state.
-template <typename T, int I, int H, bool STATE = false>
+// SOLO: as lanex_pg_kernel's.
+template <typename T, int I, int H, bool STATE = false, bool SOLO = false>
 __global__ __launch_bounds__(64, 1) void lanexg_pg_kernel(GeneralArgs g, Knobs kn, const T* __restrict__ recs,
                                                           const uint32_t* __restrict__ order, uint32_t* __restrict__ ticket,
                                                           unsigned long long* __restrict__ stats,
-                                                          const uint32_t* __restrict__ queue_len, int refill_groups) {
+                                                          const uint32_t* __restrict__ queue_len, int refill_groups,
+                                                          uint32_t solo_limit = 0u) {
     using P = LanexPlan<H>;
+    if constexpr (SOLO) {
+        static_assert(!STATE, "the presolve is a cold-start matter");
+        asm volatile("" ::: "a159");
+        if (__builtin_nontemporal_load(queue_len) > solo_limit) return;
+    }
     static_assert(P::built && P::GA * P::L == H, "chunks of five steps: N = 10, 20, 30, 40");
     static_assert(I == 1 || I == 2, "one or two inputs");
     constexpr int L = P::L, G = P::G, GA = P::GA, NG = P::NG, RL = LaneRec<T, H>::kLen;

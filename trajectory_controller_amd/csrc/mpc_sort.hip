@@ -119,6 +119,25 @@ __global__ void presolve_merge_kernel(const uint32_t* __restrict__ queue, const 
         if (it) it[k] = si[k];
     }
 }
+// ... and for the general form: `rows` output rows of leading dimension ld (u0)
+__global__ void presolve_merge_rows_kernel(const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queue_len,
+                                           const double* __restrict__ su, const int32_t* __restrict__ si, double* __restrict__ u,
+                                           int32_t* __restrict__ it, int rows, int64_t ld, uint32_t limit) {
+    const uint32_t nq = *queue_len;
+    if (nq > limit) return;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+        const uint32_t k = queue[q];
+        for (int j = 0; j < rows; ++j) u[(int64_t)j * ld + k] = su[(int64_t)j * ld + k];
+        if (it) it[k] = si[k];
+    }
+}
+hipError_t presolve_merge_rows(const uint32_t* queue, const uint32_t* queue_len, int64_t n, const void* su, const int32_t* si,
+                               void* u, int32_t* it, int rows, int64_t ld, uint32_t limit, hipStream_t s) {
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(presolve_merge_rows_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, s, queue, queue_len,
+                       (const double*)su, si, (double*)u, it, rows, ld, limit);
+    return hipGetLastError();
+}
 hipError_t presolve_merge(const uint32_t* queue, const uint32_t* queue_len, int64_t n, const void* sf, const void* sr,
                           const int32_t* si, void* f, void* r, int32_t* it, uint32_t limit, hipStream_t s) {
     const int64_t blocks = (n + 255) / 256;

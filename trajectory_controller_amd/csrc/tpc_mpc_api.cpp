@@ -17,7 +17,8 @@ namespace tpc {
     hipError_t lane_general_h##h(int, int, const GeneralArgs&, const Knobs&, const Workspace&, hipStream_t); \
     hipError_t lane_resolve_compact_h##h(const CompactArgs&, const Knobs&, const Workspace&, const int32_t*, const uint32_t*, hipStream_t, double, const uint32_t*, uint32_t); \
     hipError_t lane_presolve_compact_h##h(const CompactArgs&, const Knobs&, const Workspace&, double, uint32_t, hipStream_t); \
-    hipError_t lane_resolve_general_h##h(int, const GeneralArgs&, const Knobs&, const Workspace&, const int32_t*, const uint32_t*, hipStream_t); \
+    hipError_t lane_resolve_general_h##h(int, const GeneralArgs&, const Knobs&, const Workspace&, const int32_t*, const uint32_t*, hipStream_t, double, const uint32_t*, uint32_t); \
+    hipError_t lane_presolve_general_h##h(int, const GeneralArgs&, const Knobs&, const Workspace&, double, uint32_t, hipStream_t); \
     hipError_t wave_compact_h##h(int, const CompactArgs&, const Knobs&, const Workspace&, hipStream_t); \
     hipError_t wave_general_h##h(int, int, const GeneralArgs&, const Knobs&, const Workspace&, hipStream_t); \
     hipError_t ub_compact_h##h(int, int, const CompactArgs&, const Knobs&, const Workspace&, hipStream_t); \
@@ -307,9 +308,10 @@ hipError_t resolve_compact(int H, const CompactArgs& a, const Knobs& k, const Wo
     }
     return hipErrorInvalidValue;
 }
-hipError_t resolve_general(int I, int H, const GeneralArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
+hipError_t resolve_general(int I, int H, const GeneralArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s,
+                           double presolved_from = 0.0, const uint32_t* pre_len = nullptr, uint32_t pre_limit = 0u) {
     switch (H) {
-#define X(h) case h: return lane_resolve_general_h##h(I, a, k, ws, a.iters, a.flags, s);
+#define X(h) case h: return lane_resolve_general_h##h(I, a, k, ws, a.iters, a.flags, s, presolved_from, pre_len, pre_limit);
         X(4) X(5) X(10) X(20) X(30) X(40)
 #undef X
     }
@@ -500,6 +502,45 @@ int context_new(int device, int cu_count, tpc_mpc_context** out) {
 
 // The general form on DEVICE arrays, launches only (the sharded entry, tpc_mpc_comm.cpp, brackets it with the stream
 // order, the flag word and the exchange): io describes the block to solve.
+static double presolve_lambda(const tpc_mpc_params* p);
+// AUTO's presolve (see presolve_begin below): scratch of its own in the LANE layout, `side_bytes` behind it, the side
+// stream and its events
+static int presolve_scratch(tpc_mpc_context* h, int H, int dtype, int64_t n, int64_t side_bytes, Workspace* ws, char** side) {
+    const int64_t rec_b = pad256(lane_rec_len(H, dtype) * (int64_t)esize(dtype) * n), col_b = pad256(n * 4);
+    const size_t tmp_b = sort_temp_bytes(n);
+    const int64_t lane_b = rec_b + 3 * col_b + pad256((int64_t)tmp_b);
+    int rc = ensure(h, &h->pre, &h->pre_bytes, lane_b + side_bytes);
+    if (rc) return rc;
+    if (!h->pre_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking));
+    if (!h->pre_fork) HIP_TRY(h, hipEventCreateWithFlags(&h->pre_fork, hipEventDisableTiming));
+    if (!h->pre_done) HIP_TRY(h, hipEventCreateWithFlags(&h->pre_done, hipEventDisableTiming));
+    char* b = (char*)h->pre;
+    std::memset(ws, 0, sizeof(*ws));
+    ws->state = b;
+    ws->keys = (uint32_t*)(b + rec_b);
+    ws->rank = (uint32_t*)(b + rec_b + col_b);
+    ws->order = (uint32_t*)(b + rec_b + 2 * col_b);
+    ws->sort_temp = b + rec_b + 3 * col_b;
+    ws->sort_temp_bytes = tmp_b;
+    ws->capacity_bytes = lane_b;
+    ws->ev = nullptr;
+    ws->lanex_below = h->opt_lanex_below;
+    ws->cu_count = h->cu_count;
+    ws->ticket = h->ws_words + 24;   // ticket | queue length | statistics: 32 contiguous bytes, as the second pass's (resolve_workspace)
+    ws->stats = (unsigned long long*)(h->ws_words + 26);
+    *side = b + lane_b;
+    return TPC_MPC_OK;
+}
+// the share of the chip a presolve takes (see presolve_begin): false = this batch is not tried
+static bool presolve_share(tpc_mpc_context* h, int64_t n, Presolve* ps) {
+    const int simds = (h->cu_count > 0 ? h->cu_count : 256) * 4;
+    const int solo_waves = simds * 7 / 16;
+    if (n > (int64_t)solo_waves * 8 * 5) return false;
+    ps->limit = (uint32_t)solo_waves * 8u;
+    ps->group_waves = simds - solo_waves;
+    return true;
+}
+
 int general_launch(tpc_mpc_context* h, const tpc_mpc_params* p, const tpc_mpc_general_io* io, hipStream_t s) {
     const int I = io->inputs, H = p->horizon;
     const int64_t n = io->n;
@@ -519,15 +560,61 @@ int general_launch(tpc_mpc_context* h, const tpc_mpc_params* p, const tpc_mpc_ge
     if (fix && !a.iters) rc = cap_iters_buffer(h, n, &a.iters);
     if (!rc && fix) rc = resolve_reserve(h, H, p->dtype, n);
     if (rc) return rc;
+    // AUTO's presolve, as the compact form's (presolve_begin): side outputs = I rows of u0 and the iteration counts
+    Presolve ps;
+    const double lf = presolve_lambda(p);
+    const int64_t ubytes = pad256((int64_t)I * a.ld * 8);   // (the kernels address row j at u0 + j * ld: the side rows keep the caller's ld)
+    if (fix && algo == TPC_MPC_ALGO_GROUP && lf > 0.0 && !h->pre_busy && presolve_share(h, n, &ps)) {
+        Workspace wp;
+        char* side = nullptr;
+        rc = presolve_scratch(h, H, p->dtype, n, ubytes + pad256(n * 4), &wp, &side);
+        if (rc) return rc;
+        GeneralArgs a2 = a;
+        a2.u0 = side;
+        a2.iters = (int32_t*)(side + ubytes);
+        a2.work_hint = nullptr;
+        ps.side_front = side;
+        ps.side_iters = a2.iters;
+        ps.queue = wp.order;
+        ps.queue_len = wp.ticket + 1;
+        ps.lambda_from = lf;
+        HIP_TRY(h, hipEventRecord(h->pre_fork, s));
+        HIP_TRY(h, hipStreamWaitEvent(h->pre_stream, h->pre_fork, 0));
+        ps.on = true;
+        h->pre_busy = true;
+        h->pre_group_waves = ps.group_waves;
+        hipError_t e = hipErrorInvalidValue;
+        switch (H) {
+#define X(hh) case hh: e = lane_presolve_general_h##hh(I, a2, knobs_of(p), wp, lf, ps.limit, h->pre_stream); break;
+            X(4) X(5) X(10) X(20) X(30) X(40)
+#undef X
+        }
+        if (e != hipSuccess) {
+            h->pre_busy = false;
+            (void)hipEventRecord(h->pre_done, h->pre_stream);
+            (void)hipStreamWaitEvent(s, h->pre_done, 0);
+            return hip_fail(h, e, "kernel launch (presolve)");
+        }
+    }
+    auto join = [&]() {
+        if (!ps.on) return;
+        ps.on = false;
+        h->pre_busy = false;
+        (void)hipEventRecord(h->pre_done, h->pre_stream);
+        (void)hipStreamWaitEvent(s, h->pre_done, 0);
+    };
     Workspace ws;
     rc = prepare_workspace(h, algo, H, p->dtype, n, &ws, 1);
-    if (rc) return rc;
+    if (rc) { join(); return rc; }
     hipError_t e = dispatch_general(algo, I, H, p->dtype, a, knobs_of(p), ws, s);
+    join();
+    if (e == hipSuccess && ps.lambda_from > 0.0)
+        e = presolve_merge_rows(ps.queue, ps.queue_len, n, ps.side_front, ps.side_iters, a.u0, a.iters, I, a.ld, ps.limit, s);
     if (e == hipSuccess && fix) {
         Workspace ws2;
         rc = resolve_workspace(h, H, p->dtype, n, &ws2);
         if (rc) return rc;
-        e = resolve_general(I, H, a, knobs_of(p), ws2, s);
+        e = resolve_general(I, H, a, knobs_of(p), ws2, s, ps.lambda_from, ps.queue_len, ps.limit);
     }
     if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
     return TPC_MPC_OK;
@@ -562,11 +649,13 @@ static void compact_args(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n,
 // prediction, not a decision: an instance it takes comes back with dlib's bits whether it capped or not, one it misses is
 // caught by the flag-driven second pass as before.  Horizons below 30 never get near the cap with dlib's defaults and
 // (and N = 30: lambda <= 1.1e6 at 4 m/s) are left alone: a presolve that finds nothing still costs GROUP its share of the chip.
-static double presolve_lambda(const tpc_mpc_params* p) {
+double presolve_lambda_impl(const tpc_mpc_params* p) {
     if (p->horizon < 40 || p->max_iter < 2000) return 0.0;
     const double t = (double)p->max_iter / 7.0;
     return t * t;
 }
+
+static double presolve_lambda(const tpc_mpc_params* p) { return presolve_lambda_impl(p); }
 
 int presolve_begin(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const void* v, const void* dy, const void* dphi,
                    hipStream_t s, Presolve* ps) {
@@ -580,37 +669,16 @@ int presolve_begin(tpc_mpc_context* h, const tpc_mpc_params* p, int64_t n, const
     // bounded by its longest instance rather than by its share of the chip at the batch sizes it is AUTO's choice for
     // (16 384 x N = 40: 4.7 ms on the whole chip, 8.8 on 11 / 16).  A batch whose predicted set cannot run in ONE round of
     // those wavefronts is left to the second pass -- decided on the device, where the set's size is known; a batch too
-    // large for a fifth of it to fit is not tried.
-    const int simds = (h->cu_count > 0 ? h->cu_count : 256) * 4;
-    const int solo_waves = simds * 7 / 16;
-    if (n > (int64_t)solo_waves * 8 * 5) return TPC_MPC_OK;
-    ps->limit = (uint32_t)solo_waves * 8u;
-    ps->group_waves = simds - solo_waves;
-    // scratch of its own (the tolerance pass runs in the handle's main scratch at the same time): LANE layout | side outputs
-    const int H = p->horizon, dtype = p->dtype;
-    const int64_t rec_b = pad256(lane_rec_len(H, dtype) * (int64_t)esize(dtype) * n), col_b = pad256(n * 4), out_b = pad256(n * 8);
-    const size_t tmp_b = sort_temp_bytes(n);
-    const int64_t lane_b = rec_b + 3 * col_b + pad256((int64_t)tmp_b);
-    int rc = ensure(h, &h->pre, &h->pre_bytes, lane_b + 2 * out_b + col_b);
-    if (rc) return rc;
-    if (!h->pre_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking));
-    if (!h->pre_fork) HIP_TRY(h, hipEventCreateWithFlags(&h->pre_fork, hipEventDisableTiming));
-    if (!h->pre_done) HIP_TRY(h, hipEventCreateWithFlags(&h->pre_done, hipEventDisableTiming));
-    char* b = (char*)h->pre;
+    // large for a fifth of it to fit is not tried (presolve_share).
+    if (!presolve_share(h, n, ps)) return TPC_MPC_OK;
+    const int H = p->horizon;
+    const int64_t out_b = pad256(n * 8), col_b = pad256(n * 4);
     Workspace ws;
-    std::memset(&ws, 0, sizeof(ws));
-    ws.state = b;
-    ws.keys = (uint32_t*)(b + rec_b);
-    ws.rank = (uint32_t*)(b + rec_b + col_b);
-    ws.order = (uint32_t*)(b + rec_b + 2 * col_b);
-    ws.sort_temp = b + rec_b + 3 * col_b;
-    ws.sort_temp_bytes = tmp_b;
-    ws.capacity_bytes = lane_b;
-    ws.ev = nullptr;
-    ws.lanex_below = h->opt_lanex_below;
-    ws.cu_count = h->cu_count;
-    ws.ticket = h->ws_words + 24;   // ticket | queue length | statistics: 32 contiguous bytes, as the second pass's (resolve_workspace)
-    ws.stats = (unsigned long long*)(h->ws_words + 26);
+    char* side = nullptr;
+    int rc = presolve_scratch(h, H, p->dtype, n, 2 * out_b + col_b, &ws, &side);
+    if (rc) return rc;
+    char* b = side;
+    const int64_t lane_b = 0;
     ps->side_front = b + lane_b;
     ps->side_rear = b + lane_b + out_b;
     ps->side_iters = (int32_t*)(b + lane_b + 2 * out_b);

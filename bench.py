@@ -384,7 +384,7 @@ def main():
         # dominant kernel = the longer of the two launches of a step
         dom_ms = max(k1, k2)
         dom_name = {1: "wave_kernel", 2: "lane_pg_fused_kernel" if k2 >= k1 else "lane_cd_kernel",
-                    3: "ub_pg_kernel" if k2 >= k1 else "ub_cd_kernel",
+                    3: ("ub_pg_asm_kernel" if (a.dtype == "f64" and H == 20) else "ub_pg_kernel") if k2 >= k1 else "ub_cd_kernel",   # (fp64 N = 20: the hand-written kernel, csrc/mpc_ub_asm.h)
                     4: "group_pg_kernel" if k2 >= k1 else "ub_cd_kernel"}[algo_ran]
         alg_bytes = 5 * esz * n                       # 3 in + 2 out scalars per solve
         # the PG kernel also reads what the CD kernel left per instance (not algorithmic traffic)

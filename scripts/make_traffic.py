@@ -10,9 +10,9 @@ MI355X_MICROARCH.md (HBM) asks:
 Kernels with no calibration of their own get k = 1 and say so."""
 import csv, json, os, sys
 src = sys.argv[1] if len(sys.argv) > 1 else "profiles"
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r05"
 CONFIGS = {   # tag -> (kernel in the csv, bench key, k, note)
-    "headline": ("tpc::ub_pg_kernel<fast>", "ub_pg_kernel_f64_H20_n262144", 1, "strided record reads: k=1 (as calibrated on the LANE kernel's identical access pattern)"),
+    "headline": ("tpc::ub_pg_asm_kernel", "ub_pg_asm_kernel_f64_H20_n262144", 1, "record reads, 25 x 16 B per instance: k=1 (as calibrated on the LANE kernel's strided record reads)"),
     "bitexact": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_f64_H20_n262144", 1, "strided record reads: k=1 (calibrated)"),
     # (fp32 at 262 144 x N=20 under AUTO is GROUP since the end of round 4: two lanes per instance, two wavefronts per SIMD)
     "fp32": ("tpc::group_pg_kernel<f32 moved>", "group_pg_kernel_f32_H20_n262144", 1, "chunked record reads: k=1 (uncalibrated)"),

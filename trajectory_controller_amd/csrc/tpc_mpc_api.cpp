@@ -485,6 +485,7 @@ int context_new(int device, int cu_count, tpc_mpc_context** out) {
     if (!h) return fail(nullptr, TPC_MPC_ERR_ALLOC, "out of host memory");
     h->device = device;
     h->cu_count = cu_count;
+    h->device_cu_count = cu_count;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc((void**)&h->ws_words, 128);
     if (e == hipSuccess) e = hipMemset(h->ws_words, 0, 128);
@@ -533,7 +534,7 @@ static int presolve_scratch(tpc_mpc_context* h, int H, int dtype, int64_t n, int
 }
 // the share of the chip a presolve takes (see presolve_begin): false = this batch is not tried
 static bool presolve_share(tpc_mpc_context* h, int64_t n, Presolve* ps) {
-    const int simds = (h->cu_count > 0 ? h->cu_count : 256) * 4;
+    const int simds = (h->device_cu_count > 0 ? h->device_cu_count : 256) * 4;
     const int solo_waves = simds * 7 / 16;
     if (n > (int64_t)solo_waves * 8 * 5) return false;
     ps->limit = (uint32_t)solo_waves * 8u;
@@ -1398,7 +1399,7 @@ int tpc_mpc_x_set_group_share(tpc_mpc_handle h, int waves, int cu_count) {
         if (!h) return fail(nullptr, TPC_MPC_ERR_BAD_ARG, "null handle");
         if (waves < 0 || cu_count < 0) return fail(h, TPC_MPC_ERR_BAD_ARG, "need waves >= 0, cu_count >= 0");
         h->max_waves = waves;
-        if (cu_count > 0) h->cu_count = cu_count;
+        h->cu_count = cu_count > 0 ? cu_count : h->device_cu_count;   // (0: back to the device's own)
         return TPC_MPC_OK;
     });
 }

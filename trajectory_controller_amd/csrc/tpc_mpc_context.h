@@ -27,7 +27,8 @@ constexpr size_t kTpcErrLen = 512;
 
 struct tpc_mpc_context {
     int device = 0;
-    int cu_count = 0;
+    int cu_count = 0;                // what AUTO's crossovers are scaled to: the device's, unless tpc_mpc_x_set_group_share overrides it
+    int device_cu_count = 0;         // the device's own (cu_count == 0 in that call restores it)
     char err[kTpcErrLen] = "";
     // device scratch (grown on demand, never shrunk)
     void* ws_state = nullptr;

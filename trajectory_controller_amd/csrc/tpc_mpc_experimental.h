@@ -20,11 +20,11 @@ extern "C" {
 int tpc_mpc_x_set_work_hint(tpc_mpc_handle h, const int32_t* hint, int64_t n, int mem);
 
 /* The share of the chip a handle's GROUP solves take: `waves` persistent wavefronts (0 = one per SIMD, the default) and
- * the CU count AUTO's crossover table is scaled to (0 = the device's).  What tpc_mpc_solve_batch_compact_mixed sets on
+ * the CU count AUTO's crossover table is scaled to (0 = back to the device's own).  What tpc_mpc_solve_batch_compact_mixed sets on
  * the child handles of its bins; exported to measure one bin on a share by itself (scripts/group_share.py). */
 int tpc_mpc_x_set_group_share(tpc_mpc_handle h, int waves, int cu_count);
 
-/* The bit-exact LANE family, compact form, fp64, N = 10 / 20 / 40: batches of fewer than `below` instances run their
+/* The bit-exact LANE family, compact form, fp64, N = 10 / 20 / 30 / 40: batches of fewer than `below` instances run their
  * projected-gradient phase G lanes per instance (csrc/mpc_lanex.h: same bits, a third of the iteration's latency, a third
  * of the throughput of a full chip).  -1 (default): the measured crossover; 0: never.  Exported to measure that crossover
  * (scripts/lanex_crossover.py). */

@@ -27,6 +27,13 @@ bool TrajectoryPointController::initialize() {
     // the one new piece of state: a solver handle on the configured GPU.  No CPU fallback: without
     // the device the module refuses to initialise.
     const int device = config().get<int>("gpuDevice", 0);
+    // the library next to this module must speak the header it was compiled against: ABI 4 changed the meaning of a field
+    // of tpc_mpc_params (`reserved` became `options` and must be zero), later versions only add symbols
+    if (tpc_mpc_abi_version() < 4 || tpc_mpc_abi_version() > TPC_MPC_ABI_VERSION) {
+        logger.error("trajectory_point_controller") << "libtpc_mpc.so speaks ABI " << tpc_mpc_abi_version()
+                                                     << ", this module was built for " << TPC_MPC_ABI_VERSION;
+        return false;
+    }
     if (tpc_mpc_create(device, &solver_) != TPC_MPC_OK) {
         logger.error("trajectory_point_controller") << "tpc_mpc_create failed: " << tpc_mpc_last_error(nullptr);
         return false;

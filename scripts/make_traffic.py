@@ -12,15 +12,15 @@ import csv, json, os, sys
 src = sys.argv[1] if len(sys.argv) > 1 else "profiles"
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r05"
 CONFIGS = {   # tag -> (kernel in the csv, bench key, k, note)
-    "headline": ("tpc::ub_pg_asm_kernel", "ub_pg_asm_kernel_f64_H20_n262144", 1, "record reads, 25 x 16 B per instance: k=1 (as calibrated on the LANE kernel's strided record reads)"),
+    # the hand-written kernel reads each instance's 400-byte record with 25 dwordx4 loads + one 4-byte queue entry: 105.9 MB
+    # known, FETCH_SIZE reports 0.64 of it -> k = 1.57 (between the wide-streaming k = 2 and the strided 8-byte k = 1)
+    "headline": ("tpc::ub_pg_asm_kernel", "ub_pg_asm_kernel_f64_H20_n262144", 1.57, "25 x 16 B record loads per instance: k calibrated on this kernel's own known read set (404 B x n)"),
     "bitexact": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_f64_H20_n262144", 1, "strided record reads: k=1 (calibrated)"),
     # (fp32 at 262 144 x N=20 under AUTO is GROUP since the end of round 4: two lanes per instance, two wavefronts per SIMD)
     "fp32": ("tpc::group_pg_kernel<f32 moved>", "group_pg_kernel_f32_H20_n262144", 1, "chunked record reads: k=1 (uncalibrated)"),
     "group_f32_h20_256k": ("tpc::group_pg_kernel<f32 moved>", "group_pg_kernel_f32_H20_n262144_lane_h", 1, "the same kernel through scripts/lane_h.py: k=1 (uncalibrated)"),
     "group_f32_h40_256k": ("tpc::group_pg_kernel<f32 mask>", "group_pg_kernel_f32_H40_n262144", 1, "chunked record reads: k=1 (uncalibrated)"),
     "config2": ("tpc::wave_pair_queue_kernel", "wave_kernel_f64_H10_n4096", 1, "broadcast loads of 3 scalars per wavefront + the queue order: uncalibrated, k=1"),
-    "h30": ("tpc::ub_pg_kernel<fast>", "ub_pg_kernel_f64_H30_n262144", 1, "strided record reads: k=1"),
-    "h40": ("tpc::ub_pg_kernel<fast>", "ub_pg_kernel_f64_H40_n262144", 1, "strided record reads: k=1"),
     "general": ("tpc::lane_pg_fused_kernel<fast>", "lane_pg_fused_kernel_general_I2_f64_H20_n262144", 1, "strided record reads + SoA model loads: k=1"),
     "group_h20": ("tpc::group_pg_kernel", "group_pg_kernel_f64_H20_n16384", 1, "chunked record reads, 8 lanes per record: k=1 (uncalibrated)"),
     "group_h20_64k": ("tpc::group_pg_kernel", "group_pg_kernel_f64_H20_n65536", 1, "chunked record reads: k=1 (uncalibrated)"),

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Every rocprofv3 summary DESIGN.md / profiles/README.md quote (run from the repo root, through gpurun):
-#   bash scripts/profile_all.sh r04 [a|b|c|d|e|all]   -> gpurun_out/r04_<tag>_{kernel_stats,pmc}.csv  (copy into profiles/)
+#   bash scripts/profile_all.sh r05 [a|b|c|d|e|all]   -> gpurun_out/r05_<tag>_{kernel_stats,pmc}.csv  (copy into profiles/)
 # Each tag = scripts/profile.sh: one --kernel-trace --stats run, then separate --pmc runs.  Three parts, because one
 # gpurun call is limited to 20 minutes:  a = the bench.py workloads, b = long horizons / general form / follow,
 # c = the GROUP family (round 4) and config 5, d = GROUP at 262 144 x N = 30 / 40 and for the general form, the bit-exact family G lanes per instance.
 # bench.py runs with --no-pipelined: the default run appends a two-batches-in-flight leg after its timed region,
 # whose overlapping dispatches would be averaged into the same per-kernel rows.
-R=${1:-r04}
+R=${1:-r05}
 PART=${2:-all}
 P="bash scripts/profile.sh"
 LOG=gpurun_out/prof_${R}_${PART}.log
@@ -18,8 +18,6 @@ $P ${R}_config2   python3 bench.py --steps 20 --warmup 2 --batch 4096 --horizon 
 $P ${R}_fp32      python3 bench.py --steps 10 --warmup 2 --dtype f32 --no-cpu --no-pipelined --no-config1 --no-config2 --no-config5 --no-config4 --no-mid >> $LOG 2>&1
 fi
 if [ $PART = b ] || [ $PART = all ]; then
-$P ${R}_h30        python3 scripts/lane_h.py f64 30 262144 lane_fma >> $LOG 2>&1
-$P ${R}_h40        python3 scripts/lane_h.py f64 40 262144 lane_fma >> $LOG 2>&1
 $P ${R}_scan       python3 scripts/lane_h.py f64 40 8192 wave >> $LOG 2>&1
 $P ${R}_wave2      python3 scripts/general_rate.py 2 40 wave 8192 >> $LOG 2>&1
 $P ${R}_general    python3 scripts/general_rate.py 2 20 lane >> $LOG 2>&1
@@ -32,6 +30,7 @@ $P ${R}_group_h20_64k python3 scripts/lane_h.py f64 20 65536 group >> $LOG 2>&1
 $P ${R}_group_h40  python3 scripts/lane_h.py f64 40 16384 group >> $LOG 2>&1
 $P ${R}_group_h10  python3 scripts/lane_h.py f64 10 32768 group >> $LOG 2>&1
 $P ${R}_config5    python3 scripts/mixed_horizons.py f64fast >> $LOG 2>&1
+$P ${R}_config5_shipped python3 scripts/mixed_horizons.py f64 >> $LOG 2>&1   # with AUTO's guarantee: the presolve beside the bins
 fi
 if [ $PART = d ] || [ $PART = all ]; then   # GROUP where AUTO takes it at the full batch (long horizons), and the general form
 $P ${R}_group_h40_256k python3 scripts/lane_h.py f64 40 262144 group >> $LOG 2>&1

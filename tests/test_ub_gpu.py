@@ -51,8 +51,12 @@ def _run(torch, s, v, dy, dphi, dtype=None):
     return f.cpu().numpy(), r.cpu().numpy(), it.cpu().numpy()
 
 
-@pytest.mark.parametrize("H,n", [(4, 5000), (5, 5000), (10, 3000), (20, 2500), (30, 1200), (40, 700)])
+@pytest.mark.parametrize("H,n", [(4, 5000), (5, 5000), (10, 3000), (20, 2500)])
 def test_ub_bits_vs_model_f64(torch_cuda, model, H, n):
+    """(N = 30 / 40 in fp64: GROUP takes LANE_FMA's requests since round 5 -- tpc_mpc_api.cpp, pick_algo; the one-lane
+    screened kernels of those horizons are no longer built.  The model's arithmetic there still serves the host path of
+    tpc_mpc_solve_one, tests/test_host_path.py; the exact-stop-test build, which GROUP falls back on, is held to the
+    model below: test_ub_exact_build_long_horizons.)"""
     from trajectory_controller_amd.synth import compact_inputs
     v, dy, dphi = compact_inputs(H, n, first=200000)
     mf, mr, mit, _ = model.solve_compact(H, v, dy, dphi, nthreads=8)

@@ -98,7 +98,12 @@ hipError_t run(const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStr
 // with the extra per-step addition.
 hipError_t TPC_CAT(ub_compact_h, TPC_UB_H)(int dtype, int equal_bounds, const CompactArgs& a, const Knobs& k,
                                             const Workspace& ws, hipStream_t s) {
-    if (dtype == 0) return equal_bounds ? run<double, true>(a, k, ws, s) : run<double, false>(a, k, ws, s);
+    if (dtype == 0) {
+        // fp64 at N = 30 / 40: GROUP takes LANE_FMA's requests (tpc_mpc_api.cpp, pick_algo); the screened one-lane kernels
+        // of those horizons -- the ones that parked their registers in scratch around every refill -- are not built
+        if constexpr (kH >= 30) return hipErrorInvalidValue;
+        else return equal_bounds ? run<double, true>(a, k, ws, s) : run<double, false>(a, k, ws, s);
+    }
     return run<float, true>(a, k, ws, s);   // fp32 keeps dlib's coordinates: no bound-dependent build (mpc_ub_model.h)
 }
 

@@ -134,6 +134,13 @@ int pick_algo(const tpc_mpc_context* h, int algo, int I, int H, int64_t n, int d
     const int lane = fma_ok ? TPC_MPC_ALGO_LANE_FMA : TPC_MPC_ALGO_LANE;   // the throughput family of AUTO
     if (algo == TPC_MPC_ALGO_WAVE) return wave_ok ? algo : -1;
     if (algo == TPC_MPC_ALGO_LANE) return algo;
+    // LANE_FMA named at N = 30 / 40, compact form, fp64: GROUP (the same arithmetic, G lanes per instance) takes the request.
+    // The one-lane kernels there parked their state in scratch around every refill pass -- 0.28 / 4.4 GB of HBM traffic per
+    // 262 144-instance launch, 26x / 419x the algorithmic bytes -- and lost to GROUP at every batch size (43.9 against 54-56 ms
+    // at N = 40); they are no longer built (mpc_ub_inst.hip).  fp32 keeps them (no spill), as does the exact-stop-test build
+    // GROUP itself falls back on.
+    if (algo == TPC_MPC_ALGO_LANE_FMA && compact && fma_ok && dtype == TPC_MPC_F64 && H >= 30 && group_lanes(h, H) > 0)
+        return TPC_MPC_ALGO_GROUP;
     if (algo == TPC_MPC_ALGO_LANE_FMA) return lane;
     // GROUP is LANE_FMA's arithmetic with G lanes per instance: the same requests, the horizons a group divides
     if (algo == TPC_MPC_ALGO_GROUP) return (compact ? (fma_ok && group_lanes(h, H) > 0) : group_general) ? algo : lane;

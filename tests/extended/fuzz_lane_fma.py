@@ -24,7 +24,9 @@ threads = int(os.environ.get("THREADS", "16"))
 bad = flips = total = 0
 worst = 0.0
 for s_i in range(sets):
-    H = (4, 5, 10, 20, 30, 40)[s_i % 6]
+    # (fp64 at N = 30 / 40: GROUP takes LANE_FMA's requests since round 5 -- tests/extended/fuzz_group.py covers it;
+    #  N = 20 with equal bounds is the hand-written kernel, csrc/mpc_ub_asm.h: weighted up)
+    H = ((4, 5, 10, 20, 20, 20) if DT == "f64" else (4, 5, 10, 20, 30, 40))[s_i % 6]
     m = n if H <= 20 else n // 4
     w = (10 ** rng.uniform(-1, 2), 10 ** rng.uniform(-1, 2), 10 ** rng.uniform(-4, 1), 10 ** rng.uniform(-2, 1.5))
     kind = rng.integers(0, 5)

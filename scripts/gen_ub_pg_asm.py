@@ -28,7 +28,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import ubasm
 
 H = 20
-NA = int(sys.argv[1]) if len(sys.argv) > 1 else 4   # steps H-NA .. H-1 keep v in AGPRs
+NA = int(sys.argv[1]) if len(sys.argv) > 1 else 3   # steps H-NA .. H-1 keep v in AGPRs
 DIAG = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # diagnostic builds only (scripts/build_asm_variant.sh): the wave-iteration statistic
                                                       # becomes the shader cycles spent in: 1 ticket wait, 2 queue-entry wait, 3 record wait, 4 a whole refill pass, 5 the iteration loop
 BATCH = 3                                            # lanes that must wait before a refill pass is due (UbRefillBatch<20>)
@@ -36,11 +36,15 @@ RL_BYTES = 400                                       # LaneRec<double, 20>::kLen
 P = ubasm.Plan(H=H, NA=NA, batch=BATCH, all_hard=True)
 NREG = P.NREG
 X, V, Wz, Wy, t0, t1, n0, n1, acc, C = P.X, P.V, P.Wz, P.Wy, P.t0, P.t1, P.n0, P.n1, P.acc, P.C
-assert P.top <= 252
-VK, VBASE, VCAP, VTMP = "v252", "v253", "v254", "v255"   # instance index, iteration-count base, cap (wave iteration), scratch
+# per-lane bookkeeping touched only at stop events and refill passes: instance index, iteration-count base, cap (in wave
+# iterations).  With room (NA >= 4) in the last VGPRs; with NA = 3 the loop's state fills all 256 and they live in AGPRs
+PARK = P.top > 252
+assert P.top <= 256
+VK, VBASE, VCAP, VTMP = ("v252", "v253", "v254", "v255") if not PARK else (None, None, None, n0.lo)
 # AGPRs: v of the AGPR steps, z0
 AG = {}
-_n = 0
+_n = 3 if PARK else 0
+AK, ABASE, ACAP = "a0", "a1", "a2"
 for q in range(2 * NREG, 2 * H):
     AG[f"av{q}lo"], AG[f"av{q}hi"] = f"a{_n}", f"a{_n + 1}"; _n += 2
 AG["z0lo"], AG["z0hi"] = f"a{_n}", f"a{_n + 1}"; _n += 2
@@ -62,7 +66,8 @@ def publish(which, it_expr):
     """stores the controls of the lanes in EXEC: front[k] = control(0, x[0]), rear[k] = control(1, x[1]) (Unit::control:
     the bounds and the untouched start point come out exactly), iters[k] = it_expr + the lane's base; `which`: 'x' = from
     x[0], x[1]; 'zero' = 0, 0 (non-finite inputs).  Uses t0, t1, acc, VTMP, vcc, stmp."""
-    o = [f"v_lshlrev_b32 {VTMP}, 3, {VK}"]
+    kreg, breg = (VK, VBASE) if not PARK else (n0.hi, n1.lo)
+    o = ([f"v_accvgpr_read_b32 {kreg}, {AK}", f"v_accvgpr_read_b32 {breg}, {ABASE}"] if PARK else []) + [f"v_lshlrev_b32 {VTMP}, 3, {kreg}"]
     if which == "zero":
         o += [f"v_mov_b64 {t0}, 0", f"v_mov_b64 {t1}, 0"]
     else:
@@ -75,7 +80,7 @@ def publish(which, it_expr):
                   "s_mov_b64 exec, %[stmp]"]
     o += [f"global_store_dwordx2 {VTMP}, {t0}, %[pfront]", f"global_store_dwordx2 {VTMP}, {t1}, %[prear]",
           "s_cmp_eq_u64 %[piters], 0", "s_cbranch_scc1 1f",
-          f"v_lshlrev_b32 {VTMP}, 2, {VK}", f"v_add_u32 {acc.lo}, {it_expr}, {VBASE}",
+          f"v_lshlrev_b32 {VTMP}, 2, {kreg}", f"v_add_u32 {acc.lo}, {it_expr}, {breg}",
           f"global_store_dword {VTMP}, {acc.lo}, %[piters]", "1:"]
     return o
 
@@ -110,7 +115,8 @@ def stamp_end(k):
 
 
 def gen_body():
-    sc = [scratch(j) for j in range(12)]   # refill scratch pairs
+    sc = [scratch(j) for j in range(14)]   # refill scratch pairs
+    vk, vbase, vcap = (VK, VBASE, VCAP) if not PARK else (sc[12].lo, sc[12].hi, sc[13].lo)   # (refill's working copies)
     o = ["s_mov_b32 %[sdiag], 0"] if DIAG else []
     if DIAG == 6: o += ["s_memtime s[96:97]", "s_waitcnt lgkmcnt(0)"]
     if DIAG == 7: o += ["s_memrealtime s[96:97]", "s_waitcnt lgkmcnt(0)"]
@@ -121,8 +127,11 @@ def gen_body():
         o += [f"v_mov_b64 {r}, 0"]
     for a in AG.values():
         o += [f"v_accvgpr_write_b32 {a}, 0"]
-    o += [f"v_mov_b32 {VK}, 0", f"v_mov_b32 {VBASE}, 0", f"v_mov_b32 {VCAP}, -1",
-          f"v_mov_b64 {C['cgl0']}, %[sgrl0]", f"v_mov_b64 {C['cgl1']}, %[sgrl1]"]
+    if PARK:
+        o += [f"v_accvgpr_write_b32 {AK}, 0", f"v_accvgpr_write_b32 {ABASE}, 0", f"v_accvgpr_write_b32 {ACAP}, -1"]
+    else:
+        o += [f"v_mov_b32 {VK}, 0", f"v_mov_b32 {VBASE}, 0", f"v_mov_b32 {VCAP}, -1"]
+    o += [f"v_mov_b64 {C['cgl0']}, %[sgrl0]", f"v_mov_b64 {C['cgl1']}, %[sgrl1]"]
     # ---------------- main: refill when due, else iterate
     o += ["MAIN%=:",
           "s_or_b64 %[stmp], %[shave], %[sexh]", "s_not_b64 %[swant], %[stmp]",
@@ -151,10 +160,10 @@ def gen_body():
           "s_mov_b64 exec, %[snew]",
           "s_cbranch_execz RDONE%=",
           f"v_lshlrev_b32 {sc[0].lo}, 2, {sc[0].lo}"] + stamp_begin(2) + [
-          f"global_load_dword {VK}, {sc[0].lo}, %[porder]",
-          "s_waitcnt vmcnt(0)"] + stamp_end(2) + [
+          f"global_load_dword {vk}, {sc[0].lo}, %[porder]",
+          "s_waitcnt vmcnt(0)"] + stamp_end(2) + ([f"v_accvgpr_write_b32 {AK}, {vk}"] if PARK else []) + [
           f"v_mov_b32 {sc[0].hi}, {RL_BYTES}",
-          f"v_mad_u64_u32 {sc[1]}, vcc, {VK}, {sc[0].hi}, %[precs]"]      # &recs[k * RL]
+          f"v_mad_u64_u32 {sc[1]}, vcc, {vk}, {sc[0].hi}, %[precs]"]      # &recs[k * RL]
     o += stamp_begin(3)
     for i in range(H):
         o += [f"global_load_dwordx4 v[{4 * i}:{4 * i + 3}], {sc[1]}, off offset:{16 * i}"]   # x[2i], x[2i+1]
@@ -173,8 +182,10 @@ def gen_body():
           f"v_add_f64 {sc[11]}, 0, {ty.neg()}",                                      # z0 = 0 - ty
           f"v_accvgpr_write_b32 {AG['z0lo']}, {sc[11].lo}", f"v_accvgpr_write_b32 {AG['z0hi']}, {sc[11].hi}",
           f"v_add_f64 {sc[11]}, %[slo1], {tphi}", f"v_mul_f64 {C['cq']}, %[sgq1], {sc[11]}",   # q1th = gq1 (lo1 + tphi)
-          f"v_subrev_u32 {VBASE}, %[sit], {meta.lo}",                                # lane's count = base + wave iterations
-          f"v_sub_u32 {VCAP}, %[smaxit], {VBASE}"]                                   # wave iteration at which the lane reaches max_iter
+          f"v_subrev_u32 {vbase}, %[sit], {meta.lo}",                                # lane's count = base + wave iterations
+          f"v_sub_u32 {vcap}, %[smaxit], {vbase}"]                                   # wave iteration at which the lane reaches max_iter
+    if PARK:
+        o += [f"v_accvgpr_write_b32 {ABASE}, {vbase}", f"v_accvgpr_write_b32 {ACAP}, {vcap}"]
     # v := x where the coordinate-descent phase ended on its last iteration (mpc.h:330-334), else the start point u = 0
     o += [f"v_mov_b64 {t0}, %[sxz0]", f"v_mov_b64 {t1}, %[sxz1]"]
     for q in range(2 * NREG):
@@ -212,7 +223,7 @@ def gen_body():
           "s_mov_b64 %[stmp], %[snew]",
           "RCAP%=:", "s_cmp_eq_u64 %[stmp], 0", "s_cbranch_scc1 RDONE%=",
           "s_ff1_i32_b64 %[sa], %[stmp]", "s_bitset0_b64 %[stmp], %[sa]",
-          f"v_readlane_b32 %[sb], {VCAP}, %[sa]", "s_min_u32 %[scap], %[scap], %[sb]",
+          f"v_readlane_b32 %[sb], {vcap}, %[sa]", "s_min_u32 %[scap], %[scap], %[sb]",
           "s_branch RCAP%=",
           "RDONE%=:", "s_mov_b64 exec, -1"] + stamp_end(4) + ["s_branch MAIN%="]
     # ---------------- iterate
@@ -231,8 +242,9 @@ def gen_body():
           "s_sub_u32 %[sit], %[scap], %[sleft]", "s_sub_u32 %[sit], %[sit], 1",       # wave iterations so far
           "s_cmp_ge_u32 %[sit], %[scap]", "s_cbranch_scc0 MAIN%="]
     # ---------------- a lane may have reached max_iter (mpc.h:271): publish those, recompute the earliest cap exactly
-    o += ["CAPCHK%=:",
-          f"v_cmp_le_u32_e64 vcc, {VCAP}, %[sit]", "s_and_b64 %[sstop], vcc, %[shave]",
+    capreg = VCAP if not PARK else acc.hi
+    o += ["CAPCHK%=:"] + ([f"v_accvgpr_read_b32 {capreg}, {ACAP}", "s_nop 1"] if PARK else []) + [
+          f"v_cmp_le_u32_e64 vcc, {capreg}, %[sit]", "s_and_b64 %[sstop], vcc, %[shave]",
           "s_cmp_eq_u64 %[sstop], 0", "s_cbranch_scc1 CAPMIN%=",
           "s_or_b32 %[sflags], %[sflags], 2",
           "s_mov_b64 exec, %[sstop]"]
@@ -241,7 +253,7 @@ def gen_body():
           "CAPMIN%=:", "s_mov_b32 %[scap], -1", "s_mov_b64 %[stmp], %[shave]",
           "CAPL%=:", "s_cmp_eq_u64 %[stmp], 0", "s_cbranch_scc1 MAIN%=",
           "s_ff1_i32_b64 %[sa], %[stmp]", "s_bitset0_b64 %[stmp], %[sa]",
-          f"v_readlane_b32 %[sb], {VCAP}, %[sa]", "s_min_u32 %[scap], %[scap], %[sb]",
+          f"v_readlane_b32 %[sb], {capreg}, %[sa]", "s_min_u32 %[scap], %[scap], %[sb]",
           "s_branch CAPL%=",
           "DONE%=:", "s_waitcnt vmcnt(0)"]
     if DIAG == 6: o += ["s_memtime s[98:99]", "s_waitcnt lgkmcnt(0)", "s_sub_u32 %[sdiag], s98, s96"]

@@ -9,7 +9,8 @@ Register plan (one wavefront per SIMD: 256 VGPRs + 256 AGPRs):
     (Z[i], Y[i]) of the forward pass is dead once the backward sweep has consumed it and receives the new momentum
     vector v[i]; the pair holding the old v[i] is dead once the momentum difference is formed and takes (Z[i], Y[i]) in
     the next forward pass.  Two iterations (halves A and B) are written out, so no value is ever copied.
-  * v of the last NA steps lives in AGPRs (2 + 2 transfers per value and iteration), their W pairs never swap.
+  * v of the last NA steps lives in AGPRs (2 + 2 transfers per value and iteration), their W pairs never swap.  NA = 3 is the
+    least that fits: 3 x 8 + 17 x 12 registers of state, 18 of constants, 10 temporaries = 256.
 """
 
 

@@ -62,7 +62,7 @@ hipError_t pg_launch(const CompactArgs& a, const Knobs& k, const Workspace& ws, 
     constexpr int bt = kWave * UbPlan<T, kH>::occ;
     const int64_t need = (a.n + bt - 1) / bt;
 #if TPC_UB_H == 20 && !defined(TPC_UB_NO_ASM)   // (TPC_UB_NO_ASM: the compiler's loop, for A/B runs -- scripts/build_ub_variant.sh)
-    if constexpr (sizeof(T) == 8 && EQB && MODE == 2) {   // mpc_ub_asm.h: the same kernel, 538 instructions per iteration instead of 708
+    if constexpr (sizeof(T) == 8 && EQB && MODE == 2) {   // mpc_ub_asm.h: the same kernel, 530 instructions per iteration instead of 708
         static_assert(bt == kWave, "one wavefront per workgroup");
         return ub_pg_asm_launch(a, k, ws, need, s);   // (its own translation unit: mpc_ub_asm_inst.hip)
     }

@@ -48,6 +48,14 @@ AK, ABASE, ACAP = "a0", "a1", "a2"
 for q in range(2 * NREG, 2 * H):
     AG[f"av{q}lo"], AG[f"av{q}hi"] = f"a{_n}", f"a{_n + 1}"; _n += 2
 AG["z0lo"], AG["z0hi"] = f"a{_n}", f"a{_n + 1}"; _n += 2
+# CHUNK > 0: tickets are drawn CHUNK at a time (one device-scope atomic and one load of queue entries per CHUNK / BATCH refill
+# passes instead of one each per pass: ~1 770 and ~490 cycles of waiting, scripts/probes/asm_diag.sh); the chunk's queue entries
+# wait in an AGPR, lane j = entry j.  Measured SLOWER on one box (profiles/r05_ab_chunk.txt: 4.75 ms with a draw per pass, 4.90 /
+# 4.94 / 4.92 with chunks of 6 / 12 / 24 -- a pass that finds fewer tickets than waiting lanes leaves lanes idle, +1.2 % wave
+# iterations, and the waiting it saves was not the limit: the kernel is power-bound).  0 (shipped): a ticket draw per pass
+CHUNK = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+AORD = f"a{_n}"
+if CHUNK: _n += 1
 N_AGPR = _n
 P.A = AG
 P.S = {n: f"%[{n}]" for n in ("sgq0", "sgq1", "sgrs0", "sgrs1", "slo1", "sgeps", "shave", "sleft")}
@@ -123,6 +131,8 @@ def gen_body():
     # ---------------- prologue: state of every lane to zero (idle lanes iterate on it harmlessly)
     o += ["s_mov_b64 %[shave], 0", "s_mov_b64 %[sexh], 0", "s_mov_b32 %[sit], 0", "s_mov_b32 %[srefills], 0",
           "s_mov_b32 %[sflags], 0", "s_mov_b32 %[scap], -1"]
+    if CHUNK:
+        o += ["s_mov_b32 %[scnext], 0", "s_mov_b32 %[scend], 0", "s_mov_b32 %[scbase], 0", f"v_accvgpr_write_b32 {AORD}, 0"]
     for r in X + V + list(C.values()):
         o += [f"v_mov_b64 {r}, 0"]
     for a in AG.values():
@@ -144,25 +154,70 @@ def gen_body():
           "s_cmp_eq_u64 %[shave], 0", "s_cbranch_scc1 DONE%=",
           "s_branch ITER%="]
     # ---------------- refill pass (lane_pg_fused_kernel's protocol: one atomic for the wavefront's tickets)
-    o += ["REFILL%=:"] + stamp_begin(4) + [
-          "s_add_u32 %[srefills], %[srefills], 1",
-          "s_ff1_i32_b64 %[sa], %[swant]", "s_lshl_b64 exec, 1, %[sa]",
-          f"v_mov_b32 {sc[0].lo}, %[scnt]", f"v_mov_b32 {sc[0].hi}, 0"] + stamp_begin(1) + [
-          f"global_atomic_add {sc[1].lo}, {sc[0].hi}, {sc[0].lo}, %[pticket] sc0",
-          "s_waitcnt vmcnt(0)"] + stamp_end(1) + ["s_nop 1",
-          f"v_readfirstlane_b32 %[sfirst], {sc[1].lo}",
-          "s_mov_b64 exec, %[swant]",
-          f"v_mbcnt_lo_u32_b32 {sc[0].lo}, exec_lo, 0", f"v_mbcnt_hi_u32_b32 {sc[0].lo}, exec_hi, {sc[0].lo}",   # rank among the waiting lanes
-          f"v_add_u32 {sc[0].lo}, %[sfirst], {sc[0].lo}",          # ticket
-          f"v_cmp_le_u32_e64 vcc, %[snq], {sc[0].lo}",              # past the queue's end: exhausted
-          "s_or_b64 %[sexh], %[sexh], vcc",
-          "s_andn2_b64 %[snew], exec, vcc",
-          "s_mov_b64 exec, %[snew]",
-          "s_cbranch_execz RDONE%=",
-          f"v_lshlrev_b32 {sc[0].lo}, 2, {sc[0].lo}"] + stamp_begin(2) + [
-          f"global_load_dword {vk}, {sc[0].lo}, %[porder]",
-          "s_waitcnt vmcnt(0)"] + stamp_end(2) + ([f"v_accvgpr_write_b32 {AK}, {vk}"] if PARK else []) + [
-          f"v_mov_b32 {sc[0].hi}, {RL_BYTES}",
+    if not CHUNK:
+        o += ["REFILL%=:"] + stamp_begin(4) + [
+              "s_add_u32 %[srefills], %[srefills], 1",
+              "s_ff1_i32_b64 %[sa], %[swant]", "s_lshl_b64 exec, 1, %[sa]",
+              f"v_mov_b32 {sc[0].lo}, %[scnt]", f"v_mov_b32 {sc[0].hi}, 0"] + stamp_begin(1) + [
+              f"global_atomic_add {sc[1].lo}, {sc[0].hi}, {sc[0].lo}, %[pticket] sc0",
+              "s_waitcnt vmcnt(0)"] + stamp_end(1) + ["s_nop 1",
+              f"v_readfirstlane_b32 %[sfirst], {sc[1].lo}",
+              "s_mov_b64 exec, %[swant]",
+              f"v_mbcnt_lo_u32_b32 {sc[0].lo}, exec_lo, 0", f"v_mbcnt_hi_u32_b32 {sc[0].lo}, exec_hi, {sc[0].lo}",   # rank among the waiting lanes
+              f"v_add_u32 {sc[0].lo}, %[sfirst], {sc[0].lo}",          # ticket
+              f"v_cmp_le_u32_e64 vcc, %[snq], {sc[0].lo}",              # past the queue's end: exhausted
+              "s_or_b64 %[sexh], %[sexh], vcc",
+              "s_andn2_b64 %[snew], exec, vcc",
+              "s_mov_b64 exec, %[snew]",
+              "s_cbranch_execz RDONE%=",
+              f"v_lshlrev_b32 {sc[0].lo}, 2, {sc[0].lo}"] + stamp_begin(2) + [
+              f"global_load_dword {vk}, {sc[0].lo}, %[porder]",
+              "s_waitcnt vmcnt(0)"] + stamp_end(2) + ([f"v_accvgpr_write_b32 {AK}, {vk}"] if PARK else [])
+    else:
+        o += ["REFILL%=:"] + stamp_begin(4) + [
+              "s_add_u32 %[srefills], %[srefills], 1",
+              "s_sub_u32 %[sb], %[scend], %[scnext]",                    # tickets left in the wavefront's chunk
+              "s_cmp_lg_u32 %[sb], 0", "s_cbranch_scc1 RCHUNK%=",
+              # ---- a new chunk: max(CHUNK, waiting lanes) tickets with one atomic (lane_pg_fused_kernel's protocol)
+              f"s_max_u32 %[sb], %[scnt], {CHUNK}",
+              "s_ff1_i32_b64 %[sa], %[swant]", "s_lshl_b64 exec, 1, %[sa]",
+              f"v_mov_b32 {sc[0].lo}, %[sb]", f"v_mov_b32 {sc[0].hi}, 0"] + stamp_begin(1) + [
+              f"global_atomic_add {sc[1].lo}, {sc[0].hi}, {sc[0].lo}, %[pticket] sc0",
+              "s_waitcnt vmcnt(0)"] + stamp_end(1) + ["s_nop 1",
+              f"v_readfirstlane_b32 %[scbase], {sc[1].lo}",
+              "s_mov_b32 %[scnext], %[scbase]",
+              "s_add_u32 %[scend], %[scbase], %[sb]",
+              "s_min_u32 %[scend], %[scend], %[snq]", "s_max_u32 %[scend], %[scend], %[scnext]",   # the part of it inside the queue
+              "s_sub_u32 %[sb], %[scend], %[scnext]",
+              "s_cmp_eq_u32 %[sb], 0", "s_cbranch_scc1 REXH%=",
+              # its queue entries: lane j < sb loads entry j
+              "s_mov_b64 exec, -1",
+              f"v_mbcnt_lo_u32_b32 {sc[0].lo}, -1, 0", f"v_mbcnt_hi_u32_b32 {sc[0].lo}, -1, {sc[0].lo}",   # lane number
+              f"v_cmp_gt_u32_e64 vcc, %[sb], {sc[0].lo}", "s_mov_b64 exec, vcc",
+              f"v_add_u32 {sc[0].lo}, %[scbase], {sc[0].lo}", f"v_lshlrev_b32 {sc[0].lo}, 2, {sc[0].lo}"] + stamp_begin(2) + [
+              f"global_load_dword {sc[1].lo}, {sc[0].lo}, %[porder]",
+              "s_waitcnt vmcnt(0)"] + stamp_end(2) + [
+              f"v_accvgpr_write_b32 {AORD}, {sc[1].lo}",
+              "s_branch RCHUNK%=",
+              "REXH%=:",                                                  # the queue is empty: every waiting lane is exhausted
+              "s_or_b64 %[sexh], %[sexh], %[swant]", "s_branch RDONE%=",
+              # ---- min(left in the chunk, waiting lanes) lanes take the chunk's next tickets
+              "RCHUNK%=:",
+              "s_min_u32 %[sb], %[sb], %[scnt]",
+              "s_mov_b64 exec, %[swant]",
+              f"v_mbcnt_lo_u32_b32 {sc[0].lo}, exec_lo, 0", f"v_mbcnt_hi_u32_b32 {sc[0].lo}, exec_hi, {sc[0].lo}",   # rank among the waiting lanes
+              f"v_cmp_gt_u32_e64 vcc, %[sb], {sc[0].lo}",
+              "s_and_b64 %[snew], exec, vcc",
+              "s_sub_u32 %[sa], %[scnext], %[scbase]",
+              f"v_add_u32 {sc[0].lo}, %[sa], {sc[0].lo}", f"v_lshlrev_b32 {sc[0].lo}, 2, {sc[0].lo}",   # byte address of the lane that holds the entry
+              "s_add_u32 %[scnext], %[scnext], %[sb]",
+              "s_mov_b64 exec, -1",                                       # (ds_bpermute reads zero from a source lane outside EXEC)
+              f"v_accvgpr_read_b32 {sc[1].lo}, {AORD}", "s_nop 1",
+              f"ds_bpermute_b32 {sc[1].hi}, {sc[0].lo}, {sc[1].lo}",
+              "s_waitcnt lgkmcnt(0)",
+              "s_mov_b64 exec, %[snew]",
+              f"v_mov_b32 {vk}, {sc[1].hi}"] + ([f"v_accvgpr_write_b32 {AK}, {vk}"] if PARK else [])
+    o += [f"v_mov_b32 {sc[0].hi}, {RL_BYTES}",
           f"v_mad_u64_u32 {sc[1]}, vcc, {vk}, {sc[0].hi}, %[precs]"]      # &recs[k * RL]
     o += stamp_begin(3)
     for i in range(H):
@@ -281,6 +336,7 @@ def gen():
                + ("    uint32_t sdiag;\n" if DIAG else "") +
                "    uint64_t shave, sexh, swant, snew, stmp, sstop, sdonenow;\n"
                "    uint32_t scap, sleft, scnt, sfirst, sa, sb, scapf;\n"
+               + ("    uint32_t scnext, scend, scbase;\n" if CHUNK else "") +
                "    asm volatile(\n")
     for l in body:
         out.append(f'        "{l}\\n"\n')
@@ -288,6 +344,8 @@ def gen():
             '[shave] "=&s"(shave)', '[sexh] "=&s"(sexh)', '[swant] "=&s"(swant)', '[snew] "=&s"(snew)', '[stmp] "=&s"(stmp)',
             '[sstop] "=&s"(sstop)', '[sdonenow] "=&s"(sdonenow)', '[scap] "=&s"(scap)', '[sleft] "=&s"(sleft)', '[scnt] "=&s"(scnt)',
             '[sfirst] "=&s"(sfirst)', '[sa] "=&s"(sa)', '[sb] "=&s"(sb)', '[scapf] "=&s"(scapf)']
+    if CHUNK:
+        outs += ['[scnext] "=&s"(scnext)', '[scend] "=&s"(scend)', '[scbase] "=&s"(scbase)']
     ins = ['[precs] "s"(in.recs)', '[porder] "s"(in.order)', '[pticket] "s"(in.ticket)', '[pfront] "s"(in.front)', '[prear] "s"(in.rear)',
            '[piters] "s"(in.iters)', '[snq] "s"(in.n_queue)', '[smaxit] "s"(in.max_iter)',
            '[sgq0] "s"(in.gq0)', '[sgq1] "s"(in.gq1)', '[sgrs0] "s"(in.grs0)', '[sgrs1] "s"(in.grs1)', '[sgrl0] "s"(in.grl0)', '[sgrl1] "s"(in.grl1)',

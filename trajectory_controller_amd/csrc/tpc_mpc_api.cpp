@@ -1367,6 +1367,15 @@ int tpc_mpc_reserve(tpc_mpc_handle h, const tpc_mpc_params* p, int64_t n, int me
             int32_t* unused = nullptr;
             rc = cap_iters_buffer(h, n, &unused);
             if (rc) return rc;
+            // AUTO's presolve: its scratch, side stream and events (sized as presolve_begin / general_launch size them
+            // for two inputs and ld = n)
+            Presolve ps;
+            if (presolve_lambda(p) > 0.0 && presolve_share(h, n, &ps)) {
+                Workspace unused_ws;
+                char* side = nullptr;
+                rc = presolve_scratch(h, p->horizon, p->dtype, n, 2 * pad256(n * 8) + pad256(n * 4), &unused_ws, &side);
+                if (rc) return rc;
+            }
         }
         if (mem == TPC_MPC_HOST) {
             const int64_t col = pad256(n * (int64_t)esize(p->dtype)), icol = pad256(n * 4);

@@ -54,6 +54,12 @@ AG["z0lo"], AG["z0hi"] = f"a{_n}", f"a{_n + 1}"; _n += 2
 # 4.94 / 4.92 with chunks of 6 / 12 / 24 -- a pass that finds fewer tickets than waiting lanes leaves lanes idle, +1.2 % wave
 # iterations, and the waiting it saves was not the limit: the kernel is power-bound).  0 (shipped): a ticket draw per pass
 CHUNK = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+# CHECKS: after that many steps of the backward sweep, ask whether the stop test is already decided for the whole wavefront
+# (ubasm.Plan.backward) and if so finish the sweep without its 3 stop-test instructions per variable; "0" = never.  On the
+# headline batch the test is decided for all 64 lanes after 2 steps in 48 % of a wavefront's iterations, after 5 in 65 %
+# (tests/extended/stop_depth_stats.cpp + stop_depth_sim.py); one box, PG kernel: 4.78-4.80 ms without, 4.50-4.62 with any of
+# "1,2,4" "2,4" "2" "3" "2,5" "3,6", "1,2,3,5" and "1,2,3,4,6,9" 2 % behind those (profiles/r05_ab_checks.txt)
+CHECKS = [int(c) for c in (sys.argv[5] if len(sys.argv) > 5 else "2,5").split(",") if int(c) > 0]
 AORD = f"a{_n}"
 if CHUNK: _n += 1
 N_AGPR = _n
@@ -288,10 +294,17 @@ def gen_body():
           "s_sub_u32 %[sleft], %[scap], %[sit]", "s_sub_u32 %[sleft], %[sleft], 1"] + stamp_begin(5) + [   # iterations to the earliest cap, less one
           f"s_mov_b64 exec, {P.S['sexec']}",
           ".p2align 3", "LA%=:"]
-    o += P.forward("A") + P.backward("A", tailA)
-    o += ["LB%=:"] + P.forward("B") + P.backward("B", tailB)
+    chk = {k: "NTA" for k in CHECKS}
+    o += P.forward("A") + P.backward("A", tailA, checks=chk)
+    chk = {k: "NTB" for k in CHECKS}
+    o += ["LB%=:"] + P.forward("B") + P.backward("B", tailB, checks=chk)
     o += ["SA%=:"] + stop_block("LB%=", "XODD%=")
     o += ["SB%=:"] + stop_block("LA%=", "XEVEN%=")
+    if CHECKS:
+        # the rest of the sweep without the stop test (entered from the checks: no lane of the wavefront can stop in this iteration)
+        top = H - 1 - min(CHECKS)
+        o += [".p2align 3"] + P.backward("A", ["s_cbranch_scc1 XODD%=", "s_branch LB%="], notest_from=top, label="NTA")
+        o += [".p2align 3"] + P.backward("B", ["s_cbranch_scc1 XEVEN%=", "s_branch LA%="], notest_from=top, label="NTB")
     o += ["XODD%=:"] + [f"v_mov_b64 {V[q]}, {(Wz if q % 2 == 0 else Wy)[q // 2]}" for q in range(2 * NREG)]
     o += ["XEVEN%=:", "s_mov_b64 exec, -1"] + stamp_end(5) + [
           "s_sub_u32 %[sit], %[scap], %[sleft]", "s_sub_u32 %[sit], %[sit], 1",       # wave iterations so far

@@ -92,12 +92,19 @@ class Plan:
 
     # ---- the backward sweep: Unit::bwd_last / bwd (mpc.h:278-281), gradient (mpc.h:283), projected step (mpc.h:342),
     #      stop-test term, momentum step (mpc.h:343); at step 0 the stop test and the end of the iteration
-    def backward(self, half, tail):
+    #      `checks` (steps visited -> label prefix): after that many steps the sweep asks whether the stop test is already
+    #      DECIDED for every lane with work -- the running maximum has reached g eps, and mpc.h:310 needs every term below
+    #      it -- and if so goes on in the sweep WITHOUT the three stop-test instructions per variable (`notest_from`:
+    #      that version, from the given step down, entry labels prefix + step).  Same decisions, fewer instructions.
+    def backward(self, half, tail, checks=None, notest_from=None, label=None):
         C, S, A = self.C, self.S, self.A
         t0, t1, n0, n1, acc = self.t0, self.t1, self.n0, self.n1, self.acc
         o = []
         first = True
-        for i in range(self.H - 1, -1, -1):
+        test = notest_from is None
+        for i in range(self.H - 1 if test else notest_from, -1, -1):
+            if not test:
+                o += [f"{label}{i}%=:"]
             x0, x1 = self.X[2 * i], self.X[2 * i + 1]
             agpr = i >= self.NREG
             if agpr:
@@ -122,13 +129,14 @@ class Plan:
             o += bw
             o += [f"v_fma_f64 {py}, {S['sgrs0']}, {x0}, {C['cgl0']}",
                   f"v_fma_f64 {py}, {C['cc']}, {n1}, {py}",                 # df0
-                  f"v_fma_f64 {pz}, {C['cil'].neg()}, {py}, {x0} clamp",    # vn0
-                  f"v_add_f64 {s0}, {x0}, {pz.neg()}"]
-            if first:
-                o += [f"v_min_f64 {acc}, {py.abs()}, {s0.abs()}"]
-                first = False
-            else:
-                o += [f"v_min_f64 {s0}, {py.abs()}, {s0.abs()}", f"v_max_f64 {acc}, {acc}, {s0}"]
+                  f"v_fma_f64 {pz}, {C['cil'].neg()}, {py}, {x0} clamp"]    # vn0
+            if test:
+                o += [f"v_add_f64 {s0}, {x0}, {pz.neg()}"]
+                if first:
+                    o += [f"v_min_f64 {acc}, {py.abs()}, {s0.abs()}"]
+                    first = False
+                else:
+                    o += [f"v_min_f64 {s0}, {py.abs()}, {s0.abs()}", f"v_max_f64 {acc}, {acc}, {s0}"]
             if not last:
                 o += [f"v_add_f64 {o0}, {pz}, {o0.neg()}",             # vn0 - vold0
                       f"v_fma_f64 {x0}, {C['cb']}, {o0}, {pz} clamp"]
@@ -137,15 +145,28 @@ class Plan:
             o += [f"v_fma_f64 {d1}, {S['sgrs1']}, {x1}, {C['cgl1']}",
                   f"v_fma_f64 {d1}, {C['cc'].neg()}, {n1}, {d1}",
                   f"v_fma_f64 {d1}, {C['ca']}, {n0}, {d1}",                 # df1
-                  f"v_fma_f64 {py}, {C['cil'].neg()}, {d1}, {x1} clamp",    # vn1
-                  f"v_add_f64 {s1}, {x1}, {py.neg()}",
-                  f"v_min_f64 {s1}, {d1.abs()}, {s1.abs()}",
-                  f"v_max_f64 {acc}, {acc}, {s1}"]
+                  f"v_fma_f64 {py}, {C['cil'].neg()}, {d1}, {x1} clamp"]    # vn1
+            if test:
+                o += [f"v_add_f64 {s1}, {x1}, {py.neg()}",
+                      f"v_min_f64 {s1}, {d1.abs()}, {s1.abs()}",
+                      f"v_max_f64 {acc}, {acc}, {s1}"]
             if not last:
                 o += [f"v_add_f64 {o1}, {py}, {o1.neg()}",
                       f"v_fma_f64 {x1}, {C['cb']}, {o1}, {py} clamp"]
                 if agpr:
                     o += [f"v_accvgpr_write_b32 {A[f'av{2 * i + 1}lo']}, {py.lo}", f"v_accvgpr_write_b32 {A[f'av{2 * i + 1}hi']}, {py.hi}"]
+                if test and checks and (self.H - i) in checks:
+                    # decided = acc >= g eps (false for a NaN: such a lane stays undecided); every lane with work decided -> no stop this iteration
+                    o += [f"v_cmp_le_f64_e64 vcc, {S['sgeps']}, {acc}",
+                          f"s_andn2_b64 vcc, {S['shave']}, vcc",
+                          f"s_cbranch_scc0 {checks[self.H - i]}{i - 1}%="]
+            elif not test:
+                o += [f"v_add_f64 {o0}, {pz}, {o0.neg()}",
+                      f"v_fma_f64 {x0}, {C['cb']}, {o0}, {pz} clamp",
+                      f"v_add_f64 {o1}, {py}, {o1.neg()}",
+                      f"v_fma_f64 {x1}, {C['cb']}, {o1}, {py} clamp",
+                      f"s_sub_u32 {S['sleft']}, {S['sleft']}, 1"]
+                o += tail
             else:
                 # (e64: the loop's 4-byte instructions must come in PAIRS -- an 8-byte instruction that starts on an odd dword costs a
                 #  lone wavefront 5 cycles instead of 4, scripts/probes/issue_forms.py)

@@ -27,6 +27,7 @@ int main(int argc, char** argv) {
     if (!fi || fread(in.data(), 8, 3 * n, fi) != (size_t)(3 * n)) return 3;
     fclose(fi);
     FILE* fo = fopen(argv[3], "wb");
+    FILE* fx = getenv("STOP_DEPTH_FEATURES") ? fopen(getenv("STOP_DEPTH_FEATURES"), "wb") : nullptr;   // lambda, last CD max_df, PG iterations per instance
     const T q[2] = {1.0, 1.0}, r[2] = {1.0, 1.0};   // overwritten below from argv if given
     T qq[2] = {q[0], q[1]}, rr[2] = {r[0], r[1]};
     double step = 0.1, wb = 0.21, lo[2] = {-0.3665191429188092, -0.3665191429188092}, hi[2] = {0.3665191429188092, 0.3665191429188092};
@@ -46,6 +47,7 @@ int main(int argc, char** argv) {
         });
         unsigned long iter = 0;
         bool stopped = false, vinit = false;
+        double last_max_df = 0.0;
         for (unsigned long it = 0; it < smo_iters && !stopped; ++it) {
             T Z, Y;
             m.fwd_init(Z, Y);
@@ -65,12 +67,32 @@ int main(int argc, char** argv) {
                 const T mag = max_(up, dn);
                 if (mag > max_df) { max_df = mag; best = qv; }
             }
+            last_max_df = (double)max_df;
             if (max_df < eps) { stopped = true; break; }
             if (iqd[best] != (T)0) {
                 x[best] = m.project(fma_(-iqd[best], dd[best], x[best]), best & 1);
                 vinit = (it + 1 == smo_iters);
             }
             ++iter;
+        }
+        double feat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double accs[256];
+        for (int j = 0; j < 256; ++j) accs[j] = 0.0;
+        {   // features of the state the PG phase starts from: sums of the gradient over the horizon (smooth modes), bound counts
+            T Z, Y;
+            m.fwd_init(Z, Y);
+            for (int i = 0; i < H; ++i) { m.fwd(Z, Y, x[2 * i], x[2 * i + 1]); wz[i] = Z; wy[i] = Y; }
+            T n0, n1;
+            m.bwd_last(n0, n1, Z, Y);
+            for (int i = H - 1; i >= 0; --i) {
+                if (i < H - 1) m.bwd(n0, n1, wz[i], wy[i]);
+                const double d0 = (double)m.df0(n1, x[2 * i]), d1 = (double)m.df1(n0, n1, x[2 * i + 1]);
+                const bool b0 = x[2 * i] <= m.bl(0) || x[2 * i] >= m.bh(0), b1 = x[2 * i + 1] <= m.bl(1) || x[2 * i + 1] >= m.bh(1);
+                feat[0] += b0 ? 0 : d0; feat[1] += b1 ? 0 : d1;
+                feat[2] += b0 ? 0 : i * d0; feat[3] += b1 ? 0 : i * d1;
+                feat[4] += b0; feat[5] += b1;
+                feat[6] += b0 ? 0 : d0 * d0; feat[7] += b1 ? 0 : d1 * d1;
+            }
         }
         depth.clear();
         if (!stopped) {
@@ -81,6 +103,7 @@ int main(int argc, char** argv) {
             T il0, il1, beta;
             pg_constants<T>(lambda, m.s0, m.s1, il0, il1, beta);
             for (int i = 0; i < H; ++i) { vv[2 * i] = vinit ? x[2 * i] : m.xz0; vv[2 * i + 1] = vinit ? x[2 * i + 1] : m.xz1; }
+            unsigned long pgk = 0;
             while (true) {
                 T Z, Y;
                 m.fwd_init(Z, Y);
@@ -102,6 +125,8 @@ int main(int argc, char** argv) {
                     if (decided == H + 1 && !(acc < geps)) decided = H - i;
                 }
                 depth.push_back((unsigned char)decided);
+                if (pgk < 256) accs[pgk] = (double)(acc / g);
+                ++pgk;
                 if (acc < geps) break;
                 ++iter;
                 if (iter >= max_iter) break;
@@ -110,8 +135,10 @@ int main(int argc, char** argv) {
         const unsigned int cnt = (unsigned int)depth.size(), cd = (unsigned int)iter - (cnt ? cnt - 1 : 0);
         fwrite(&cnt, 4, 1, fo);
         fwrite(&cd, 4, 1, fo);
+        if (fx) { const double rec[3] = {(double)lambda, last_max_df, (double)cnt}; fwrite(rec, 8, 3, fx); fwrite(feat, 8, 8, fx); fwrite(accs, 8, 256, fx); }
         if (cnt) fwrite(depth.data(), 1, cnt, fo);
     }
     fclose(fo);
+    if (fx) fclose(fx);
     return 0;
 }

@@ -176,3 +176,28 @@ def test_presolve_prediction_wrong_in_both_directions(torch_cuda, oracle, eps, e
     assert bits_equal(f[exact], of[exact]) and bits_equal(r[exact], orr[exact])
     assert max(np.abs(f - of).max(), np.abs(r - orr).max()) <= 1e-9
     assert bool(flags & FLAG_MAX_ITER) == bool(capped.any())
+
+
+def test_reserve_covers_the_presolve(torch_cuda):
+    """tpc_mpc_reserve sizes everything a later solve of that shape needs -- AUTO's presolve scratch, side stream and
+    events included (tpc_mpc_api.cpp) -- so that no solve allocates (an allocation synchronises the device): free device
+    memory does not move across the first N = 40 AUTO solve after a reserve, and it did move in the reserve."""
+    from trajectory_controller_amd import MpcSolver
+    from trajectory_controller_amd.synth import compact_inputs
+    torch = torch_cuda
+    H, n = 40, 16384
+    v, dy, dphi = (torch.from_numpy(a).cuda() for a in compact_inputs(H, n, first=17))
+    with MpcSolver(horizon=H, device=0, algo="auto") as s:
+        s.set_profiling(True)
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        s.reserve(n)
+        torch.cuda.synchronize()
+        free1 = torch.cuda.mem_get_info()[0]
+        assert free0 - free1 >= 2 * n * 8 * 2 * H   # at least the records of the main scratch and of the presolve's own
+        f, r, it = s.solve_batch_compact(v, dy, dphi, want_iters=True)
+        torch.cuda.synchronize()
+        free2 = torch.cuda.mem_get_info()[0]
+        grown_by_torch = f.numel() * 8 * 2 + it.numel() * 4 + (4 << 20)   # the outputs torch allocated (its pool may grow in 2 MiB blocks)
+        assert free1 - free2 <= grown_by_torch, (free1 - free2, grown_by_torch)
+        assert s.last_kernel_times()[2] == GROUP

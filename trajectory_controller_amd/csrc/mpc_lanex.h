@@ -29,6 +29,8 @@
 // there the same trade as GROUP's against LANE_FMA -- a third of the latency for a third of the full-chip throughput.
 #pragma once
 
+#include <type_traits>
+
 #include "mpc_group.h"
 #include "mpc_lane.h"
 
@@ -217,8 +219,8 @@ __global__ __launch_bounds__(64, 1) void lanex_pg_kernel(CompactArgs g, Knobs kn
             // ---- gradient (mpc.h:283), dlib's mask and maximum (mpc.h:298-309), the speculative update (mpc.h:342-343)
             u0_prev[0] = u[0]; u0_prev[1] = u[1];
             T acc = (T)0;
-#pragma unroll
-            for (int l = 0; l < L; ++l) {
+            auto step = [&](int l, auto test_c) {
+                constexpr bool TEST = decltype(test_c)::value;
                 const T cn1 = m.c * nl1[l];
                 const T bt[2] = {cn1, m.a * nl0[l] - cn1};                               // CompactModel::btm
 #pragma unroll
@@ -226,15 +228,32 @@ __global__ __launch_bounds__(64, 1) void lanex_pg_kernel(CompactArgs g, Knobs kn
                     const int q = 2 * l + j;
                     const T uu = u[q];
                     const T dd = (mm[q] + bt[j]) + uu * m.R(j);                           // mpc.h:283
-                    const T up = (uu <= m.lo(j)) ? (T)0 : dd;                             // mpc.h:298-299
-                    const T dn = (uu >= m.hi(j)) ? (T)0 : -dd;
-                    acc = tmax(acc, tmax(up, dn));
+                    if constexpr (TEST) {
+                        const T up = (uu <= m.lo(j)) ? (T)0 : dd;                         // mpc.h:298-299
+                        const T dn = (uu >= m.hi(j)) ? (T)0 : -dd;
+                        acc = tmax(acc, tmax(up, dn));
+                    }
                     const T vn = clamp3(uu - inv_lambda * dd, m.lo(j), m.hi(j));          // mpc.h:342
                     u[q] = clamp3(vn + beta * (vn - vi[q]), m.lo(j), m.hi(j));            // mpc.h:343
                     vo[q] = vn;
                 }
+            };
+            // The stop test decided early (as in the hand-written kernel, scripts/ubasm.py): mpc.h:310 stops only if EVERY
+            // term is below eps, so a group one of whose lanes has a term >= eps after its chunk's first step goes on whatever
+            // the other terms are; when that holds for every group of the wavefront with an instance, the remaining steps
+            // run without dlib's mask and maximum (6 of 17 instructions per variable).  Instances on their way to the cap --
+            // what this kernel is mostly given -- are decided at once.
+            step(0, std::true_type{});
+            const int part = group_or<G>((active && acc >= eps) ? 1 : 0);
+            int go = 1;
+            if (ballot_b(have && part == 0) == 0ull) {
+#pragma unroll
+                for (int l = 1; l < L; ++l) step(l, std::false_type{});
+            } else {
+#pragma unroll
+                for (int l = 1; l < L; ++l) step(l, std::true_type{});
+                go = group_or<G>((!active || acc < eps) ? 0 : 1);                         // mpc.h:310-311 (a NaN maximum goes on)
             }
-            const int go = group_or<G>((!active || acc < eps) ? 0 : 1);                   // mpc.h:310-311 (a NaN maximum goes on)
             ++wave_iters;
             ++iter;
             const bool ends = go == 0 || iter >= kn.max_iter;                            // mpc.h:271
@@ -457,22 +476,35 @@ __global__ __launch_bounds__(64, 1) void lanexg_pg_kernel(GeneralArgs g, Knobs k
 #pragma unroll
             for (int j = 0; j < (STATE ? I * L : I); ++j) u0_prev[j] = u[j];
             T acc = (T)0;
-#pragma unroll
-            for (int l = 0; l < L; ++l) {
+            auto step = [&](int l, auto test_c) {
+                constexpr bool TEST = decltype(test_c)::value;
 #pragma unroll
                 for (int j = 0; j < I; ++j) {
                     const int q = I * l + j;
                     const T uu = u[q];
                     const T dd = (mm[q] + m.btm(j, nl0[l], nl1[l])) + uu * m.R(j);        // mpc.h:283
-                    const T up = (uu <= m.lo(j)) ? (T)0 : dd;                             // mpc.h:298-299
-                    const T dn = (uu >= m.hi(j)) ? (T)0 : -dd;
-                    acc = tmax(acc, tmax(up, dn));
+                    if constexpr (TEST) {
+                        const T up = (uu <= m.lo(j)) ? (T)0 : dd;                         // mpc.h:298-299
+                        const T dn = (uu >= m.hi(j)) ? (T)0 : -dd;
+                        acc = tmax(acc, tmax(up, dn));
+                    }
                     const T vn = clamp3(uu - inv_lambda * dd, m.lo(j), m.hi(j));          // mpc.h:342
                     u[q] = clamp3(vn + beta * (vn - vi[q]), m.lo(j), m.hi(j));            // mpc.h:343
                     vo[q] = vn;
                 }
+            };
+            // (the stop test decided early: see lanex_pg_kernel)
+            step(0, std::true_type{});
+            const int part = group_or<G>((active && acc >= eps) ? 1 : 0);
+            int go = 1;
+            if (ballot_b(have && part == 0) == 0ull) {
+#pragma unroll
+                for (int l = 1; l < L; ++l) step(l, std::false_type{});
+            } else {
+#pragma unroll
+                for (int l = 1; l < L; ++l) step(l, std::true_type{});
+                go = group_or<G>((!active || acc < eps) ? 0 : 1);                         // mpc.h:310-311
             }
-            const int go = group_or<G>((!active || acc < eps) ? 0 : 1);                   // mpc.h:310-311
             ++wave_iters;
             ++iter;
             const bool ends = go == 0 || iter >= kn.max_iter;                            // mpc.h:271

@@ -47,6 +47,10 @@ import os
 import sys
 import time
 
+# dmabuf IPC (the only kind this pool's host driver supports): RCCL between the ranks of one node needs it; the driver's
+# environment has it already -- this is for a launch from a bare shell
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -47,7 +47,7 @@ int main(int argc, char** argv) {
         });
         unsigned long iter = 0;
         bool stopped = false, vinit = false;
-        double last_max_df = 0.0;
+        double last_max_df = 0.0, first_max_df = 0.0;
         for (unsigned long it = 0; it < smo_iters && !stopped; ++it) {
             T Z, Y;
             m.fwd_init(Z, Y);
@@ -68,6 +68,7 @@ int main(int argc, char** argv) {
                 if (mag > max_df) { max_df = mag; best = qv; }
             }
             last_max_df = (double)max_df;
+            if (it == 0) first_max_df = (double)max_df;
             if (max_df < eps) { stopped = true; break; }
             if (iqd[best] != (T)0) {
                 x[best] = m.project(fma_(-iqd[best], dd[best], x[best]), best & 1);
@@ -135,7 +136,7 @@ int main(int argc, char** argv) {
         const unsigned int cnt = (unsigned int)depth.size(), cd = (unsigned int)iter - (cnt ? cnt - 1 : 0);
         fwrite(&cnt, 4, 1, fo);
         fwrite(&cd, 4, 1, fo);
-        if (fx) { const double rec[3] = {(double)lambda, last_max_df, (double)cnt}; fwrite(rec, 8, 3, fx); fwrite(feat, 8, 8, fx); fwrite(accs, 8, 256, fx); }
+        if (fx) { const double rec[3] = {(double)lambda, last_max_df, (double)cnt}; fwrite(rec, 8, 3, fx); fwrite(&first_max_df, 8, 1, fx); fwrite(feat, 8, 8, fx); fwrite(accs, 8, 256, fx); }
         if (cnt) fwrite(depth.data(), 1, cnt, fo);
     }
     fclose(fo);

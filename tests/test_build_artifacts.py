@@ -63,3 +63,43 @@ def test_auto_table_matches_its_records():
             derived[(form, 0 if m.group(1) == "f64" else 1, int(m.group(2)))] = (
                 val(m.group(3)), val(m.group(4)), val(m.group(5)), val(m.group(6)), int(m.group(7)) if m.group(7) else never)
     assert derived == rows, {k: (rows.get(k), derived.get(k)) for k in set(rows) | set(derived) if rows.get(k) != derived.get(k)}
+
+
+def test_hand_written_kernel_header_is_what_its_generator_writes():
+    """csrc/mpc_ub_pg_asm.h is GENERATED (scripts/gen_ub_pg_asm.py + scripts/ubasm.py, `make -C csrc regen`): the committed
+    header must be the generator's output for the shipped arguments -- a hand edit of either side alone fails -- and the
+    stream it holds must keep the properties the kernel's speed rests on: every instruction of the loop 8 bytes long except
+    an even number of 4-byte scalar ones per half (an 8-byte instruction starting on an odd dword costs a fifth cycle), no
+    register copy in the loop, and the no-stop-test copies of the sweep free of stop-test instructions."""
+    import subprocess
+    gen = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_ub_pg_asm.py"), "3"], capture_output=True, text=True, timeout=120)
+    assert gen.returncode == 0, gen.stderr[-2000:]
+    committed = open(os.path.join(ROOT, "trajectory_controller_amd", "csrc", "mpc_ub_pg_asm.h")).read()
+    assert gen.stdout == committed
+    lines = [l.strip().strip('"').replace("\\n", "") for l in committed.splitlines() if l.strip().startswith('"')]
+    la, lb, sa = lines.index("LA%=:"), lines.index("LB%=:"), lines.index("SA%=:")
+    four_byte = ("s_and_b64", "s_andn2_b64", "s_mov_b64", "s_sub_u32", "s_cbranch", "s_branch", "s_add_u32", "s_or_b64", "s_cmp")
+    def walk(block):
+        """byte offsets of a block that starts on an 8-byte boundary: every 8-byte instruction on an even dword; returns its size"""
+        off = 0
+        for l in block:
+            if l.endswith(":") or l.startswith("."): continue
+            if l.startswith(four_byte): off += 4
+            else:
+                assert l.startswith("v_") and l.split()[0].endswith(("_f64", "_e64", "_b32")), l   # (VOP3 / accvgpr: 8 bytes)
+                assert off % 8 == 0, (off, l)
+                off += 8
+        return off
+    half_a, half_b = lines[la + 1:lb], lines[lb + 1:sa]
+    assert lines[la - 1] == ".p2align 3"
+    assert walk(half_a) % 8 == 0   # (LB follows half A directly)
+    walk(half_b)
+    for half in (half_a, half_b):
+        assert not any(l.startswith(("v_mov_b64", "v_mov_b32")) for l in half)
+    nta, ntb = lines.index(next(l for l in lines if l.startswith("NTA") and l.endswith("%=:"))), lines.index(next(l for l in lines if l.startswith("NTB") and l.endswith("%=:")))
+    xodd = lines.index("XODD%=:")
+    for first, copy in ((nta, lines[nta:ntb]), (ntb, lines[ntb:xodd])):
+        assert lines[first - 1] == ".p2align 3"
+        walk(copy)
+        assert not any(l.startswith(("v_min_f64", "v_max_f64", "v_cmp")) for l in copy)
+        assert sum(l.startswith("v_fma_f64") for l in copy) > 100

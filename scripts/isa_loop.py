@@ -2,7 +2,11 @@
 """Static look at a kernel's hottest loop in a hipcc `-save-temps` .s file (or llvm-objdump -d text):
 instruction histogram of the largest innermost loop body (the label..backward-branch span with the most
 instructions that contains no other backward branch).
-    python scripts/isa_loop.py file.s kernel_name_substring [...]"""
+    python scripts/isa_loop.py file.s kernel_name_substring [...]
+    python scripts/isa_loop.py --asm-kernel [trajectory_controller_amd/lib/obj/ub_asm.o]
+        the hand-written headline kernel (csrc/mpc_ub_pg_asm.h) as it sits in the shipped object: its labels survive
+        as symbols, so the two halves of the loop (LA..LB, LB..SA), the no-stop-test copies of the sweep (NTA*, NTB*)
+        and the addresses they start on are read off llvm-objdump -d"""
 import collections, re, sys
 
 def kernels(path):
@@ -56,7 +60,48 @@ def classify(op):
     if op.startswith("v_"): return "valu_other"
     return "other"
 
+def asm_kernel(obj):
+    import os, subprocess, tempfile
+    llvm = "/opt/rocm/lib/llvm/bin/"
+    with tempfile.TemporaryDirectory() as td:
+        o = os.path.join(td, "k.o")
+        open(o, "wb").write(open(obj, "rb").read())
+        subprocess.run([llvm + "llvm-objdump", "--offloading", o], cwd=td, capture_output=True)
+        co = [f for f in os.listdir(td) if "gfx950" in f]
+        assert co, "no gfx950 code object in " + obj
+        text = subprocess.run([llvm + "llvm-objdump", "-d", os.path.join(td, co[0])], capture_output=True, text=True).stdout
+    blocks, cur = collections.OrderedDict(), None
+    for l in text.splitlines():
+        m = re.match(r"^([0-9a-f]+) <(\w+)>:", l)
+        if m:
+            cur = m.group(2); blocks[cur] = (int(m.group(1), 16), [])
+            continue
+        if cur and l.startswith("\t"):
+            blocks[cur][1].append(l.strip().split("//")[0].strip())
+    def span(first, until):
+        names = list(blocks); a, b = names.index(first), names.index(until)
+        return [i for n in names[a:b] for i in blocks[n][1]]
+    def show(title, ins, addr):
+        h = collections.Counter(classify(i.split()[0]) for i in ins)
+        ops = collections.Counter(i.split()[0] for i in ins)
+        print(f"{title}: {len(ins)} instructions at {addr:#x} (mod 8 = {addr % 8})  {dict(h)}")
+        print("    " + ", ".join(f"{k}:{v}" for k, v in ops.most_common(12)))
+    show("half A (LA..LB)", span("LA0", "LB0"), blocks["LA0"][0])
+    show("half B (LB..SA)", span("LB0", "SA0"), blocks["LB0"][0])
+    nta = [n for n in blocks if n.startswith("NTA")]; ntb = [n for n in blocks if n.startswith("NTB")]
+    if nta:
+        show(f"no-stop-test copy A ({nta[0]}..)", span(nta[0], ntb[0]), blocks[nta[0]][0])
+        after = list(blocks)[list(blocks).index(ntb[-1]) + 1]
+        show(f"no-stop-test copy B ({ntb[0]}..)", span(ntb[0], after), blocks[ntb[0]][0])
+        print("    entries:", " ".join(f"{n}@{blocks[n][0] % 8}" for n in (nta + ntb) if any(i.split()[-1] == n for i in span("LA0", "SA0"))))
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "--asm-kernel":
+        import os
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        asm_kernel(sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "trajectory_controller_amd", "lib", "obj", "ub_asm.o"))
+        sys.exit(0)
     ks = kernels(sys.argv[1])
     for name, body in ks.items():
         if not all(p in name for p in sys.argv[2:]):

@@ -27,12 +27,13 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import ubasm
 
-H = 20
+H = int(sys.argv[6]) if len(sys.argv) > 6 else 20   # 20: the headline kernel (mpc_ub_pg_asm.h); 10: mpc_ub_pg_asm_h10.h (the state fits the VGPRs: NA = 0)
+SUFFIX = "" if H == 20 else f"_h{H}"
 NA = int(sys.argv[1]) if len(sys.argv) > 1 else 3   # steps H-NA .. H-1 keep v in AGPRs
 DIAG = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # diagnostic builds only (scripts/build_asm_variant.sh): the wave-iteration statistic
                                                       # becomes the shader cycles spent in: 1 ticket wait, 2 queue-entry wait, 3 record wait, 4 a whole refill pass, 5 the iteration loop
-BATCH = 3                                            # lanes that must wait before a refill pass is due (UbRefillBatch<20>)
-RL_BYTES = 400                                       # LaneRec<double, 20>::kLen * 8
+BATCH = int(sys.argv[7]) if len(sys.argv) > 7 else (3 if H == 20 else 10)   # lanes that must wait before a refill pass is due (N = 10, 1 048 576 instances: 3.94 / 2.54 / 2.19 / 2.24 ms at 3 / 6 / 10 / 16)
+RL_BYTES = (2 * H + 1 + 1 + 7 + 1) // 2 * 2 * 8     # LaneRec<double, H>::kLen * 8 (400 at N = 20)
 P = ubasm.Plan(H=H, NA=NA, batch=BATCH, all_hard=True)
 NREG = P.NREG
 X, V, Wz, Wy, t0, t1, n0, n1, acc, C = P.X, P.V, P.Wz, P.Wy, P.t0, P.t1, P.n0, P.n1, P.acc, P.C
@@ -40,7 +41,11 @@ X, V, Wz, Wy, t0, t1, n0, n1, acc, C = P.X, P.V, P.Wz, P.Wy, P.t0, P.t1, P.n0, P
 # iterations).  With room (NA >= 4) in the last VGPRs; with NA = 3 the loop's state fills all 256 and they live in AGPRs
 PARK = P.top > 252
 assert P.top <= 256
-VK, VBASE, VCAP, VTMP = ("v252", "v253", "v254", "v255") if not PARK else (None, None, None, n0.lo)
+# (N = 20: the last four of the 256; a horizon whose state leaves room keeps them right above it, so that the statement claims
+#  only the registers it uses and several wavefronts fit a SIMD -- at N = 10 the second one hides the refill passes)
+_BK = 252 if H == 20 else P.top
+NVGPR = 256 if H == 20 else P.top + 4
+VK, VBASE, VCAP, VTMP = (f"v{_BK}", f"v{_BK + 1}", f"v{_BK + 2}", f"v{_BK + 3}") if not PARK else (None, None, None, n0.lo)
 # AGPRs: v of the AGPR steps, z0
 AG = {}
 _n = 3 if PARK else 0
@@ -335,17 +340,21 @@ def gen():
     out = []
     out.append("// GENERATED by scripts/gen_ub_pg_asm.py -- do not edit (make -C csrc regen).  The persistent projected-gradient kernel\n"
                "// of ub_pg_kernel<double, %d, true, 2> (mpc_ub.h) as one asm statement with hand-assigned registers; arithmetic:\n"
-               "// mpc_ub_model.h, operation for operation.  %d instructions per iteration (the compiler's loop: 708); v of steps\n"
-               "// %d..%d in AGPRs.  Register plan and reasons: scripts/gen_ub_pg_asm.py, scripts/ubasm.py.\n"
-               "#pragma once\n\nnamespace tpc {\n\n" % (H, n_iter, NREG, H - 1))
-    out.append(f"constexpr int kUbAsmH = {H}, kUbAsmIterInstrs = {n_iter}, kUbAsmBatch = {BATCH};\n\n")
-    out.append("struct UbAsmIn {\n"
-               "    const double* recs; const uint32_t* order; uint32_t* ticket; double* front; double* rear; int32_t* iters;\n"
-               "    uint32_t n_queue, max_iter;\n"
-               "    double gq0, gq1, grs0, grs1, grl0, grl1, lo0, lo1, hi0, hi1, s0, s1, xz0, xz1, geps;   // wave-uniform: MUST reach the asm in SGPRs (kernel arguments)\n"
-               "};\n"
-               "// Runs the whole queue (every lane of the wavefront must be live).  Out: wave iterations, refill passes, TPC_MPC_FLAG bits.\n"
-               "TPC_DEV void ub_pg_asm_run(const UbAsmIn& in, uint32_t& wave_iters, uint32_t& refills, uint32_t& flags) {\n"
+               "// mpc_ub_model.h, operation for operation.  %d instructions per iteration%s; v of steps\n"
+               "// %s in AGPRs.  Register plan and reasons: scripts/gen_ub_pg_asm.py, scripts/ubasm.py.\n"
+               "#pragma once\n\nnamespace tpc {\n\n" % (H, n_iter, " (the compiler's loop: 708)" if H == 20 else "",
+                                                      f"{NREG}..{H - 1}" if NA else "none"))
+    out.append(f"constexpr int kUbAsmH{SUFFIX} = {H}, kUbAsmIterInstrs{SUFFIX} = {n_iter}, kUbAsmBatch{SUFFIX} = {BATCH};\n\n")
+    if H == 20:
+        out.append("struct UbAsmIn {\n"
+                   "    const double* recs; const uint32_t* order; uint32_t* ticket; double* front; double* rear; int32_t* iters;\n"
+                   "    uint32_t n_queue, max_iter;\n"
+                   "    double gq0, gq1, grs0, grs1, grl0, grl1, lo0, lo1, hi0, hi1, s0, s1, xz0, xz1, geps;   // wave-uniform: MUST reach the asm in SGPRs (kernel arguments)\n"
+                   "};\n")
+    else:
+        out.append("// (UbAsmIn: mpc_ub_pg_asm.h, included first by mpc_ub_asm.h)\n")
+    out.append("// Runs the whole queue (every lane of the wavefront must be live).  Out: wave iterations, refill passes, TPC_MPC_FLAG bits.\n"
+               "TPC_DEV void ub_pg_asm_run%s(const UbAsmIn& in, uint32_t& wave_iters, uint32_t& refills, uint32_t& flags) {\n" % SUFFIX
                + ("    uint32_t sdiag;\n" if DIAG else "") +
                "    uint64_t shave, sexh, swant, snew, stmp, sstop, sdonenow;\n"
                "    uint32_t scap, sleft, scnt, sfirst, sa, sb, scapf;\n"
@@ -364,7 +373,7 @@ def gen():
            '[sgq0] "s"(in.gq0)', '[sgq1] "s"(in.gq1)', '[sgrs0] "s"(in.grs0)', '[sgrs1] "s"(in.grs1)', '[sgrl0] "s"(in.grl0)', '[sgrl1] "s"(in.grl1)',
            '[slo0] "s"(in.lo0)', '[slo1] "s"(in.lo1)', '[shi0] "s"(in.hi0)', '[shi1] "s"(in.hi1)', '[ss0] "s"(in.s0)', '[ss1] "s"(in.s1)',
            '[sxz0] "s"(in.xz0)', '[sxz1] "s"(in.xz1)', '[sgeps] "s"(in.geps)']
-    clob = [f'"v{r}"' for r in range(256)] + [f'"a{r}"' for r in range(N_AGPR)] + ['"vcc"', '"scc"', '"memory"']
+    clob = [f'"v{r}"' for r in range(NVGPR)] + [f'"a{r}"' for r in range(N_AGPR)] + ['"vcc"', '"scc"', '"memory"']
     if DIAG:
         outs.append('[sdiag] "=&s"(sdiag)')
         clob += ['"s96"', '"s97"', '"s98"', '"s99"']

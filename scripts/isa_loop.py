@@ -86,15 +86,23 @@ def asm_kernel(obj):
         ops = collections.Counter(i.split()[0] for i in ins)
         print(f"{title}: {len(ins)} instructions at {addr:#x} (mod 8 = {addr % 8})  {dict(h)}")
         print("    " + ", ".join(f"{k}:{v}" for k, v in ops.most_common(12)))
-    show("half A (LA..LB)", span("LA0", "LB0"), blocks["LA0"][0])
-    show("half B (LB..SA)", span("LB0", "SA0"), blocks["LB0"][0])
-    nta = [n for n in blocks if n.startswith("NTA")]; ntb = [n for n in blocks if n.startswith("NTB")]
-    if nta:
-        show(f"no-stop-test copy A ({nta[0]}..)", span(nta[0], ntb[0]), blocks[nta[0]][0])
-        after = list(blocks)[list(blocks).index(ntb[-1]) + 1]
-        show(f"no-stop-test copy B ({ntb[0]}..)", span(ntb[0], after), blocks[ntb[0]][0])
-        print("    entries:", " ".join(f"{n}@{blocks[n][0] % 8}" for n in (nta + ntb) if any(i.split()[-1] == n for i in span("LA0", "SA0"))))
-
+    names = list(blocks)
+    for sfx in sorted({n[2:] for n in names if re.fullmatch(r"LA\d+", n)}, key=int):   # one asm statement per kernel: its labels end in its number
+        kern = [n for n in names[:names.index("LA" + sfx)] if n.startswith("_Z")][-1]
+        print(f"== {kern}")
+        show("half A (LA..LB)", span("LA" + sfx, "LB" + sfx), blocks["LA" + sfx][0])
+        show("half B (LB..SA)", span("LB" + sfx, "SA" + sfx), blocks["LB" + sfx][0])
+        nta = [n for n in names if re.fullmatch(r"NTA\d+" + sfx, n) and len(n) > 3 + len(sfx)]
+        ntb = [n for n in names if re.fullmatch(r"NTB\d+" + sfx, n) and len(n) > 3 + len(sfx)]
+        # (a label NTA17 of statement 0 prints as NTA170: keep those whose step number is a horizon step and whose address follows LA of this statement)
+        lo = blocks["SA" + sfx][0]
+        nxt = min([blocks[n][0] for n in names if n.startswith("_Z") and blocks[n][0] > lo] + [1 << 62])
+        nta = [n for n in nta if lo < blocks[n][0] < nxt]; ntb = [n for n in ntb if lo < blocks[n][0] < nxt]
+        if nta and ntb:
+            show(f"no-stop-test copy A ({nta[0]}..)", span(nta[0], ntb[0]), blocks[nta[0]][0])
+            show(f"no-stop-test copy B ({ntb[0]}..)", span(ntb[0], "XODD" + sfx), blocks[ntb[0]][0])
+            loop = span("LA" + sfx, "SA" + sfx)
+            print("    entries:", " ".join(f"{n}@{blocks[n][0] % 8}" for n in (nta + ntb) if any(i.split()[-1] == n for i in loop)))
 
 if __name__ == "__main__":
     if sys.argv[1] == "--asm-kernel":

@@ -52,7 +52,7 @@ def test_auto_table_matches_its_records():
     assert len(rows) == 12 and all(len(r) == 5 for r in rows.values())
     never = 1 << 40
     derived = {}
-    for form, records in ((0, "profiles/r04_crossover.txt,profiles/r04_crossover_top.txt,profiles/r04_crossover_f32.txt,profiles/r04_crossover_f32_top.txt"),
+    for form, records in ((0, "profiles/r04_crossover.txt,profiles/r04_crossover_top.txt,profiles/r04_crossover_f32.txt,profiles/r04_crossover_f32_top.txt,profiles/r05_crossover_h10.txt"),
                           (1, "profiles/r04_crossover_general.txt,profiles/r04_crossover_general_top.txt")):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "measure_crossover.py"), "--from-record", records],
                              cwd=ROOT, capture_output=True, text=True, timeout=300)
@@ -65,16 +65,18 @@ def test_auto_table_matches_its_records():
     assert derived == rows, {k: (rows.get(k), derived.get(k)) for k in set(rows) | set(derived) if rows.get(k) != derived.get(k)}
 
 
-def test_hand_written_kernel_header_is_what_its_generator_writes():
-    """csrc/mpc_ub_pg_asm.h is GENERATED (scripts/gen_ub_pg_asm.py + scripts/ubasm.py, `make -C csrc regen`): the committed
+@pytest.mark.parametrize("header, fmas", [("mpc_ub_pg_asm.h", 100), ("mpc_ub_pg_asm_h10.h", 50)])
+def test_hand_written_kernel_header_is_what_its_generator_writes(header, fmas):
+    """csrc/mpc_ub_pg_asm.h (N = 20) and mpc_ub_pg_asm_h10.h are GENERATED (scripts/gen_ub_pg_asm.py + scripts/ubasm.py, `make -C csrc regen`): the committed
     header must be the generator's output for the shipped arguments -- a hand edit of either side alone fails -- and the
     stream it holds must keep the properties the kernel's speed rests on: every instruction of the loop 8 bytes long except
     an even number of 4-byte scalar ones per half (an 8-byte instruction starting on an odd dword costs a fifth cycle), no
     register copy in the loop, and the no-stop-test copies of the sweep free of stop-test instructions."""
     import subprocess
-    gen = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_ub_pg_asm.py"), "3"], capture_output=True, text=True, timeout=120)
+    gen_args = {"mpc_ub_pg_asm.h": ["3"], "mpc_ub_pg_asm_h10.h": ["0", "0", "0", "0", "2,5", "10"]}[header]   # (csrc/Makefile, regen)
+    gen = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_ub_pg_asm.py")] + gen_args, capture_output=True, text=True, timeout=120)
     assert gen.returncode == 0, gen.stderr[-2000:]
-    committed = open(os.path.join(ROOT, "trajectory_controller_amd", "csrc", "mpc_ub_pg_asm.h")).read()
+    committed = open(os.path.join(ROOT, "trajectory_controller_amd", "csrc", header)).read()
     assert gen.stdout == committed
     lines = [l.strip().strip('"').replace("\\n", "") for l in committed.splitlines() if l.strip().startswith('"')]
     la, lb, sa = lines.index("LA%=:"), lines.index("LB%=:"), lines.index("SA%=:")
@@ -102,4 +104,4 @@ def test_hand_written_kernel_header_is_what_its_generator_writes():
         assert lines[first - 1] == ".p2align 3"
         walk(copy)
         assert not any(l.startswith(("v_min_f64", "v_max_f64", "v_cmp")) for l in copy)
-        assert sum(l.startswith("v_fma_f64") for l in copy) > 100
+        assert sum(l.startswith("v_fma_f64") for l in copy) > fmas

@@ -12,6 +12,7 @@
 namespace tpc {
 
 hipError_t ub_pg_asm_launch(const CompactArgs& a, const Knobs& k, const Workspace& ws, int64_t need, hipStream_t s);
+hipError_t ub_pg_asm_launch_h10(const CompactArgs& a, const Knobs& k, const Workspace& ws, int64_t need, hipStream_t s);
 
 namespace {
 
@@ -61,10 +62,10 @@ template <typename T, bool EQB, int MODE>
 hipError_t pg_launch(const CompactArgs& a, const Knobs& k, const Workspace& ws, hipStream_t s) {
     constexpr int bt = kWave * UbPlan<T, kH>::occ;
     const int64_t need = (a.n + bt - 1) / bt;
-#if TPC_UB_H == 20 && !defined(TPC_UB_NO_ASM)   // (TPC_UB_NO_ASM: the compiler's loop, for A/B runs -- scripts/build_ub_variant.sh)
-    if constexpr (sizeof(T) == 8 && EQB && MODE == 2) {   // mpc_ub_asm.h: the same kernel, 530 instructions per iteration instead of 708
-        static_assert(bt == kWave, "one wavefront per workgroup");
-        return ub_pg_asm_launch(a, k, ws, need, s);   // (its own translation unit: mpc_ub_asm_inst.hip)
+#if (TPC_UB_H == 20 || TPC_UB_H == 10) && !defined(TPC_UB_NO_ASM)   // (TPC_UB_NO_ASM: the compiler's loop, for A/B runs -- scripts/build_ub_variant.sh)
+    if constexpr (sizeof(T) == 8 && EQB && MODE == 2) {   // mpc_ub_asm.h: the same kernel written by hand (N = 20: 536 instructions per iteration instead of 708)
+        const int64_t waves = (a.n + kWave - 1) / kWave;  // one wavefront per workgroup (its own translation unit: mpc_ub_asm_inst.hip)
+        return kH == 20 ? ub_pg_asm_launch(a, k, ws, waves, s) : ub_pg_asm_launch_h10(a, k, ws, waves, s);
     }
 #endif
     int cap = ub_grid<TagPg<T, EQB, MODE>>(ub_pg_kernel<T, kH, EQB, MODE>, bt);

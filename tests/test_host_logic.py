@@ -214,7 +214,11 @@ def solve(a, b, c):
 front, rear = solve_sharded(solve, v, dy, dphi)
 ef, er, _ = orc.solve_compact(H, v.numpy(), dy.numpy(), dphi.numpy())
 assert np.array_equal(front.numpy(), ef) and np.array_equal(rear.numpy(), er)
-print("rank", dist.get_rank(), "ok")
+for turn in range(2):
+    dist.barrier()
+    if turn == dist.get_rank():
+        sys.stdout.write("rank %d ok\n" % turn); sys.stdout.flush()
+dist.barrier()
 dist.destroy_process_group()
 '''
 
@@ -262,13 +266,17 @@ for split in ("block", "interleaved"):
     dist.all_gather(both, t)
     a, b = int(both[0]), int(both[1])
     ratio = max(a, b) / min(a, b)
-    if dist.get_rank() == 0:
-        print(split, "iteration totals per rank", a, b, "max/min %.3f" % ratio)
+    if dist.get_rank() == 0:   # (one write per line, and the other rank silent until the barrier below: the launcher interleaves the ranks' output)
+        sys.stdout.write("%s iteration totals per rank %d %d max/min %.3f\n" % (split, a, b, ratio)); sys.stdout.flush()
     if split == "block":
         assert ratio > 2.0, ratio              # one rank gets the slow half
     else:
         assert ratio < 1.05, ratio
-print("rank", dist.get_rank(), "ok")
+for turn in range(2):
+    dist.barrier()
+    if turn == dist.get_rank():
+        sys.stdout.write("rank %d ok\n" % turn); sys.stdout.flush()
+dist.barrier()
 dist.destroy_process_group()
 '''
 

@@ -226,6 +226,30 @@ def test_ub_full_batch_vs_bit_exact_family(torch_cuda):
     assert torch.equal(f, f2) and torch.equal(r, r2) and torch.equal(it, it2)
 
 
+def test_ub_h10_both_builds_of_the_hand_written_kernel(torch_cuda, model):
+    """N = 10, fp64: the hand-written kernel has two builds of one statement (csrc/mpc_ub_asm.h) -- the whole register file
+    per wavefront below six instances per lane, three wavefronts per SIMD above.  524 288 instances take the second, their
+    first 98 304 alone the first: the same outputs bit for bit on the common instances, equal to the bit-exact LANE family's
+    iteration counts everywhere (|du| <= 1e-9), and the first 4 096 bit-identical to the CPU model of the arithmetic."""
+    from trajectory_controller_amd.synth import compact_inputs
+    torch = torch_cuda
+    H, n, m = 10, 524288, 98304
+    v, dy, dphi = compact_inputs(H, n)
+    tv, ty, tp = (torch.from_numpy(a).to("cuda:0") for a in (v, dy, dphi))
+    with _solver(H, "lane") as s:
+        lf, lr, lit = s.solve_batch_compact(tv, ty, tp, want_iters=True)
+    with _solver(H, "lane_fma") as s:
+        f, r, it = s.solve_batch_compact(tv, ty, tp, want_iters=True)
+        g, h, jt = s.solve_batch_compact(tv[:m].contiguous(), ty[:m].contiguous(), tp[:m].contiguous(), want_iters=True)
+    assert torch.equal(it, lit)
+    assert float(torch.maximum((f - lf).abs().max(), (r - lr).abs().max())) <= UB_ATOL
+    assert torch.equal(f[:m], g) and torch.equal(r[:m], h) and torch.equal(it[:m], jt)
+    k = 4096
+    mf, mr, mit, _ = model.solve_compact(H, v[:k], dy[:k], dphi[:k], nthreads=8)
+    assert np.array_equal(it[:k].cpu().numpy(), mit)
+    assert bits_equal(f[:k].cpu().numpy(), mf) and bits_equal(r[:k].cpu().numpy(), mr)
+
+
 def test_ub_fp32_full_batch_tolerance(torch_cuda, oracle32):
     """BASELINE config 3 as written (262 144 x N = 20, fp32): properties on the full batch, and the first
     4 096 instances against the float-typed restatement -- a tolerance statement (fp32 is unpinned)."""
